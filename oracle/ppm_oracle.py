@@ -1,0 +1,454 @@
+"""CPU ORACLE for the PPMStereo hot path -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A from-scratch restatement (torch CPU ops, fp32) of the reference algorithm on the path
+``PPMStereo.forward_update_block`` and its callees.  Only ``tests/``, ``__graft_entry__.smoke()``
+and ``bench.py``'s ``cpu_baseline`` leg may import this module; the product path
+(``ppmstereo_amd``) never does and fails loudly when its HIP library is missing.
+
+Parity status: PINNED.  ``tools/gen_golden.py`` imports the reference itself in the build container
+(with the four import shims of SURVEY.md Appendix A), runs it on seeded inputs and procedural
+weights and commits the resulting vectors under ``tests/golden/``; ``tests/test_oracle_golden.py``
+checks every function here against them.  The one third-party piece, ``flash_attn.flash_attn_func``
+(un-vendored, un-pinned; call site /root/reference/models/core/ppmstereo.py:550), is restated from its
+published semantics: softmax(Q K^T * scale) V with fp32 softmax/accumulate, bf16 in, bf16 out.
+
+Every function cites the reference file:line it follows (paths relative to /root/reference).
+Weights are passed as dicts keyed by the reference ``state_dict`` names (see
+``ppmstereo_amd/weights.py``).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+TOP_K = 5  # models/core/ppmstereo.py:445
+
+
+# --------------------------------------------------------------------------------------
+# correlation pyramid  (models/core/corr.py)
+# --------------------------------------------------------------------------------------
+def coords_grid(batch: int, ht: int, wd: int) -> Tensor:
+    """corr.py:47-52 -- (B,2,H,W): channel 0 = x index, channel 1 = y index."""
+    ys, xs = torch.meshgrid(torch.arange(ht), torch.arange(wd), indexing="ij")
+    return torch.stack([xs, ys], 0).float()[None].repeat(batch, 1, 1, 1)
+
+
+def corr_volume(fmap1: Tensor, fmap2: Tensor) -> Tensor:
+    """corr.py:96-104 -- vol[b,y,x1,x2] = sum_c f1[b,c,y,x1] f2[b,c,y,x2] / sqrt(C)."""
+    B, D, H, W1 = fmap1.shape
+    vol = torch.einsum("bcyi,bcyj->byij", fmap1.float(), fmap2.float())
+    return vol / math.sqrt(D)
+
+
+def corr_pyramid(fmap1: Tensor, fmap2: Tensor, num_levels: int = 4) -> List[Tensor]:
+    """corr.py:56-72 -- num_levels+1 entries (B*H*W1, 1, 1, W2_l); the last one is never read."""
+    vol = corr_volume(fmap1, fmap2)
+    B, H, W1, W2 = vol.shape
+    lvl = vol.reshape(B * H * W1, 1, 1, W2)
+    pyr = [lvl]
+    for _ in range(num_levels):
+        w = lvl.shape[-1] // 2
+        lvl = 0.5 * (lvl[..., 0:2 * w:2] + lvl[..., 1:2 * w:2])       # avg_pool2d([1,2]) floors odd widths
+        pyr.append(lvl)
+    return pyr
+
+
+def corr_lookup(pyr: List[Tensor], flow: Tensor, num_levels: int = 4, radius: int = 4) -> Tensor:
+    """corr.py:74-94 + bilinear_sampler :10-27 (grid_sample, align_corners=True, zero padding).
+
+    p = (x + flow_x)/2^l + (kk - r); out[b, 9l+kk, y, x] = (1-a) L_l[.., floor p] + a L_l[.., floor p + 1],
+    taps outside [0, W_l-1] contribute 0.  The y component of the flow is ignored (:77).
+    """
+    B, _, H, W = flow.shape
+    x = coords_grid(B, H, W)[:, 0] + flow[:, 0]                       # (B,H,W)
+    x = x.reshape(B * H * W, 1)
+    outs = []
+    dx = torch.arange(-radius, radius + 1, dtype=torch.float32)[None]  # (1,9)
+    for l in range(num_levels):
+        L = pyr[l].reshape(B * H * W, -1)
+        Wl = L.shape[1]
+        # the reference normalises p -> g = 2p/(W_l-1) - 1 (corr.py:14) and grid_sample maps it back with
+        # ((g+1)/2)*(W_l-1); the same fp32 op sequence is kept so the round trip rounds identically
+        g = 2 * (dx + x / 2 ** l) / (Wl - 1) - 1
+        p = ((g + 1) / 2) * (Wl - 1)
+        p0 = torch.floor(p)
+        a = p - p0
+        i0 = p0.long()
+        i1 = i0 + 1
+        v0 = torch.gather(L, 1, i0.clamp(0, Wl - 1)) * ((i0 >= 0) & (i0 <= Wl - 1))
+        v1 = torch.gather(L, 1, i1.clamp(0, Wl - 1)) * ((i1 >= 0) & (i1 <= Wl - 1))
+        outs.append((1 - a) * v0 + a * v1)
+    out = torch.cat(outs, 1).reshape(B, H, W, -1)
+    return out.permute(0, 3, 1, 2).contiguous().float()
+
+
+# --------------------------------------------------------------------------------------
+# temporal PE, frame similarity, QAM pick, play (models/core/ppmstereo.py, ppmtereo_update.py)
+# --------------------------------------------------------------------------------------
+def temporal_pe(T: int, channels: int) -> Tensor:
+    """ppmtereo_update.py:25-49 with is_normalize=True, scale=1 (call site ppmstereo.py:453-458).
+    Returns (T, channels).  T == 1 gives 0/0 = NaN exactly like the reference."""
+    pos = torch.arange(T)
+    pos = pos / pos[-1] * 1.0
+    pos = pos.unsqueeze(1)
+    div = 1.0 / (10000.0 ** (torch.arange(0, channels, 2).float() / channels))
+    ang = pos * div
+    pe = torch.zeros(T, channels)
+    pe[:, 0::2] = torch.sin(ang)
+    pe[:, 1::2] = torch.cos(ang)
+    return pe
+
+
+def qk_similarity(q: Tensor, k: Tensor) -> Tensor:
+    """ppmstereo.py:397-423.  q,k: (T,C,h,w) of one batch element -> sim (T,T) with
+    sim[i,j] = cos(kbar_i, qbar_j), kbar = mean_c(AdaptiveMaxPool2d(h//4,w//4)(k))."""
+    T, C, h, w = q.shape
+    q_ = F.adaptive_max_pool2d(q, (h // 4, w // 4)).mean(1).reshape(T, -1)
+    k_ = F.adaptive_max_pool2d(k, (h // 4, w // 4)).mean(1).reshape(T, -1)
+    return F.cosine_similarity(q_.unsqueeze(0), k_.unsqueeze(1), dim=-1)      # [i,j] = cos(k_i, q_j)
+
+
+def qam_select(sim: Tensor, strive: Tensor, conf: Tensor) -> Tuple[Tensor, Tensor, Tensor]:
+    """ppmstereo.py:501-513.  sim, strive: (T,T); conf: (T,) = mean_hw(uncertainty).
+    Returns (frame_score (T,T), mask (T,T) bool, strive_new)."""
+    T = sim.shape[0]
+    pen = torch.exp(-strive / (strive.sum(1, keepdim=True) + T))
+    score = pen * sim + conf[None, :]
+    idx = torch.argsort(score, dim=-1, descending=True)[:, :TOP_K]
+    mask = torch.zeros_like(score, dtype=torch.bool).scatter_(1, idx, True)
+    strive = strive.clone()
+    strive[mask] += 1
+    return score, mask, strive
+
+
+def play_inputs(q: Tensor, key: Tensor, pe: Tensor, value: Tensor, score: Tensor, mask: Tensor, clip: int,
+                mean: Optional[Tensor] = None):
+    """ppmstereo.py:517-548.  q,key,value: (T,C,h,w); pe: (T,C).  Builds the (n,C)/(k*n,C) operands of clip
+    ``clip``: Q = q_i + PE_i; frames J ascending; s_hat = score[i,J]/mean; K' = K_J*s_hat + PE_J; V = value_J.
+    ``mean`` overrides the normaliser (the reference's .mean() at :533 also runs over batch elements)."""
+    T, C, h, w = q.shape
+    J = torch.nonzero(mask[clip]).flatten()
+    s = score[clip, J]
+    s_hat = s / (s.mean() if mean is None else mean)
+    Q = (q[clip] + pe[clip][:, None, None]).reshape(C, -1).t()
+    K = key[J] * s_hat[:, None, None, None] + pe[J][:, :, None, None]          # (k,C,h,w)
+    K = K.permute(0, 2, 3, 1).reshape(-1, C)
+    V = value[J].permute(0, 2, 3, 1).reshape(-1, C)
+    return Q.contiguous(), K.contiguous(), V.contiguous(), J, s_hat
+
+
+def softmax_scale(c: int = 128) -> float:
+    """ppmstereo.py:494 -- c^-0.5 * log_12000(2c)."""
+    return c ** -0.5 * math.log(2 * c, 12000)
+
+
+def flash_attn_math(Q: Tensor, K: Tensor, V: Tensor, scale: float) -> Tensor:
+    """flash_attn.flash_attn_func semantics at ppmstereo.py:550: bf16 operands, fp32 softmax and
+    accumulation, bf16 result; returned as float (the call site's ``.float()``)."""
+    Qb, Kb, Vb = (t.to(torch.bfloat16).float() for t in (Q, K, V))
+    out = torch.empty(Q.shape[0], V.shape[1])
+    step = 2048
+    for s in range(0, Q.shape[0], step):
+        P = torch.softmax((Qb[s:s + step] @ Kb.t()) * scale, dim=-1)
+        out[s:s + step] = P @ Vb
+    return out.to(torch.bfloat16).float()
+
+
+# --------------------------------------------------------------------------------------
+# update block (models/core/ppmtereo_update.py)
+# --------------------------------------------------------------------------------------
+def _c2(W, pre, x, pad=0, groups=1):
+    return F.conv2d(x, W[pre + ".weight"], W.get(pre + ".bias"), padding=pad, groups=groups)
+
+
+def _c3(W, pre, x, pad):
+    return F.conv3d(x, W[pre + ".weight"], W.get(pre + ".bias"), padding=pad)
+
+
+def pcblock(W: Dict[str, Tensor], pre: str, x: Tensor) -> Tensor:
+    """PCBlock4_Deep_nopool_res.forward, ppmtereo_update.py:1024-1030 (k_conv=[1,7])."""
+    y = _c2(W, pre + ".ffn1.2", F.gelu(_c2(W, pre + ".ffn1.0", x)))
+    x = F.gelu(x + y)
+    c = x.shape[1]
+    x = F.gelu(x + _c2(W, pre + ".conv_list.0", x, 0, groups=c))
+    x = F.gelu(x + _c2(W, pre + ".conv_list.1", x, 3, groups=c))
+    x = F.gelu(x + _c2(W, pre + ".pw", x))
+    return _c2(W, pre + ".ffn2.2", F.gelu(_c2(W, pre + ".ffn2.0", x)))
+
+
+def motion_encoder(W, flow: Tensor, corr: Tensor, mhs: Optional[Tensor], inp: Tensor):
+    """BasicMotionEncoder_v2.forward, ppmtereo_update.py:466-482.  Returns (mf (N,128), mhs (N,64))."""
+    p = "encoder."
+    if mhs is None:
+        mhs = _c2(W, p + "init_conv.2", F.relu(_c2(W, p + "init_conv.0", inp, 1)), 1)
+    cor = F.gelu(pcblock(W, p + "convc1", corr))
+    cor = F.relu(_c2(W, p + "convc2", cor, 1))
+    flo = F.relu(_c2(W, p + "convf1", flow, 3))
+    flo = F.relu(_c2(W, p + "convf2", flo, 1))
+    out = F.relu(_c2(W, p + "final_conv", torch.cat([cor, flo, mhs], 1), 1))
+    out, mhs = torch.split(out, [126, 64], 1)
+    return torch.cat([out, flow], 1), mhs
+
+
+def get_motion_and_value(W, flow, corr, mhs, inp):
+    """SequenceUpdateBlock3D.get_motion_and_value, ppmtereo_update.py:945-950."""
+    mf, mhs = motion_encoder(W, flow, corr, mhs, inp)
+    value = F.conv2d(mf, W["aggregator.to_v.weight"])
+    return mf, mhs, value
+
+
+def get_uncertainty(W, x: Tensor) -> Tensor:
+    """ppmtereo_update.py:889-893,936-938 -- sigmoid(conv1x1(relu(conv3x3(x))))."""
+    return torch.sigmoid(_c2(W, "uncertainty.2", F.relu(_c2(W, "uncertainty.0", x, 1))))
+
+
+def gru3d(W, h: Tensor, x: Tensor) -> Tensor:
+    """SKSepConvGRU3D.forward, ppmtereo_update.py:291-312.  h (b,128,t,H,W), x (b,384,t,H,W)."""
+    g = "gru."
+    hx = torch.cat([h, x], 1)
+    z = torch.sigmoid(_c3(W, g + "convz1.2", F.gelu(_c3(W, g + "convz1.0", hx, (0, 0, 7))), (0, 0, 2)))
+    r = torch.sigmoid(_c3(W, g + "convr1.2", F.gelu(_c3(W, g + "convr1.0", hx, (0, 0, 7))), (0, 0, 2)))
+    q = torch.tanh(_c3(W, g + "convq1", torch.cat([r * h, x], 1), (0, 0, 2)))
+    h = (1 - z) * h + z * q
+    for n, pad in (("2", (0, 2, 0)), ("3", (2, 0, 0))):
+        hx = torch.cat([h, x], 1)
+        z = torch.sigmoid(_c3(W, g + "convz" + n, hx, pad))
+        r = torch.sigmoid(_c3(W, g + "convr" + n, hx, pad))
+        q = torch.tanh(_c3(W, g + "convq" + n, torch.cat([r * h, x], 1), pad))
+        h = (1 - z) * h + z * q
+    return h
+
+
+def flow_head3d(W, x: Tensor) -> Tensor:
+    """FlowHead3D.forward, ppmtereo_update.py:670-678."""
+    return _c3(W, "flow_head.conv2", F.relu(_c3(W, "flow_head.conv1", x, 1)), 1)
+
+
+def layer_norm(x, w, b):
+    return F.layer_norm(x, (x.shape[-1],), w, b, 1e-5)
+
+
+def time_attn(W, x: Tensor, T: int, pre: str = "time_attn.") -> Tensor:
+    """TimeAttnBlock.forward ppmtereo_update.py:603-618 with Attention.forward :409-420
+    (q = k = v = LayerNorm(x) split in 8 heads; the qkv Linear is never applied)."""
+    BT, C, h, w = x.shape
+    b = BT // T
+    tok = x.reshape(b, T, C, h, w).permute(0, 3, 4, 1, 2).reshape(b * h * w, T, C)
+    y = layer_norm(tok, W[pre + "temporal_norm1.weight"], W[pre + "temporal_norm1.bias"])
+    nh = 8
+    qkv = y.reshape(-1, T, nh, C // nh).permute(0, 2, 1, 3)
+    att = torch.softmax((qkv @ qkv.transpose(-2, -1)) * (C // nh) ** -0.5, dim=-1)
+    o = (att @ qkv).transpose(1, 2).reshape(-1, T, C)
+    o = F.linear(o, W[pre + "temporal_attn.proj.weight"], W[pre + "temporal_attn.proj.bias"])
+    o = F.linear(o, W[pre + "temporal_fc.weight"], W[pre + "temporal_fc.bias"])
+    tok = tok + o
+    return tok.reshape(b, h, w, T, C).permute(0, 3, 4, 1, 2).reshape(BT, C, h, w)
+
+
+def loftr_layer(W, pre: str, x: Tensor, src: Tensor, nhead: int = 8) -> Tensor:
+    """LoFTREncoderLayer.forward + LinearAttention.forward, models/core/attention.py:164-190,73-100."""
+    N, L, C = x.shape
+    d = C // nhead
+    q = F.linear(x, W[pre + "q_proj.weight"]).view(N, -1, nhead, d)
+    k = F.linear(src, W[pre + "k_proj.weight"]).view(N, -1, nhead, d)
+    v = F.linear(src, W[pre + "v_proj.weight"]).view(N, -1, nhead, d)
+    Q = F.elu(q) + 1
+    K = F.elu(k) + 1
+    S = v.shape[1]
+    v = v / S
+    KV = torch.einsum("nshd,nshv->nhdv", K, v)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", Q, K.sum(1)) + 1e-6)
+    msg = torch.einsum("nlhd,nhdv,nlh->nlhv", Q, KV, Z) * S
+    msg = F.linear(msg.reshape(N, -1, C), W[pre + "merge.weight"])
+    msg = layer_norm(msg, W[pre + "norm1.weight"], W[pre + "norm1.bias"])
+    msg = F.linear(F.relu(F.linear(torch.cat([x, msg], 2), W[pre + "mlp.0.weight"])), W[pre + "mlp.2.weight"])
+    msg = layer_norm(msg, W[pre + "norm2.weight"], W[pre + "norm2.bias"])
+    return x + msg
+
+
+def space_attn(W, x: Tensor) -> Tensor:
+    """SpaceAttnBlock.forward ppmtereo_update.py:626-631."""
+    BT, C, h, w = x.shape
+    tok = x.reshape(BT, C, h * w).transpose(1, 2)
+    tok = loftr_layer(W, "space_attn.encoder_layer.", tok, tok)
+    return tok.transpose(1, 2).reshape(BT, C, h, w)
+
+
+def update_block_forward(W, net, inp, mf, mfg, t: int, with_attention: bool):
+    """SequenceUpdateBlock3D.forward, ppmtereo_update.py:971-1003 (use_convex_3d=False)."""
+    x = torch.cat([inp, mf, mfg], 1)
+    if with_attention:
+        x = time_attn(W, x, t)
+        x = space_attn(W, x)
+    BT, _, h, w = net.shape
+    b = BT // t
+    to5 = lambda a: a.reshape(b, t, -1, h, w).permute(0, 2, 1, 3, 4)
+    to4 = lambda a: a.permute(0, 2, 1, 3, 4).reshape(BT, -1, h, w)
+    net5 = gru3d(W, to5(net), to5(x))
+    dflow = to4(flow_head3d(W, net5))
+    net = to4(net5)
+    mask = 0.25 * _c2(W, "mask_2d.2", F.relu(_c2(W, "mask_2d.0", net, 1)))
+    return net, mask, dflow
+
+
+def convex_upsample(flow: Tensor, mask: Tensor, rate: int = 4) -> Tensor:
+    """PPMStereo.convex_upsample, ppmstereo.py:185-197 -- closed form
+    out[n,c,4y+i,4x+j] = sum_k softmax_k(mask[n,16k+4i+j,y,x]) * 4 flow[n,c,y+k//3-1,x+k%3-1]."""
+    N, _, H, W = flow.shape
+    m = torch.softmax(mask.view(N, 1, 9, rate, rate, H, W), dim=2)
+    fp = F.pad(rate * flow, (1, 1, 1, 1))
+    nb = torch.stack([fp[:, :, dy:dy + H, dx:dx + W] for dy in range(3) for dx in range(3)], 2)  # (N,2,9,H,W)
+    up = (m * nb.view(N, 2, 9, 1, 1, H, W)).sum(2)                     # (N,2,r,r,H,W)
+    return up.permute(0, 1, 4, 2, 5, 3).reshape(N, 2, rate * H, rate * W)
+
+
+def interp(x: Tensor, size) -> Tensor:
+    """models/core/utils/utils.py:10-16."""
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+
+
+# --------------------------------------------------------------------------------------
+# the hot loop
+# --------------------------------------------------------------------------------------
+def forward_update_block(Wb, Watt, pyr, flow, net, inp, mhs, iters: int, interp_scale: int, t: int,
+                         with_attention: bool, predictions: list, uncertainties: list, trace: Optional[list] = None):
+    """PPMStereo.forward_update_block, ppmstereo.py:426-594 (live branches only: interp_scale in {4,2,1}).
+
+    Wb: update-block weights, Watt: {"to_qk.weight"}, pyr: output of corr_pyramid.  b == 1 layouts
+    generalise to b > 1 exactly as the reference does (frames of all batch elements share QAM means).
+    """
+    BT, c, h, w = inp.shape
+    b = BT // t
+    qk = F.conv2d(inp, Watt["to_qk.weight"])
+    query, key = qk[:, :c], qk[:, c:]                                   # (BT,c,h,w) each; frame index = b*t + ti
+    pe = temporal_pe(t, c)
+    scale = softmax_scale(c)
+    sims = [qk_similarity(query[bi * t:(bi + 1) * t], key[bi * t:(bi + 1) * t]) for bi in range(b)]
+    strive = [torch.ones_like(s) for s in sims]
+    beta = Wb["aggregator.beta"]
+    flow_out = None
+    for itr in range(iters):
+        out_corrs = corr_lookup(pyr, flow)
+        mf, mhs, value = get_motion_and_value(Wb, flow, out_corrs, mhs, inp)
+        unc = get_uncertainty(Wb, torch.cat([net, value], 1))
+        conf = unc.reshape(b, t, -1).mean(-1)
+        scores, masks = [], []
+        for bi in range(b):
+            sc, mk, strive[bi] = qam_select(sims[bi], strive[bi], conf[bi])
+            scores.append(sc)
+            masks.append(mk)
+        # selected_score.mean() (ppmstereo.py:533) averages over batch elements too
+        mfg = torch.empty_like(mf)
+        for clip in range(t):
+            mean_all = torch.cat([scores[bi][clip][masks[bi][clip]] for bi in range(b)]).mean()
+            for bi in range(b):
+                sl = slice(bi * t, (bi + 1) * t)
+                Q, K, V, J, _ = play_inputs(query[sl], key[sl], pe, value[sl], scores[bi], masks[bi], clip, mean_all)
+                hid = flash_attn_math(Q, K, V, scale)                   # (n,c)
+                hid = hid.t().reshape(c, h, w)
+                mfg[bi * t + clip] = mf[bi * t + clip] + beta * hid
+        net, up_mask, dflow = update_block_forward(Wb, net, inp, mf, mfg, t, with_attention)
+        flow = flow + dflow
+        flow_out = convex_upsample(flow, up_mask, 4)
+        unc_up = F.interpolate(unc, scale_factor=4 * interp_scale, mode="bilinear")
+        flow_up = flow_out
+        if interp_scale > 1:
+            flow_up = interp_scale * interp(flow_out, (interp_scale * flow_out.shape[2], interp_scale * flow_out.shape[3]))
+        predictions.append(flow_up[:, :1])
+        uncertainties.append(unc_up)
+        if trace is not None:
+            trace.append(dict(corr=out_corrs, mf=mf, value=value, unc=unc, mfg=mfg, net=net, mask=up_mask,
+                              dflow=dflow, flow=flow, flow_out=flow_out,
+                              score=torch.stack(scores), sel=torch.stack(masks)))
+    return flow_out, net, mhs
+
+
+def cascade(W, feats, iters: int, t: int, predictions: Optional[list] = None, uncertainties: Optional[list] = None):
+    """The three-scale cascade of PPMStereo.forward, ppmstereo.py:696-804 (from encoder outputs on).
+
+    feats: dict with fmap1/fmap2 at scales 16, 8, 4 ("f1_16", "f2_16", ...) and net/inp ("net_16", "inp_16", ...),
+    i.e. everything the encoders + SST block hand to the loop.  Returns (flow_up (BT,1,H,W), unc_up (BT,1,H,W)).
+    """
+    preds = [] if predictions is None else predictions
+    uncs = [] if uncertainties is None else uncertainties
+    f16 = feats["f1_16"]
+    flow16 = torch.zeros(f16.shape[0], 2, f16.shape[2], f16.shape[3])
+    fo, net16, mhs16 = forward_update_block(W["update_block16"], W["att.0"], corr_pyramid(feats["f1_16"], feats["f2_16"]),
+                                            flow16, feats["net_16"], feats["inp_16"], None, iters // 2, 4, t, True, preds, uncs)
+    h8, w8 = feats["f1_8"].shape[2:]
+    flow8 = -(h8 / fo.shape[2]) * interp(fo, (h8, w8))
+    mhs8 = F.interpolate(mhs16, scale_factor=2, mode="bilinear", align_corners=True)
+    net8 = (feats["net_8"] + interp(net16, (2 * net16.shape[2], 2 * net16.shape[3]))) / 2.0
+    fo, net8, mhs8 = forward_update_block(W["update_block08"], W["att.1"], corr_pyramid(feats["f1_8"], feats["f2_8"]),
+                                          flow8, net8, feats["inp_8"], mhs8, iters // 2, 2, t, False, preds, uncs)
+    h4, w4 = feats["f1_4"].shape[2:]
+    flow4 = -(h4 / fo.shape[2]) * interp(fo, (h4, w4))
+    mhs4 = F.interpolate(mhs8, scale_factor=2, mode="bilinear", align_corners=True)
+    net4 = (feats["net_4"] + interp(net8, (2 * net8.shape[2], 2 * net8.shape[3]))) / 2.0
+    forward_update_block(W["update_block04"], W["att.2"], corr_pyramid(feats["f1_4"], feats["f2_4"]),
+                         flow4, net4, feats["inp_4"], mhs4, iters, 1, t, False, preds, uncs)
+    return preds[-1], uncs[-1]
+
+
+def window_plan(num_ims: int, kernel_size: int = 20):
+    """Index-only restatement of forward_batch_test's sliding window, ppmstereo.py:242-310.
+    Returns [(start, stop, keep_from, keep_to)] in window-local indices for every window whose output is kept."""
+    stride = kernel_size // 2
+    if kernel_size > num_ims:
+        return [(0, num_ims, 0, num_ims)]
+    plan = []
+    for i in range(0, num_ims, stride):
+        n = min(i + kernel_size, num_ims) - i
+        if plan and n >= stride:
+            if n < kernel_size:
+                plan.append((i, i + n, stride // 2, n))
+            else:
+                plan.append((i, i + n, stride // 2, n + (-stride // 2)))
+        elif not plan:
+            plan.append((i, i + n, 0, n + (-stride // 2)))
+    return plan
+
+
+# --------------------------------------------------------------------------------------
+# caller-side glue needed to drive / check the path end to end (not on the hot path itself)
+# --------------------------------------------------------------------------------------
+def position_encoding_sine(d_model: int, h: int, w: int) -> Tensor:
+    """PositionEncodingSine (temp_bug_fix=True), models/core/attention.py:23-64 -> (d_model,h,w)."""
+    y = torch.ones(h, w).cumsum(0)[None]
+    x = torch.ones(h, w).cumsum(1)[None]
+    div = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / (d_model // 2)))[:, None, None]
+    pe = torch.zeros(d_model, h, w)
+    pe[0::4], pe[1::4] = torch.sin(x * div), torch.cos(x * div)
+    pe[2::4], pe[3::4] = torch.sin(y * div), torch.cos(y * div)
+    return pe
+
+
+def pre_loop_glue(fmap1: Tensor, fmap2: Tensor, c4: Tensor, c8: Tensor, c16: Tensor, sst_fn=None, hdim: int = 128):
+    """PPMStereo.forward between the encoders and the loop, ppmstereo.py:620-682.
+    sst_fn(f1_16, f2_16) stands for forward_sst_block (:322-395); None = positional encoding only
+    (what the reference does with attention_type=None)."""
+    feats = {}
+    net, inp = torch.split(fmap1, [hdim, hdim], 1)
+    feats["net_4"] = torch.tanh((net + c4[:, :hdim]) / 2.0)
+    feats["inp_4"] = F.relu((inp + c4[:, hdim:]) / 2.0)
+    h, w = fmap1.shape[2:]
+    f1_16, f2_16 = F.avg_pool2d(fmap1, 4, 4), F.avg_pool2d(fmap2, 4, 4)
+    if sst_fn is None:
+        pe = position_encoding_sine(fmap1.shape[1], f1_16.shape[2], f1_16.shape[3])
+        f1_16, f2_16 = f1_16 + pe, f2_16 + pe
+    else:
+        f1_16, f2_16 = sst_fn(f1_16, f2_16)
+    n16, i16 = torch.split(f1_16, [hdim, hdim], 1)
+    feats["net_16"] = torch.tanh((n16 + c16[:, :hdim]) / 2.0)
+    feats["inp_16"] = F.relu((i16 + c16[:, hdim:]) / 2.0)
+    f1_8 = (F.avg_pool2d(fmap1, 2, 2) + interp(f1_16, (h // 2, w // 2))) / 2.0
+    f2_8 = (F.avg_pool2d(fmap2, 2, 2) + interp(f2_16, (h // 2, w // 2))) / 2.0
+    n8, i8 = torch.split(f1_8, [hdim, hdim], 1)
+    feats["net_8"] = torch.tanh((n8 + c8[:, :hdim]) / 2.0)
+    feats["inp_8"] = F.relu((i8 + c8[:, hdim:]) / 2.0)
+    feats.update(f1_16=f1_16, f2_16=f2_16, f1_8=f1_8, f2_8=f2_8, f1_4=fmap1, f2_4=fmap2)
+    return feats

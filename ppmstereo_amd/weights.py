@@ -1,0 +1,140 @@
+"""Parameter inventory and procedural (name-keyed) weights for the PPMStereo hot path.
+
+The key names and shapes below are the reference's ``state_dict`` layout for the modules that
+live on the hot path, so published checkpoints load unchanged:
+
+* ``SequenceUpdateBlock3D``  -- /root/reference/models/core/ppmtereo_update.py:880-933
+  (encoder = BasicMotionEncoder_v2 :445-465, convc1 = PCBlock4_Deep_nopool_res :1006-1022,
+  gru = SKSepConvGRU3D :254-289, flow_head = FlowHead3D :670-675, uncertainty :889-893,
+  mask_2d :910-914, aggregator = Aggregate :634-652, time_attn :593-601, space_attn :621-624
+  -> LoFTREncoderLayer /root/reference/models/core/attention.py:140-165)
+* ``Attention_qk.to_qk``     -- ppmtereo_update.py:118-129
+
+No weights file travels with the repo: weights are generated from a hash of the parameter name,
+so the GPU box regenerates bit-identical tensors (numpy PCG64 is platform independent).
+"""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+HIDDEN = 128
+COR_PLANES = 36  # 4 levels x 9 taps
+
+
+def update_block_param_shapes(with_attention: bool) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Name -> shape of every parameter of one SequenceUpdateBlock3D (use_convex_3d=False)."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+
+    def conv(name, cout, cin, *k, bias=True):
+        s[name + ".weight"] = (cout, cin, *k)
+        if bias:
+            s[name + ".bias"] = (cout,)
+
+    c = COR_PLANES
+    # encoder.convc1 = PCBlock4_Deep_nopool_res(36, 256, k_conv=[1, 7])
+    conv("encoder.convc1.conv_list.0", c, 1, 1, 1)        # depthwise 1x1
+    conv("encoder.convc1.conv_list.1", c, 1, 7, 7)        # depthwise 7x7
+    conv("encoder.convc1.ffn1.0", int(1.5 * c), c, 1, 1)
+    conv("encoder.convc1.ffn1.2", c, int(1.5 * c), 1, 1)
+    conv("encoder.convc1.pw", c, c, 1, 1)
+    conv("encoder.convc1.ffn2.0", int(1.5 * c), c, 1, 1)
+    conv("encoder.convc1.ffn2.2", 256, int(1.5 * c), 1, 1)
+    conv("encoder.convc2", 192, 256, 3, 3)
+    conv("encoder.convf1", 128, 2, 7, 7)
+    conv("encoder.convf2", 64, 128, 3, 3)
+    conv("encoder.final_conv", 190, 320, 3, 3)
+    conv("encoder.init_conv.0", 64, 128, 3, 3)
+    conv("encoder.init_conv.2", 64, 64, 3, 3)
+    # gru = SKSepConvGRU3D(hidden 128, input 384)
+    for g in ("z", "r"):
+        conv(f"gru.conv{g}1.0", 128, 512, 1, 1, 15)
+        conv(f"gru.conv{g}1.2", 128, 128, 1, 1, 5)
+    conv("gru.convq1", 128, 512, 1, 1, 5)
+    for g in ("z", "r", "q"):
+        conv(f"gru.conv{g}2", 128, 512, 1, 5, 1)
+    for g in ("z", "r", "q"):
+        conv(f"gru.conv{g}3", 128, 512, 5, 1, 1)
+    conv("flow_head.conv1", 256, 128, 3, 3, 3)
+    conv("flow_head.conv2", 2, 256, 3, 3, 3)
+    conv("uncertainty.0", 128, 256, 3, 3)
+    conv("uncertainty.2", 1, 128, 1, 1)
+    conv("mask_2d.0", 256, 128, 3, 3)
+    conv("mask_2d.2", 144, 256, 1, 1)
+    if with_attention:
+        d = 384
+        s["time_attn.temporal_attn.qkv.weight"] = (3 * d, d)   # dead parameter (never applied)
+        s["time_attn.temporal_attn.proj.weight"] = (d, d)
+        s["time_attn.temporal_attn.proj.bias"] = (d,)
+        s["time_attn.temporal_fc.weight"] = (d, d)
+        s["time_attn.temporal_fc.bias"] = (d,)
+        s["time_attn.temporal_norm1.weight"] = (d,)
+        s["time_attn.temporal_norm1.bias"] = (d,)
+        p = "space_attn.encoder_layer."
+        for n in ("q_proj", "k_proj", "v_proj", "merge"):
+            s[p + n + ".weight"] = (d, d)
+        s[p + "mlp.0.weight"] = (2 * d, 2 * d)
+        s[p + "mlp.2.weight"] = (d, 2 * d)
+        for n in ("norm1", "norm2"):
+            s[p + n + ".weight"] = (d,)
+            s[p + n + ".bias"] = (d,)
+    s["aggregator.to_v.weight"] = (128, 128, 1, 1)
+    s["aggregator.beta"] = (1,)
+    return s
+
+
+def att_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
+    return OrderedDict([("to_qk.weight", (256, 128, 1, 1))])
+
+
+def _gen(name: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
+    rng = np.random.Generator(np.random.PCG64([zlib.crc32(name.encode()), seed]))
+    x = rng.standard_normal(size=shape, dtype=np.float64)
+    leaf = name.rsplit(".", 1)[-1]
+    if name.endswith("aggregator.beta"):
+        return np.full(shape, 0.5, np.float32)               # zero-init in the reference: would mute attention
+    if "norm" in name and leaf == "weight":
+        return (1.0 + 0.1 * x).astype(np.float32)
+    if leaf == "bias":
+        return (0.02 * x).astype(np.float32)
+    fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+    gain = 1.0
+    if "temporal_fc" in name:
+        gain = 0.3                                            # zero-init in the reference (ppmtereo_update.py:600)
+    return (gain * x / np.sqrt(fan_in)).astype(np.float32)
+
+
+def procedural_state_dict(shapes: Dict[str, Tuple[int, ...]], prefix: str = "", seed: int = 0
+                          ) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic weights keyed by ``prefix + name`` (Kaiming-like scale, beta = 0.5)."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in shapes.items():
+        out[name] = torch.from_numpy(_gen(prefix + name, tuple(shape), seed))
+    return out
+
+
+def hot_path_weights(seed: int = 0) -> Dict[str, "OrderedDict[str, torch.Tensor]"]:
+    """Weights of the three update blocks and three q/k projections (reference names:
+    update_block16 / update_block08 / update_block04, att.0 / att.1 / att.2;
+    /root/reference/models/core/ppmstereo.py:82-117)."""
+    w = {}
+    for tag, attn in (("update_block16", True), ("update_block08", False), ("update_block04", False)):
+        w[tag] = procedural_state_dict(update_block_param_shapes(attn), tag + ".", seed)
+    for i in range(3):
+        w[f"att.{i}"] = procedural_state_dict(att_param_shapes(), f"att.{i}.", seed)
+    return w
+
+
+def hash_uniform(shape, seed: int, lo: float = -1.0, hi: float = 1.0) -> torch.Tensor:
+    """Counter-hash synthetic tensor (no torch RNG: identical on every box)."""
+    rng = np.random.Generator(np.random.PCG64([0x5EED, seed]))
+    return torch.from_numpy(rng.uniform(lo, hi, size=tuple(shape)).astype(np.float32))
+
+
+def hash_normal(shape, seed: int, std: float = 1.0) -> torch.Tensor:
+    rng = np.random.Generator(np.random.PCG64([0xFEED, seed]))
+    return torch.from_numpy((std * rng.standard_normal(size=tuple(shape))).astype(np.float32))

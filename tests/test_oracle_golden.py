@@ -1,0 +1,135 @@
+"""Pins the CPU oracle (oracle/ppm_oracle.py) to vectors produced by the reference itself
+(tools/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden
+from oracle import ppm_oracle as O
+from ppmstereo_amd import weights as Wm
+from ppmstereo_amd.synth import synth_scale_inputs
+from ppmstereo_amd.weights import hash_normal
+
+W = Wm.hot_path_weights()
+torch.set_num_threads(8)
+
+
+@pytest.mark.parametrize("name,args", [("corr_small", (2, 4, 32, 11)), ("corr_odd", (1, 3, 24, 12))])
+def test_corr_pyramid_and_lookup(name, args):
+    g = Golden(name)
+    d = synth_scale_inputs(*args[:3], seed=args[3])
+    pyr = O.corr_pyramid(d["fmap1"], d["fmap2"])
+    assert len(pyr) == 5
+    for i, p in enumerate(pyr):
+        g.check(f"pyr{i}", p, 2e-5)
+    g.check("lookup", O.corr_lookup(pyr, d["flow"]), 3e-5)
+    if name == "corr_small":
+        g.check("coords", O.coords_grid(2, 4, 32), 0.0)
+
+
+def test_corr_lookup_out_of_range():
+    d = synth_scale_inputs(1, 2, 32, seed=13)
+    pyr = O.corr_pyramid(d["fmap1"], d["fmap2"])
+    out = O.corr_lookup(pyr, d["flow"] * 20)
+    Golden("corr_oob").check("lookup", out, 3e-5)
+    assert (out == 0).any()
+
+
+def test_temporal_pe():
+    g = Golden("temporal_pe")
+    for T in (2, 5, 8):
+        g_t = torch.from_numpy(g.raw(f"T{T}"))
+        assert torch.equal(O.temporal_pe(T, 128), g_t)
+    assert np.isnan(g.raw("T1")).all() and torch.isnan(O.temporal_pe(1, 128)).all()      # T = 1 -> 0/0
+
+
+def test_convex_upsample():
+    fl, mk = hash_normal((3, 2, 6, 10), 31), hash_normal((3, 144, 6, 10), 32)
+    Golden("convex_upsample").check("out", O.convex_upsample(fl, mk), 2e-6)
+
+
+def test_update_block_pieces():
+    g = Golden("update_block16_pieces")
+    Wb = W["update_block16"]
+    T, h, w = 5, 8, 32
+    d = synth_scale_inputs(T, h, w, seed=41, with_mhs=False)
+    corr = hash_normal((T, 36, h, w), 42)
+    mf, mhs, val = O.get_motion_and_value(Wb, d["flow"], corr, None, d["inp"])
+    g.check("mf", mf, 2e-5), g.check("mhs", mhs, 2e-5), g.check("value", val, 2e-5)
+    mf2, mhs2, _ = O.get_motion_and_value(Wb, d["flow"], corr, mhs, d["inp"])
+    g.check("mf2", mf2, 2e-5), g.check("mhs2", mhs2, 2e-5)
+    g.check("unc", O.get_uncertainty(Wb, torch.cat([d["net"], val], 1)), 2e-6)
+    mfg = mf + 0.3 * hash_normal((T, 128, h, w), 43)
+    x = torch.cat([d["inp"], mf, mfg], 1)
+    xt = O.time_attn(Wb, x, T)
+    g.check("time_attn", xt, 2e-5)
+    g.check("space_attn", O.space_attn(Wb, xt), 5e-5)
+    net, mask, dflow = O.update_block_forward(Wb, d["net"], d["inp"], mf, mfg, T, True)
+    g.check("net", net, 2e-5), g.check("mask", mask, 2e-5), g.check("dflow", dflow, 2e-5)
+    g4 = Golden("update_block04_pieces")
+    W4 = W["update_block04"]
+    net, mask, dflow = O.update_block_forward(W4, d["net"], d["inp"], mf, mfg, T, False)
+    g4.check("net", net, 2e-5), g4.check("mask", mask, 2e-5), g4.check("dflow", dflow, 2e-5)
+    n5 = d["net"].reshape(1, T, 128, h, w).permute(0, 2, 1, 3, 4)
+    x5 = x.reshape(1, T, 384, h, w).permute(0, 2, 1, 3, 4)
+    g4.check("gru", O.gru3d(W4, n5, x5), 2e-5)
+    g4.check("flow_head", O.flow_head3d(W4, n5), 2e-5)
+
+
+FUB = [("fub16", "update_block16", 0, 5, 8, 32, 2, 4, False), ("fub08", "update_block08", 1, 8, 8, 32, 3, 2, True),
+       ("fub04", "update_block04", 2, 5, 16, 64, 2, 1, True), ("fub04_T2", "update_block04", 2, 2, 8, 32, 2, 1, True)]
+
+
+@pytest.mark.parametrize("name,tag,ai,T,h,w,iters,isc,mh", FUB)
+def test_forward_update_block(name, tag, ai, T, h, w, iters, isc, mh):
+    g = Golden(name)
+    d = synth_scale_inputs(T, h, w, seed=50 + ai + 10 * T, with_mhs=mh)
+    pyr = O.corr_pyramid(d["fmap1"], d["fmap2"])
+    preds, uncs, trace = [], [], []
+    fo, net, mhs = O.forward_update_block(W[tag], W[f"att.{ai}"], pyr, d["flow"], d["net"], d["inp"], d["mhs"], iters, isc, T,
+                                          tag == "update_block16", preds, uncs, trace)
+    assert int(g.raw("n_attn_calls")) == T * iters
+    assert abs(float(g.raw("attn_scale")) - O.softmax_scale(128)) < 1e-12
+    # the operands the reference handed to flash_attn_func in the last iteration, clip 1 (bf16-rounded there)
+    tr_prev = trace[-1]
+    q = torch.nn.functional.conv2d(d["inp"], W[f"att.{ai}"]["to_qk.weight"])
+    Q, K, V, J, _ = O.play_inputs(q[:, :128], q[:, 128:], O.temporal_pe(T, 128), tr_prev["value"], tr_prev["score"][0], tr_prev["sel"][0], 1)
+    bf = lambda x: x.to(torch.bfloat16).float()
+    g.check("attn_q", bf(Q), 0.0, 8e-3), g.check("attn_k", bf(K), 0.0, 8e-3), g.check("attn_v", bf(V), 0.0, 8e-3)
+    g.check("attn_o", O.flash_attn_math(Q, K, V, O.softmax_scale(128)), 0.0, 8e-3)
+    # bf16 rounding of the attention operands flips on ~1e-7 input differences, so the loop is matched to a
+    # tolerance (well inside the 1e-3 px budget), not bit for bit
+    g.check("flow_out", fo, 3e-4), g.check("net", net, 6e-4), g.check("mhs", mhs, 2e-4)
+    g.check("preds", torch.stack(preds), 3e-4 * isc), g.check("uncs", torch.stack(uncs), 5e-5)
+
+
+def test_cascade():
+    g = Golden("cascade")
+    T, H, Wd = 3, 64, 256
+    fm1, fm2 = hash_normal((T, 256, H // 4, Wd // 4), 71), hash_normal((T, 256, H // 4, Wd // 4), 72)
+    ctx = [hash_normal((T, 256, H // s, Wd // s), 73 + i) for i, s in enumerate((4, 8, 16))]
+    feats = O.pre_loop_glue(fm1, fm2, *ctx)
+    preds, uncs = [], []
+    disp, unc = O.cascade(W, feats, 4, T, preds, uncs)
+    assert len(preds) == 2 + 2 + 4 and int(g.raw("n_attn_calls")) == T * 8
+    g.check("disparity", disp[None], 5e-4), g.check("uncertainty", unc[None], 5e-5)
+
+
+def test_T1_is_nan_like_the_reference():
+    g = Golden("fub_T1_nan")
+    d = synth_scale_inputs(1, 8, 32, seed=81)
+    preds, uncs = [], []
+    fo, _, _ = O.forward_update_block(W["update_block04"], W["att.2"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"],
+                                      d["inp"], d["mhs"], 1, 1, 1, False, preds, uncs)
+    assert bool(g.raw("any_nan")) and torch.isnan(fo).any()
+    assert bool(g.raw("all_nan")) == bool(torch.isnan(fo).all())
+
+
+def test_window_plan():
+    """Index-only known answers of forward_batch_test's windowing."""
+    keep = lambda n, k: [(s + a, s + b - 1) for s, e, a, b in O.window_plan(n, k)]
+    assert keep(40, 20) == [(0, 14), (15, 24), (25, 34), (35, 39)]
+    assert keep(5, 20) == [(0, 4)]
+    assert keep(25, 20) == [(0, 14), (15, 24)]
+    assert keep(150, 20)[0] == (0, 14) and keep(150, 20)[-1] == (145, 149)
+    assert keep(40, 10)[:3] == [(0, 6), (7, 11), (12, 16)] and keep(40, 10)[-1] == (37, 39)

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+The reference lives read-only at /root/reference and never travels: this script imports it in place
+(four import shims), feeds it the procedural weights of
+``ppmstereo_amd.weights`` and the synthetic inputs of ``ppmstereo_amd.synth`` and stores only
+OUTPUT vectors (inputs and weights are regenerated from their seeds by the tests).
+
+    python tools/gen_golden.py            # rewrites tests/golden/
+
+Nothing in tests/, bench.py or smoke() reads /root/reference at run time.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+sys.path.insert(0, REF)
+
+# --- shims for modules the image lacks (never used on the path we run) -------------------
+sys.modules["unfoldNd"] = types.ModuleType("unfoldNd")
+_timm, _tm, _tl = types.ModuleType("timm"), types.ModuleType("timm.models"), types.ModuleType("timm.models.layers")
+_tl.trunc_normal_ = nn.init.trunc_normal_
+
+
+class _DropPath(nn.Identity):
+    def __init__(self, *a, **k):
+        super().__init__()
+
+
+_tl.DropPath = _DropPath
+sys.modules.update({"timm": _timm, "timm.models": _tm, "timm.models.layers": _tl})
+
+from models.core import corr as rcorr                      # noqa: E402
+from models.core import ppmtereo_update as rupd            # noqa: E402
+from models.core import ppmstereo as rppm                  # noqa: E402
+
+from ppmstereo_amd import weights as Wm                    # noqa: E402
+from ppmstereo_amd.synth import synth_scale_inputs         # noqa: E402
+from ppmstereo_amd.weights import hash_normal              # noqa: E402
+
+ATTN_LOG = []
+
+
+def flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False):
+    """math stand-in for flash_attn.flash_attn_func: (B,S,H,D) bf16 -> bf16, fp32 softmax/accumulate."""
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))
+    p = torch.softmax((qf @ kf.transpose(-1, -2)) * softmax_scale, dim=-1)
+    out = (p @ vf).permute(0, 2, 1, 3).to(q.dtype)
+    ATTN_LOG.append((q, k, v, softmax_scale, out))
+    return out
+
+
+rppm.flash_attn_func = flash_attn_func
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+MAX_ELEMS = 16384
+
+
+def save(name, **arrs):
+    """Tensors above MAX_ELEMS are stored as a strided subsample x.flatten()[::step] under "key__s<step>"
+    (tests/golden_util.py applies the same rule), keeping every fixture small."""
+    path = os.path.join(OUT, name + ".npz")
+    out = {}
+    for k, v in arrs.items():
+        a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+        if a.size > MAX_ELEMS:
+            step = -(-a.size // MAX_ELEMS) | 1          # odd stride: does not alias with power-of-two dims
+            out[f"{k}__s{step}"] = a.reshape(-1)[::step].copy()
+            out[f"{k}__shape"] = np.asarray(a.shape)
+        else:
+            out[k] = a
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB", {k: tuple(np.shape(v)) for k, v in out.items()})
+
+
+def bare_model(attention_type=None):
+    """A reference PPMStereo without its encoders (they need timm/ckpt files; out of scope)."""
+    m = rppm.PPMStereo.__new__(rppm.PPMStereo)
+    nn.Module.__init__(m)
+    m.hidden_dim, m.context_dim, m.dim = 128, 128, 256
+    m.use_cnet, m.init_flow, m.use_convex_3d = True, False, False
+    m.mixed_precision, m.different_update_blocks, m.use_3d_update_block = False, True, True
+    m.attention_type, m.num_frames, m.depth = attention_type, 5, 4
+    W = Wm.hot_path_weights()
+    for tag, attn in (("update_block16", "self_stereo_temporal_update_time_update_space"),
+                      ("update_block08", None), ("update_block04", None)):
+        blk = rupd.SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4, use_convex_3d=False, attention_type=attn)
+        blk.load_state_dict(W[tag], strict=True)          # also proves key names/shapes == reference
+        setattr(m, tag, blk)
+    m.att = nn.ModuleList([rupd.Attention_qk(num_heads=1, dim_head=128) for _ in range(3)])
+    for i in range(3):
+        m.att[i].load_state_dict(W[f"att.{i}"], strict=True)
+    return m.eval()
+
+
+@torch.no_grad()
+def main():
+    # ---- G1: CorrBlock1D build + lookup (corr.py:55-104) -------------------------------------
+    d = synth_scale_inputs(2, 4, 32, seed=11)
+    cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
+    look = cb(d["flow"])
+    save("corr_small", **{f"pyr{i}": p for i, p in enumerate(cb.corr_pyramid)}, lookup=look, coords=cb.coords)
+    d = synth_scale_inputs(1, 3, 24, seed=12)               # odd pyramid widths: 24,12,6,3,1
+    cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
+    save("corr_odd", **{f"pyr{i}": p for i, p in enumerate(cb.corr_pyramid)}, lookup=cb(d["flow"]))
+    # big flows: every tap out of range on some pixels
+    d = synth_scale_inputs(1, 2, 32, seed=13)
+    cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
+    fl = d["flow"] * 20
+    save("corr_oob", lookup=cb(fl))
+
+    # ---- G2: temporal PE (ppmtereo_update.py:25-49) -------------------------------------------
+    pes = {f"T{T}": rupd.get_temporal_positional_encoding(T, 128, "cpu", is_normalize=True, scale=1.0).reshape(T, 128) for T in (1, 2, 5, 8)}
+    save("temporal_pe", **pes)
+
+    # ---- G3: convex upsample (ppmstereo.py:185-197) ---------------------------------------------
+    m = bare_model()
+    fl, mk = hash_normal((3, 2, 6, 10), 31), hash_normal((3, 144, 6, 10), 32)
+    save("convex_upsample", out=m.convex_upsample(fl, mk, 4))
+
+    # ---- G4: update-block pieces (ppmtereo_update.py) -------------------------------------------
+    blk = m.update_block16
+    T, h, w = 5, 8, 32
+    d = synth_scale_inputs(T, h, w, seed=41, with_mhs=False)
+    corr = hash_normal((T, 36, h, w), 42)
+    mf, mhs, val = blk.get_motion_and_value(d["flow"], corr, None, d["inp"])
+    mf2, mhs2, val2 = blk.get_motion_and_value(d["flow"], corr, mhs, d["inp"])
+    unc = blk.get_uncertainty(torch.cat([d["net"], val], 1))
+    mfg = mf + 0.3 * hash_normal((T, 128, h, w), 43)
+    net, mask, dflow = blk(d["net"], d["inp"], mf, mfg, t=T)
+    x = torch.cat([d["inp"], mf, mfg], 1)
+    xt = blk.time_attn(x, T=T)
+    xs = blk.space_attn(xt, T=T)
+    save("update_block16_pieces", mf=mf, mhs=mhs, value=val, mf2=mf2, mhs2=mhs2, unc=unc, net=net, mask=mask,
+         dflow=dflow, time_attn=xt, space_attn=xs)
+    blk = m.update_block04
+    net4, mask4, dflow4 = blk(d["net"], d["inp"], mf, mfg, t=T)
+    n5 = d["net"].reshape(1, T, 128, h, w).permute(0, 2, 1, 3, 4)
+    x5 = x.reshape(1, T, 384, h, w).permute(0, 2, 1, 3, 4)
+    save("update_block04_pieces", net=net4, mask=mask4, dflow=dflow4, gru=blk.gru(n5, x5), flow_head=blk.flow_head(n5))
+
+    # ---- G5: forward_update_block at the three scales (ppmstereo.py:426-594) -------------------
+    for name, tag, ai, T, h, w, iters, isc, mh in (("fub16", "update_block16", 0, 5, 8, 32, 2, 4, False),
+                                                  ("fub08", "update_block08", 1, 8, 8, 32, 3, 2, True),
+                                                  ("fub04", "update_block04", 2, 5, 16, 64, 2, 1, True),
+                                                  ("fub04_T2", "update_block04", 2, 2, 8, 32, 2, 1, True)):
+        d = synth_scale_inputs(T, h, w, seed=50 + ai + 10 * T, with_mhs=mh)
+        cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
+        preds, uncs = [], []
+        ATTN_LOG.clear()
+        fo, net, mhs = m.forward_update_block(None, getattr(m, tag), cb, d["flow"], d["net"], d["inp"], d["mhs"], m.att[ai],
+                                              preds, uncs, iters, isc, T)
+        q0, k0, v0, sc, o0 = ATTN_LOG[T * (iters - 1) + 1]     # last iteration, clip 1
+        save(name, flow_out=fo, net=net, mhs=mhs, preds=torch.stack(preds), uncs=torch.stack(uncs),
+             attn_q=q0.float()[0, :, 0], attn_k=k0.float()[0, :, 0], attn_v=v0.float()[0, :, 0], attn_o=o0.float()[0, :, 0],
+             attn_scale=sc, n_attn_calls=len(ATTN_LOG))
+
+    # ---- G6: the whole cascade through PPMStereo.forward with stubbed encoders ------------------
+    T, H, W = 3, 64, 256
+    fm1, fm2 = hash_normal((T, 256, H // 4, W // 4), 71), hash_normal((T, 256, H // 4, W // 4), 72)
+    ctx = [hash_normal((T, 256, H // s, W // s), 73 + i) for i, s in enumerate((4, 8, 16))]
+
+    class FNet(nn.Module):
+        def forward(self, x):
+            return fm1, fm2
+
+    class CNet(nn.Module):
+        def forward(self, x):
+            return ctx[0], ctx[1], ctx[2]
+
+    m.fnet, m.cnet = FNet(), CNet()
+    img = torch.zeros(1, T, 3, H, W)
+    ATTN_LOG.clear()
+    disp, unc = m.forward(img, img, iters=4, test_mode=True)
+    save("cascade", disparity=disp, uncertainty=unc, n_attn_calls=len(ATTN_LOG))
+
+    # ---- G7: T == 1 -> NaN known answer (SURVEY.md hazard 1) ------------------------------------
+    d = synth_scale_inputs(1, 8, 32, seed=81)
+    cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
+    preds, uncs = [], []
+    fo, net, mhs = m.forward_update_block(None, m.update_block04, cb, d["flow"], d["net"], d["inp"], d["mhs"], m.att[2], preds, uncs, 1, 1, 1)
+    save("fub_T1_nan", all_nan=bool(torch.isnan(fo).all()), any_nan=bool(torch.isnan(fo).any()))
+
+
+if __name__ == "__main__":
+    main()
