@@ -1,0 +1,150 @@
+/*
+ * ppms.h -- C ABI of libppms (MI355X / gfx950 kernels for the PPMStereo hot path).
+ *
+ * The reference (cocowy1/PPMStereo) has no native code: every op below replaces a PyTorch call site on the path
+ * PPMStereo.forward_update_block (/root/reference/models/core/ppmstereo.py:426-594).  Each entry point cites the
+ * reference interface it replaces.  Conventions:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers owned by the caller (PyTorch caching
+ *     allocator); the library never allocates, frees or retains device memory;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*); no call synchronises the device;
+ *   - return 0 on success, a negative PPMS_E* code otherwise; ppms_last_error() gives the thread-local message;
+ *   - "SP" tensors are the library's internal activation format: channel-last [pixel][ld] bf16 hi plane and
+ *     bf16 lo plane with x ~= hi + lo (fp32-accurate bf16x3 MFMA operands).  pixel = (frame*H + y)*W + x.
+ */
+#ifndef PPMS_H
+#define PPMS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPMS_OK 0
+#define PPMS_EINVAL (-1)   /* shape / argument contract violated (e.g. W too small for the pyramid) */
+#define PPMS_ELAUNCH (-2)  /* HIP launch error */
+#define PPMS_ENODEV (-3)   /* no gfx950 device */
+
+#define PPMS_ABI_VERSION 1
+
+int ppms_version(void);
+const char* ppms_last_error(void);
+/* 0 when a gfx950 device is current; fills name (<= 63 chars) */
+int ppms_device_info(char* name, int name_cap, int* cu_count, int* clock_mhz);
+
+/* ---------------------------------------------------------------- correlation (models/core/corr.py) */
+/* CorrBlock1D.__init__ + CorrBlock1D.corr, corr.py:56-72,96-104.
+ * fmap1,fmap2: fp32 NCHW (B,C,H,W).  pyr[l] (l=0..4): fp32 (B*H*W, W>>l) with W>>l floored; level 4 is stored
+ * but never read, as in the reference.  vol = sum_c f1 f2 / sqrt(C); level l+1 = avg of adjacent pairs. */
+int ppms_corr_build(const float* fmap1, const float* fmap2, float* const pyr[5], int B, int C, int H, int W, void* stream);
+
+/* CorrBlock1D.__call__ + bilinear_sampler + coords_grid, corr.py:74-94,10-27,47-52.
+ * flow: fp32, (B,2,H,W) NCHW when flow_nhwc == 0, [pixel][2] otherwise (only channel 0 is read).
+ * out_nchw (optional): fp32 (B,36,H,W).  out_hi/out_lo (optional): SP [pixel][out_ld], channels 36..63 zeroed.
+ * flow_sp_hi/lo (optional): SP copy of both flow channels written at [pixel][flow_sp_ld] + {0,1}. */
+int ppms_corr_lookup(const float* const pyr[4], const float* flow, int flow_nhwc, float* out_nchw, void* out_hi, void* out_lo,
+                     int out_ld, void* flow_sp_hi, void* flow_sp_lo, int flow_sp_ld, int B, int H, int W, void* stream);
+
+/* ---------------------------------------------------------------- implicit-GEMM convolution */
+/* Replaces every cuDNN conv2d/conv3d call of the update block (ppmtereo_update.py:292-310, 473-480, 673-674,
+ * 889-893, 910-914, 646, 129): out[cout][pixel] = sum_{tap,ci} W[cout][tap][ci] * X[ci][pixel + tap], zero padded,
+ * computed as hi*hi + hi*lo + lo*hi on bf16 MFMA with fp32 accumulation. */
+typedef struct ppms_sp {          /* a channel-last split-bf16 view */
+    void* hi;
+    void* lo;
+    int32_t ld;                   /* elements between pixels */
+    int32_t c;                    /* channels in this view (inputs: multiple of 32) */
+} ppms_sp;
+
+enum {                            /* epilogue kinds */
+    PPMS_EPI_STORE = 0,           /* y = act(acc + bias) * scale                                 */
+    PPMS_EPI_RESID = 1,           /* y = act(aux_sp + acc + bias)                                  */
+    PPMS_EPI_RH = 2,              /* y = sigmoid(acc + bias) * aux_sp               (GRU r * h)    */
+    PPMS_EPI_GRU = 3,             /* y = (1 - z) * aux_sp + z * tanh(acc + bias), z = aux_f32      */
+    PPMS_EPI_ADDF32 = 4           /* out_f32 += acc + bias (in place)              (flow += dflow) */
+};
+enum { PPMS_ACT_NONE = 0, PPMS_ACT_RELU = 1, PPMS_ACT_GELU = 2, PPMS_ACT_SIGMOID = 3, PPMS_ACT_TANH = 4 };
+
+typedef struct ppms_epilogue {
+    int32_t kind, act;
+    float scale;
+    int32_t n_valid;              /* couts [0, n_valid) of this half are stored                    */
+    ppms_sp out_sp;               /* optional (hi == NULL: skip)                                   */
+    float* out_f32;               /* optional [pixel][out_f32_ld]                                  */
+    int32_t out_f32_ld;
+    void* out_vt;                 /* optional bf16 [frame][n_valid][H*W] (transposed, attention V) */
+    ppms_sp aux_sp;               /* residual / h                                                  */
+    const float* aux_f32;         /* z                                                             */
+    int32_t aux_f32_ld;
+} ppms_epilogue;
+
+typedef struct ppms_conv {
+    ppms_sp seg[2];               /* input channel segments, concatenated along K                 */
+    int32_t nseg;
+    const void* w;                /* packed weights, see ppmstereo_amd/packing.py                  */
+    const float* bias;            /* [M] fp32 (never NULL; zeros when the conv has no bias)        */
+    int32_t T, H, W;              /* volume; pixels = T*H*W                                        */
+    int32_t kt, kh, kw;           /* odd kernel extents, "same" zero padding                       */
+    int32_t M;                    /* padded couts, multiple of 64                                  */
+    int32_t m_split;              /* couts >= m_split use epi[1] with cout - m_split (multiple of 64; >= M: unused) */
+    ppms_epilogue epi[2];
+} ppms_conv;
+
+/* desc: host copy (validated, sizes the grid); dev_desc: the same bytes in device memory (caller-owned, must stay
+ * valid until the kernel has run -- descriptors are built once per scale, every pointer in them is fixed). */
+int ppms_conv_gemm(const ppms_conv* desc, const ppms_conv* dev_desc, void* stream);
+/* sizeof(ppms_sp), sizeof(ppms_epilogue), sizeof(ppms_conv) as compiled: lets a foreign-language binding check its
+ * struct layout at load time */
+int ppms_struct_sizes(int* sp, int* epilogue, int* conv);
+
+/* ---------------------------------------------------------------- small ops of the update block */
+/* depthwise k x k conv + residual GELU of PCBlock4_Deep_nopool_res (ppmtereo_update.py:1026-1027):
+ * y = gelu(x + dw(x) + b) on an SP tensor; w: fp32 [C][k*k], b: fp32 [C]; k in {1,7}. */
+int ppms_dwconv_gelu(ppms_sp x, ppms_sp y, const float* w, const float* b, int k, int BT, int H, int W, void* stream);
+/* im2col of the 2-channel flow for convf1 (7x7, ppmtereo_update.py:452,477): patch[pixel][tap*2+c], 98 -> 128 zero padded */
+int ppms_flow_patch7(const float* flow_nhwc, ppms_sp patch, int BT, int H, int W, void* stream);
+/* uncertainty tail: sigmoid(w . x + b) per pixel (ppmtereo_update.py:891-892) + per-frame partial sums for the
+ * QAM frame confidence (ppmstereo.py:506).  unc: fp32 [pixel]; partial: fp32 [BT][nblk], nblk = ceil(H*W/256). */
+int ppms_unc_tail(ppms_sp x, const float* w, float bias, float* unc, float* partial, int BT, int HW, void* stream);
+
+/* layout converters between the reference's NCHW fp32 tensors and SP / channel-last fp32 */
+int ppms_nchw_to_sp(const float* src, ppms_sp dst, int BT, int C, int HW, void* stream);
+int ppms_sp_to_nchw(ppms_sp src, float* dst, int BT, int C, int HW, void* stream);
+int ppms_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int BT, int C, int HW, void* stream);
+int ppms_nhwc_to_nchw(const float* src, int src_ld, float* dst, int BT, int C, int HW, void* stream);
+int ppms_f32_to_sp(const float* src, int src_ld, ppms_sp dst, int64_t pixels, void* stream);
+int ppms_sp_to_f32(ppms_sp src, float* dst, int dst_ld, int64_t pixels, void* stream);
+
+/* flow = flow + delta_flow (ppmstereo.py:571); flow: fp32 [pixel][2], dflow: fp32 [pixel][dflow_ld] */
+int ppms_flow_add(float* flow_nhwc, const float* dflow, int dflow_ld, int64_t pixels, void* stream);
+/* PPMStereo.convex_upsample, ppmstereo.py:185-197.  flow: fp32 [pixel][2]; mask: fp32 [pixel][mask_ld] (144 used);
+ * out: fp32 NCHW (BT,2,4H,4W). */
+int ppms_convex_upsample(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int BT, int H, int W, void* stream);
+/* F.interpolate(mode="bilinear") on NCHW fp32, both align_corners modes (ppmstereo.py:578,580-587; utils.py:10-16);
+ * out = mul * interp(src). */
+int ppms_bilinear(const float* src, float* dst, int N, int C, int H, int W, int OH, int OW, int align_corners, float mul, void* stream);
+
+/* ---------------------------------------------------------------- pick-and-play memory attention */
+/* PPMStereo.compute_qk_similarity, ppmstereo.py:397-423.  q,k: fp32 [T][H*W][ld] channel-last (128 channels);
+ * pooled: workspace fp32 [2][T][(H/4)*(W/4)]; sim: fp32 [T][T], sim[i][j] = cos(kbar_i, qbar_j). */
+int ppms_qk_similarity(const float* q, const float* k, int ld, float* pooled, float* sim, int T, int H, int W, void* stream);
+/* QAM score + top-k pick + usage counter, ppmstereo.py:501-513, and the normalised play scores of :532-533.
+ * conf_partial: output of ppms_unc_tail; strive: fp32 [T][T] in/out; sel: int32 [T][5] ascending frame ids;
+ * shat: fp32 [T][5]; score (optional): fp32 [T][T]. */
+int ppms_qam_select(const float* sim, float* strive, const float* conf_partial, int nblk, int HW, int32_t* sel, float* shat,
+                    float* score, int T, void* stream);
+/* Q = bf16(q_i + PE_i) (ppmstereo.py:518-522); qb: bf16 [T][n][128] */
+int ppms_attn_prep_q(const float* q, int ld, const float* pe, void* qb, int T, int n, void* stream);
+/* K' = bf16(K_j * s_hat_ij + PE_j) for the picked frames (ppmstereo.py:541,547); kb: bf16 [T][ksel][n][128] */
+int ppms_attn_prep_k(const float* key, int ld, const float* pe, const int32_t* sel, const float* shat, void* kb, int T, int ksel,
+                     int n, void* stream);
+/* flash_attn_func call of ppmstereo.py:550 for all T clips + the aggregation of :552:
+ * hid = bf16(softmax(Q K'^T * scale) V); mfg = mf + beta * hid.
+ * qb: bf16 [T][n][128]; kb: bf16 [T][ksel][n][128]; vt: bf16 [T][128][n] (per-frame transposed values, picked through
+ * sel); mf / mfg: SP views (128 channels).  out_bf16 (optional): bf16 [T][n][128] raw attention output. */
+int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
+                  ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

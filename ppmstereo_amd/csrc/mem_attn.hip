@@ -1,0 +1,236 @@
+// Pick-and-Play memory read-out: for every clip i, hid_i = bf16( softmax(Q_i K'_i^T * scale) V_i ) over the
+// pixels of the picked frames, fused with mfg_i = mf_i + beta * hid_i.
+// Replaces the T sequential flash_attn_func calls of /root/reference/models/core/ppmstereo.py:517-552
+// (1 head, d = 128, Nq = n, Nk = ksel * n; bf16 operands, fp32 softmax / accumulate, bf16 result).
+//
+// gfx950 structure: workgroup = 4 waves x 32 queries; KV tile = 64 keys; swapped QK^T (S^T = K Q^T, so a query's
+// scores sit in one lane pair and softmax needs one cross-lane op); the S^T accumulator tile is re-used in place as
+// the B operand of O^T += V^T P^T (no LDS round trip for P); V arrives already transposed ([d][key], written by the
+// to_v conv epilogue) so both MFMA operands are plain 8/16-byte LDS reads.  K rows are XOR-swizzled on 16-B chunks,
+// V^T rows on 8-B granules: all fragment reads are bank-conflict free.  Two LDS stages, register-staged prefetch.
+#include "common.h"
+
+namespace {
+
+constexpr int D = 128, KT = 64, QW = 32, NW = 4;
+constexpr int K_TILE = KT * D * 2;       // 16 KiB
+constexpr int V_TILE = D * KT * 2;       // 16 KiB
+constexpr int ATT_STAGE = K_TILE + V_TILE;
+
+__device__ __forceinline__ u32x4 load16_guard(const bf16_t* row, int e0, int limit, bool vec_ok) {
+    // 8 bf16 at row[e0 .. e0+8), elements >= limit read as 0
+    if (vec_ok && e0 + 8 <= limit) return gload16(row + e0);
+    u32x4 v = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        unsigned int bits = 0;
+        if (e0 + j < limit) bits = *(const PPMS_GLOBAL unsigned short*)(uintptr_t)(row + e0 + j);
+        v[j >> 1] |= bits << (16 * (j & 1));
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
+                                                          const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
+                                                          float scale_log2, const float* __restrict__ beta_p, ppms_sp mf, ppms_sp mfg,
+                                                          bf16_t* __restrict__ out_bf16, int n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int clip = blockIdx.y;
+    const int q0 = blockIdx.x * (QW * NW) + wave * QW;
+    const int qi = q0 + r;                       // this lane's query
+    const int qc = qi < n ? qi : n - 1;          // clamped for loads
+    const bool n_vec = (n & 7) == 0;
+
+    // ---- Q fragments: B operand of S^T = K Q^T, lane (r,h) holds Q[q][16 s + 8 h + j] -----------------
+    bf16x8 qf[8];
+    {
+        const bf16_t* qp = qb + ((int64_t)clip * n + qc) * D + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (f32x16){0};
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int tpf = (n + KT - 1) / KT;           // tiles per frame
+    const int ntile = ksel * tpf;
+
+    u32x4 rk[4], rv[4];
+    auto load_tile = [&](int it) {
+        const int slot = it / tpf;
+        const int key0 = (it - slot * tpf) * KT;
+        const int frame = sel[clip * 5 + slot];
+        // K': [clip][slot][key][128], 256-B rows; thread -> rows (tid>>4) + 16 i, chunk tid&15
+        const bf16_t* kbase = kb + ((int64_t)(clip * ksel + slot) * n) * D;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = key0 + (tid >> 4) + 16 * i;
+            rk[i] = key < n ? gload16(kbase + (int64_t)key * D + (tid & 15) * 8) : (u32x4){0, 0, 0, 0};
+        }
+        // V^T: [frame][d][n], this tile = 64 keys (128 B) of every d row; thread -> d = (tid>>3) + 32 i, chunk tid&7
+        const bf16_t* vbase = vt + (int64_t)frame * D * n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = (tid >> 3) + 32 * i;
+            rv[i] = load16_guard(vbase + (int64_t)d * n, key0 + (tid & 7) * 8, n, n_vec);
+        }
+    };
+    auto store_tile = [&](int stage) {
+        char* ks = smem + stage * ATT_STAGE;
+        char* vs = ks + K_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            *(u32x4*)(ks + row * 256 + (((tid & 15) ^ (row & 15)) << 4)) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int d = (tid >> 3) + 32 * i;
+            const int f = (d >> 1) & 15;
+            u32x4 v = rv[i];
+            if (f & 1) v = (u32x4){v[2], v[3], v[0], v[1]};     // the 8-B granule swizzle swaps the halves of a chunk
+            *(u32x4*)(vs + d * 128 + (((tid & 7) ^ (f >> 1)) << 4)) = v;
+        }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const bool more = it + 1 < ntile;
+        if (more) load_tile(it + 1);
+        const char* ks = smem + (it & 1) * ATT_STAGE;
+        const char* vs = ks + K_TILE;
+
+        // ---- S^T[key][query] = K Q^T ---------------------------------------------------------------
+        f32x16 st[2];
+        st[0] = (f32x16){0};
+        st[1] = (f32x16){0};
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+#pragma unroll
+            for (int kblk = 0; kblk < 2; ++kblk) {
+                const int row = kblk * 32 + r;
+                const bf16x8 kf = *(const bf16x8*)(ks + row * 256 + (((2 * s + h) ^ (row & 15)) << 4));
+                st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kblk], 0, 0, 0);
+            }
+        }
+        // ---- mask keys beyond the frame (last tile of a frame when n % 64 != 0) -----------------------
+        const int key0 = (it % tpf) * KT;
+        if (key0 + KT > n) {
+#pragma unroll
+            for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int key = key0 + kblk * 32 + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    if (key >= n) st[kblk][g] = -INFINITY;
+                }
+        }
+        // ---- online softmax (fp32), one query per lane pair (r, r+32) --------------------------------
+        float mx = st[0][0];
+#pragma unroll
+        for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, st[kblk][g]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx * scale_log2);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.0f;
+#pragma unroll
+        for (int kblk = 0; kblk < 2; ++kblk)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const float p = exp2f(st[kblk][g] * scale_log2 - m_new);
+                st[kblk][g] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+
+        // ---- O^T[d][query] += V^T P^T ; P^T fragments come straight from the S^T accumulators -------------
+#pragma unroll
+        for (int kblk = 0; kblk < 2; ++kblk) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kblk][8 * s2 + j];
+                const int g1 = kblk * 8 + 4 * s2 + h;          // 8-B granule of keys 16 s2 + 4 h .. +3 ; +2 granules: keys +8
+#pragma unroll
+                for (int dblk = 0; dblk < 4; ++dblk) {
+                    const int d = dblk * 32 + r;
+                    const int f = (d >> 1) & 15;
+                    const bf16x4 v0 = *(const bf16x4*)(vs + d * 128 + ((g1 ^ f) << 3));
+                    const bf16x4 v1 = *(const bf16x4*)(vs + d * 128 + (((g1 + 2) ^ f) << 3));
+                    bf16x8 vf;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        vf[j] = v0[j];
+                        vf[4 + j] = v1[j];
+                    }
+                    o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dblk], 0, 0, 0);
+                }
+            }
+        }
+        if (more) store_tile((it + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: hid = bf16(O / l); mfg = mf + beta * hid ---------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (qi >= n) return;
+    const float inv_l = 1.0f / l_tot;
+    const float beta = beta_p[0];
+    const int64_t pix = (int64_t)clip * n + qi;
+    const bf16_t* mh = (const bf16_t*)mf.hi + pix * mf.ld;
+    const bf16_t* ml = (const bf16_t*)mf.lo + pix * mf.ld;
+    bf16_t* gh = (bf16_t*)mfg.hi + pix * mfg.ld;
+    bf16_t* gl = (bf16_t*)mfg.lo + pix * mfg.ld;
+#pragma unroll
+    for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d = dblk * 32 + 8 * g + 4 * h;
+            bf16x4 hid;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) hid[j] = (bf16_t)(o[dblk][4 * g + j] * inv_l);
+            if (out_bf16) *(bf16x4*)(out_bf16 + pix * D + d) = hid;
+            const bf16x4 a = *(const bf16x4*)(mh + d), b = *(const bf16x4*)(ml + d);
+            bf16x4 oh, ol;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = join_bf16(a[j], b[j]) + beta * (float)hid[j];
+                bf16_t hh, ll;
+                split_bf16(y, hh, ll);
+                oh[j] = hh;
+                ol[j] = ll;
+            }
+            *(bf16x4*)(gh + d) = oh;
+            *(bf16x4*)(gl + d) = ol;
+        }
+}
+
+}  // namespace
+
+extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
+                             ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* stream) {
+    PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
+    PPMS_REQUIRE(ksel >= 1 && ksel <= 5 && T >= 1 && n >= 1, "mem_attn: bad sizes ksel=%d T=%d n=%d", ksel, T, n);
+    PPMS_REQUIRE(mf.hi && mf.lo && mfg.hi && mfg.lo && mf.ld % 4 == 0 && mfg.ld % 4 == 0, "mem_attn: mf / mfg must be 8-B aligned SP views");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)mem_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        attr_set = true;
+    }
+    const float scale_log2 = scale * 1.4426950408889634f;
+    dim3 grid(ceil_div(n, QW * NW), T);
+    hipLaunchKernelGGL(mem_attn_kernel, grid, dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, (const bf16_t*)qb, (const bf16_t*)kb,
+                       (const bf16_t*)vt, sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n);
+    return ppms_check_launch("mem_attn");
+}

@@ -1,0 +1,543 @@
+// HBM-bound helper kernels of the hot path: depthwise conv, flow im2col, uncertainty tail, layout converters,
+// convex / bilinear upsampling, frame similarity, QAM pick, attention operand preparation.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void ppms_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+int ppms_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        ppms_set_error("%s: HIP launch failed: %s", what, hipGetErrorString(e));
+        return PPMS_ELAUNCH;
+    }
+    return PPMS_OK;
+}
+extern "C" const char* ppms_last_error(void) { return g_err; }
+extern "C" int ppms_version(void) { return PPMS_ABI_VERSION; }
+extern "C" int ppms_struct_sizes(int* sp, int* epilogue, int* conv) {
+    if (sp) *sp = (int)sizeof(ppms_sp);
+    if (epilogue) *epilogue = (int)sizeof(ppms_epilogue);
+    if (conv) *conv = (int)sizeof(ppms_conv);
+    return PPMS_OK;
+}
+extern "C" int ppms_device_info(char* name, int name_cap, int* cu_count, int* clock_mhz) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        ppms_set_error("no HIP device");
+        return PPMS_ENODEV;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        ppms_set_error("hipGetDeviceProperties failed");
+        return PPMS_ENODEV;
+    }
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", prop.gcnArchName);
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    return PPMS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ depthwise conv
+// y = gelu(x + dw_k(x) + b), PCBlock4_Deep_nopool_res.forward (ppmtereo_update.py:1026-1027)
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_gelu_kernel(ppms_sp x, ppms_sp y, const float* __restrict__ w, const float* __restrict__ b,
+                                                          int H, int W, int64_t P) {
+    const int C = x.c;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * C) return;
+    const int c = (int)(idx % C);
+    const int64_t pix = idx / C;
+    const int px = (int)(pix % W);
+    const int py = (int)((pix / W) % H);
+    const bf16_t* xh = (const bf16_t*)x.hi;
+    const bf16_t* xl = (const bf16_t*)x.lo;
+    const float x0 = join_bf16(xh[pix * x.ld + c], xl[pix * x.ld + c]);
+    float acc = b[c];
+    constexpr int R = K / 2;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int yy = py + ky - R;
+        if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int xx = px + kx - R;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const int64_t q = pix + (int64_t)(ky - R) * W + (kx - R);
+            acc += w[c * K * K + ky * K + kx] * join_bf16(xh[q * x.ld + c], xl[q * x.ld + c]);
+        }
+    }
+    bf16_t hi, lo;
+    split_bf16(gelu_erf(x0 + acc), hi, lo);
+    ((bf16_t*)y.hi)[pix * y.ld + c] = hi;
+    ((bf16_t*)y.lo)[pix * y.ld + c] = lo;
+}
+
+extern "C" int ppms_dwconv_gelu(ppms_sp x, ppms_sp y, const float* w, const float* b, int k, int BT, int H, int W, void* stream) {
+    PPMS_REQUIRE(k == 1 || k == 7, "dwconv_gelu: k=%d (only 1 and 7)", k);
+    PPMS_REQUIRE(x.hi && x.lo && y.hi && y.lo && x.c == y.c && x.c > 0, "dwconv_gelu: bad views");
+    const int64_t P = (int64_t)BT * H * W;
+    const dim3 grid(ceil_div(P * x.c, 256));
+    if (k == 1)
+        hipLaunchKernelGGL(dwconv_gelu_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P);
+    else
+        hipLaunchKernelGGL(dwconv_gelu_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P);
+    return ppms_check_launch("dwconv_gelu");
+}
+
+// ------------------------------------------------------------------------------------------------ flow im2col (convf1 7x7, Cin=2)
+__global__ __launch_bounds__(256) void flow_patch7_kernel(const float* __restrict__ flow, ppms_sp patch, int H, int W, int64_t P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * 128) return;
+    const int k = (int)(idx & 127);
+    const int64_t pix = idx >> 7;
+    float v = 0.0f;
+    if (k < 98) {
+        const int tap = k >> 1, c = k & 1;
+        const int ky = tap / 7, kx = tap - ky * 7;
+        const int px = (int)(pix % W), py = (int)((pix / W) % H);
+        const int xx = px + kx - 3, yy = py + ky - 3;
+        if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) v = flow[(pix + (int64_t)(ky - 3) * W + (kx - 3)) * 2 + c];
+    }
+    bf16_t hi, lo;
+    split_bf16(v, hi, lo);
+    ((bf16_t*)patch.hi)[pix * patch.ld + k] = hi;
+    ((bf16_t*)patch.lo)[pix * patch.ld + k] = lo;
+}
+
+extern "C" int ppms_flow_patch7(const float* flow_nhwc, ppms_sp patch, int BT, int H, int W, void* stream) {
+    PPMS_REQUIRE(flow_nhwc && patch.hi && patch.lo && patch.ld >= 128, "flow_patch7: bad arguments");
+    const int64_t P = (int64_t)BT * H * W;
+    hipLaunchKernelGGL(flow_patch7_kernel, dim3(ceil_div(P * 128, 256)), dim3(256), 0, (hipStream_t)stream, flow_nhwc, patch, H, W, P);
+    return ppms_check_launch("flow_patch7");
+}
+
+// ------------------------------------------------------------------------------------------------ uncertainty tail
+// unc = sigmoid(w . x + b) (128 -> 1), plus deterministic per-(frame, 256-pixel block) partial sums
+__global__ __launch_bounds__(256) void unc_tail_kernel(ppms_sp x, const float* __restrict__ w, float bias, float* __restrict__ unc,
+                                                       float* __restrict__ partial, int HW, int nblk) {
+    __shared__ float red[16];
+    const int frame = blockIdx.y, blk = blockIdx.x;
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;   // 16 lanes per pixel, 8 channels each
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = w[sub * 8 + j];
+    float local = 0.0f;
+    for (int it = 0; it < 16; ++it) {
+        const int pin = blk * 256 + it * 16 + grp;
+        float s = 0.0f;
+        if (pin < HW) {
+            const int64_t pix = (int64_t)frame * HW + pin;
+            const bf16x8 h8 = *(const bf16x8*)((const bf16_t*)x.hi + pix * x.ld + sub * 8);
+            const bf16x8 l8 = *(const bf16x8*)((const bf16_t*)x.lo + pix * x.ld + sub * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += wv[j] * join_bf16(h8[j], l8[j]);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        s += __shfl_xor(s, 8);
+        if (pin < HW && sub == 0) {
+            const float u = sigmoid_f(s + bias);
+            unc[(int64_t)frame * HW + pin] = u;
+            local += u;
+        }
+    }
+    // fixed-order block sum: 16 group leaders -> LDS -> thread 0
+    if (sub == 0) red[grp] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        partial[frame * nblk + blk] = t;
+    }
+}
+
+extern "C" int ppms_unc_tail(ppms_sp x, const float* w, float bias, float* unc, float* partial, int BT, int HW, void* stream) {
+    PPMS_REQUIRE(x.hi && x.lo && x.c == 128 && x.ld % 8 == 0, "unc_tail: expects a 128-channel SP view");
+    const int nblk = ceil_div(HW, 256);
+    hipLaunchKernelGGL(unc_tail_kernel, dim3(nblk, BT), dim3(256), 0, (hipStream_t)stream, x, w, bias, unc, partial, HW, nblk);
+    return ppms_check_launch("unc_tail");
+}
+
+// ------------------------------------------------------------------------------------------------ layout converters
+// tiled transposes between [frame][C][HW] (NCHW) and [frame*HW][ld] (channel-last); 32x32 tiles through LDS
+enum { CV_F32 = 0, CV_SP = 1 };
+template <int DST_KIND>
+__global__ __launch_bounds__(256) void nchw_to_cl_kernel(const float* __restrict__ src, float* __restrict__ dst_f32, int dst_ld,
+                                                         ppms_sp dst_sp, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int frame = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        tile[i][tx] = (c < C && p < HW) ? src[((int64_t)frame * C + c) * HW + p] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        if (p < HW && c < C) {
+            const float v = tile[tx][i];
+            const int64_t pix = (int64_t)frame * HW + p;
+            if (DST_KIND == CV_F32) {
+                dst_f32[pix * dst_ld + c] = v;
+            } else {
+                bf16_t hi, lo;
+                split_bf16(v, hi, lo);
+                ((bf16_t*)dst_sp.hi)[pix * dst_sp.ld + c] = hi;
+                ((bf16_t*)dst_sp.lo)[pix * dst_sp.ld + c] = lo;
+            }
+        }
+    }
+}
+template <int SRC_KIND>
+__global__ __launch_bounds__(256) void cl_to_nchw_kernel(const float* __restrict__ src_f32, int src_ld, ppms_sp src_sp,
+                                                         float* __restrict__ dst, int C, int HW) {
+    __shared__ float tile[32][33];
+    const int frame = blockIdx.z;
+    const int c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int p = p0 + i, c = c0 + tx;
+        float v = 0.0f;
+        if (p < HW && c < C) {
+            const int64_t pix = (int64_t)frame * HW + p;
+            if (SRC_KIND == CV_F32)
+                v = src_f32[pix * src_ld + c];
+            else
+                v = join_bf16(((const bf16_t*)src_sp.hi)[pix * src_sp.ld + c], ((const bf16_t*)src_sp.lo)[pix * src_sp.ld + c]);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, p = p0 + tx;
+        if (c < C && p < HW) dst[((int64_t)frame * C + c) * HW + p] = tile[tx][i];
+    }
+}
+
+extern "C" int ppms_nchw_to_sp(const float* src, ppms_sp dst, int BT, int C, int HW, void* stream) {
+    PPMS_REQUIRE(src && dst.hi && dst.lo && dst.ld >= C, "nchw_to_sp: bad arguments");
+    hipLaunchKernelGGL(nchw_to_cl_kernel<CV_SP>, dim3(ceil_div(HW, 32), ceil_div(C, 32), BT), dim3(256), 0, (hipStream_t)stream, src,
+                       (float*)nullptr, 0, dst, C, HW);
+    return ppms_check_launch("nchw_to_sp");
+}
+extern "C" int ppms_nchw_to_nhwc(const float* src, float* dst, int dst_ld, int BT, int C, int HW, void* stream) {
+    PPMS_REQUIRE(src && dst && dst_ld >= C, "nchw_to_nhwc: bad arguments");
+    ppms_sp none = {nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(nchw_to_cl_kernel<CV_F32>, dim3(ceil_div(HW, 32), ceil_div(C, 32), BT), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       dst_ld, none, C, HW);
+    return ppms_check_launch("nchw_to_nhwc");
+}
+extern "C" int ppms_sp_to_nchw(ppms_sp src, float* dst, int BT, int C, int HW, void* stream) {
+    PPMS_REQUIRE(dst && src.hi && src.lo && src.ld >= C, "sp_to_nchw: bad arguments");
+    hipLaunchKernelGGL(cl_to_nchw_kernel<CV_SP>, dim3(ceil_div(HW, 32), ceil_div(C, 32), BT), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, 0, src, dst, C, HW);
+    return ppms_check_launch("sp_to_nchw");
+}
+extern "C" int ppms_nhwc_to_nchw(const float* src, int src_ld, float* dst, int BT, int C, int HW, void* stream) {
+    PPMS_REQUIRE(src && dst && src_ld >= C, "nhwc_to_nchw: bad arguments");
+    ppms_sp none = {nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(cl_to_nchw_kernel<CV_F32>, dim3(ceil_div(HW, 32), ceil_div(C, 32), BT), dim3(256), 0, (hipStream_t)stream, src,
+                       src_ld, none, dst, C, HW);
+    return ppms_check_launch("nhwc_to_nchw");
+}
+
+__global__ __launch_bounds__(256) void f32_to_sp_kernel(const float* __restrict__ src, int src_ld, ppms_sp dst, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % dst.c);
+    const int64_t pix = idx / dst.c;
+    bf16_t hi, lo;
+    split_bf16(src[pix * src_ld + c], hi, lo);
+    ((bf16_t*)dst.hi)[pix * dst.ld + c] = hi;
+    ((bf16_t*)dst.lo)[pix * dst.ld + c] = lo;
+}
+__global__ __launch_bounds__(256) void sp_to_f32_kernel(ppms_sp src, float* __restrict__ dst, int dst_ld, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % src.c);
+    const int64_t pix = idx / src.c;
+    dst[pix * dst_ld + c] = join_bf16(((const bf16_t*)src.hi)[pix * src.ld + c], ((const bf16_t*)src.lo)[pix * src.ld + c]);
+}
+extern "C" int ppms_f32_to_sp(const float* src, int src_ld, ppms_sp dst, int64_t pixels, void* stream) {
+    PPMS_REQUIRE(src && dst.hi && dst.lo && dst.c > 0, "f32_to_sp: bad arguments");
+    const int64_t n = pixels * dst.c;
+    hipLaunchKernelGGL(f32_to_sp_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, src_ld, dst, n);
+    return ppms_check_launch("f32_to_sp");
+}
+extern "C" int ppms_sp_to_f32(ppms_sp src, float* dst, int dst_ld, int64_t pixels, void* stream) {
+    PPMS_REQUIRE(dst && src.hi && src.lo && src.c > 0, "sp_to_f32: bad arguments");
+    const int64_t n = pixels * src.c;
+    hipLaunchKernelGGL(sp_to_f32_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, dst_ld, n);
+    return ppms_check_launch("sp_to_f32");
+}
+
+// ------------------------------------------------------------------------------------------------ flow += delta_flow
+__global__ __launch_bounds__(256) void flow_add_kernel(float* __restrict__ flow, const float* __restrict__ dflow, int dflow_ld, int64_t P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * 2) return;
+    flow[idx] += dflow[(idx >> 1) * dflow_ld + (idx & 1)];
+}
+extern "C" int ppms_flow_add(float* flow_nhwc, const float* dflow, int dflow_ld, int64_t pixels, void* stream) {
+    PPMS_REQUIRE(flow_nhwc && dflow && dflow_ld >= 2, "flow_add: bad arguments");
+    hipLaunchKernelGGL(flow_add_kernel, dim3(ceil_div(pixels * 2, 256)), dim3(256), 0, (hipStream_t)stream, flow_nhwc, dflow, dflow_ld, pixels);
+    return ppms_check_launch("flow_add");
+}
+
+// ------------------------------------------------------------------------------------------------ convex upsample
+// out[n,c,4y+i,4x+j] = sum_k softmax_k(mask[n,16k+4i+j,y,x]) * 4*flow[n,c,y+k/3-1,x+k%3-1]   (ppmstereo.py:185-197)
+__global__ __launch_bounds__(256) void convex_upsample_kernel(const float* __restrict__ flow, const float* __restrict__ mask, int mask_ld,
+                                                              float* __restrict__ out, int H, int W, int64_t P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * 16) return;
+    const int sub = (int)(idx & 15);
+    const int64_t pix = idx >> 4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const int64_t frame = pix / ((int64_t)H * W);
+    const float* m = mask + pix * mask_ld + sub;
+    float mv[9], mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        mv[k] = m[16 * k];
+        mx = fmaxf(mx, mv[k]);
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        mv[k] = expf(mv[k] - mx);
+        den += mv[k];
+    }
+    float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int yy = y + k / 3 - 1, xx = x + k % 3 - 1;
+        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+            const int64_t q = pix + (int64_t)(k / 3 - 1) * W + (k % 3 - 1);
+            const float wgt = mv[k] / den;
+            o0 += wgt * (4.0f * flow[q * 2]);
+            o1 += wgt * (4.0f * flow[q * 2 + 1]);
+        }
+    }
+    const int i = sub >> 2, j = sub & 3;
+    const int64_t OW = 4 * (int64_t)W, OHW = 16 * (int64_t)H * W;
+    const int64_t o = (frame * 2) * OHW + (int64_t)(4 * y + i) * OW + 4 * x + j;
+    out[o] = o0;
+    out[o + OHW] = o1;
+}
+extern "C" int ppms_convex_upsample(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int BT, int H, int W, void* stream) {
+    PPMS_REQUIRE(flow_nhwc && mask && out && mask_ld >= 144, "convex_upsample: bad arguments");
+    const int64_t P = (int64_t)BT * H * W;
+    hipLaunchKernelGGL(convex_upsample_kernel, dim3(ceil_div(P * 16, 256)), dim3(256), 0, (hipStream_t)stream, flow_nhwc, mask, mask_ld,
+                       out, H, W, P);
+    return ppms_check_launch("convex_upsample");
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear resize
+// torch upsample_bilinear2d semantics (aten/native/UpSample.h area_pixel_compute_source_index)
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int OH, int OW,
+                                                       int align, float sh, float sw, float mul, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int ox = (int)(idx % OW);
+    const int oy = (int)((idx / OW) % OH);
+    const int64_t plane = idx / ((int64_t)OW * OH);
+    float fy = align ? sh * oy : fmaxf(sh * (oy + 0.5f) - 0.5f, 0.0f);
+    float fx = align ? sw * ox : fmaxf(sw * (ox + 0.5f) - 0.5f, 0.0f);
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + ((y0 < H - 1) ? 1 : 0), x1 = x0 + ((x0 < W - 1) ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const float* s = src + plane * H * W;
+    const float v = hy * (hx * s[y0 * W + x0] + lx * s[y0 * W + x1]) + ly * (hx * s[y1 * W + x0] + lx * s[y1 * W + x1]);
+    dst[idx] = mul * v;
+}
+extern "C" int ppms_bilinear(const float* src, float* dst, int N, int C, int H, int W, int OH, int OW, int align_corners, float mul,
+                             void* stream) {
+    PPMS_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "bilinear: bad arguments");
+    float sh, sw;
+    if (align_corners) {
+        sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.0f;
+        sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.0f;
+    } else {
+        sh = (float)H / (float)OH;
+        sw = (float)W / (float)OW;
+    }
+    const int64_t n = (int64_t)N * C * OH * OW;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, OH, OW, align_corners,
+                       sh, sw, mul, n);
+    return ppms_check_launch("bilinear");
+}
+
+// ------------------------------------------------------------------------------------------------ frame similarity
+// pooled[which][t][cell] = mean_c max_{adaptive window} x_t[c]  (AdaptiveMaxPool2d(h//4,w//4) + mean over channels)
+__global__ __launch_bounds__(128) void qk_pool_kernel(const float* __restrict__ q, const float* __restrict__ k, int ld,
+                                                      float* __restrict__ pooled, int T, int H, int W, int OH, int OW) {
+    __shared__ float red[128];
+    const int cell = blockIdx.x, t = blockIdx.y, which = blockIdx.z;
+    const int oy = cell / OW, ox = cell - oy * OW;
+    const int ys = (oy * H) / OH, ye = ((oy + 1) * H + OH - 1) / OH;
+    const int xs = (ox * W) / OW, xe = ((ox + 1) * W + OW - 1) / OW;
+    const float* src = (which ? k : q) + (int64_t)t * H * W * ld + threadIdx.x;
+    float m = -INFINITY;
+    for (int y = ys; y < ye; ++y)
+        for (int x = xs; x < xe; ++x) m = fmaxf(m, src[((int64_t)y * W + x) * ld]);
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pooled[((int64_t)which * T + t) * OH * OW + cell] = red[0] / 128.0f;
+}
+// sim[i][j] = cos(kbar_i, qbar_j), eps 1e-8 (F.cosine_similarity)
+__global__ __launch_bounds__(64) void qk_cos_kernel(const float* __restrict__ pooled, float* __restrict__ sim, int T, int L) {
+    const int i = blockIdx.y, j = blockIdx.x;
+    const float* qv = pooled + (int64_t)j * L;
+    const float* kv = pooled + ((int64_t)T + i) * L;
+    float dot = 0.0f, nq = 0.0f, nk = 0.0f;
+    for (int e = threadIdx.x; e < L; e += 64) {
+        const float a = qv[e], b = kv[e];
+        dot += a * b;
+        nq += a * a;
+        nk += b * b;
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        dot += __shfl_xor(dot, s);
+        nq += __shfl_xor(nq, s);
+        nk += __shfl_xor(nk, s);
+    }
+    if (threadIdx.x == 0) sim[i * T + j] = dot / (fmaxf(sqrtf(nq), 1e-8f) * fmaxf(sqrtf(nk), 1e-8f));
+}
+extern "C" int ppms_qk_similarity(const float* q, const float* k, int ld, float* pooled, float* sim, int T, int H, int W, void* stream) {
+    PPMS_REQUIRE(q && k && pooled && sim && T > 0 && H >= 4 && W >= 4 && ld >= 128, "qk_similarity: bad arguments (H,W >= 4)");
+    const int OH = H / 4, OW = W / 4;
+    hipLaunchKernelGGL(qk_pool_kernel, dim3(OH * OW, T, 2), dim3(128), 0, (hipStream_t)stream, q, k, ld, pooled, T, H, W, OH, OW);
+    hipLaunchKernelGGL(qk_cos_kernel, dim3(T, T), dim3(64), 0, (hipStream_t)stream, pooled, sim, T, OH * OW);
+    return ppms_check_launch("qk_similarity");
+}
+
+// ------------------------------------------------------------------------------------------------ QAM pick
+// one lane per clip row i: score[i][j] = exp(-S_ij / (sum_j S_ij + T)) * sim[i][j] + conf[j]; top-5 by score;
+// S[i][sel] += 1; picked frames ascending + normalised scores s_hat = score / mean(score over picked)
+__global__ __launch_bounds__(64) void qam_select_kernel(const float* __restrict__ sim, float* __restrict__ strive,
+                                                        const float* __restrict__ partial, int nblk, int HW, int32_t* __restrict__ sel,
+                                                        float* __restrict__ shat, float* __restrict__ score_out, int T) {
+    __shared__ float conf[64];
+    const int i = threadIdx.x;
+    if (i < T) {
+        float s = 0.0f;
+        for (int b = 0; b < nblk; ++b) s += partial[i * nblk + b];
+        conf[i] = s / (float)HW;
+    }
+    __syncthreads();
+    if (i >= T) return;
+    float ssum = 0.0f;
+    for (int j = 0; j < T; ++j) ssum += strive[i * T + j];
+    const int ksel = T < 5 ? T : 5;
+    unsigned long long picked = 0ull;
+    float sc[64];
+    for (int j = 0; j < T; ++j) {
+        const float pen = expf(-strive[i * T + j] / (ssum + (float)T));
+        sc[j] = pen * sim[i * T + j] + conf[j];
+        if (score_out) score_out[i * T + j] = sc[j];
+    }
+    for (int n = 0; n < ksel; ++n) {
+        int best = -1;
+        float bv = -INFINITY;
+        for (int j = 0; j < T; ++j) {
+            if ((picked >> j) & 1ull) continue;
+            const float v = sc[j];
+            if (best < 0 || v > bv || (v != v && bv == bv)) {   // NaN scores (T == 1) still pick a frame
+                best = j;
+                bv = v;
+            }
+        }
+        picked |= 1ull << best;
+    }
+    float mean = 0.0f;
+    for (int j = 0; j < T; ++j)
+        if ((picked >> j) & 1ull) mean += sc[j];
+    mean /= (float)ksel;
+    int n = 0;
+    for (int j = 0; j < T; ++j)
+        if ((picked >> j) & 1ull) {
+            strive[i * T + j] += 1.0f;
+            sel[i * 5 + n] = j;
+            shat[i * 5 + n] = sc[j] / mean;
+            ++n;
+        }
+    for (; n < 5; ++n) {
+        sel[i * 5 + n] = 0;
+        shat[i * 5 + n] = 0.0f;
+    }
+}
+extern "C" int ppms_qam_select(const float* sim, float* strive, const float* conf_partial, int nblk, int HW, int32_t* sel, float* shat,
+                               float* score, int T, void* stream) {
+    PPMS_REQUIRE(sim && strive && conf_partial && sel && shat && T > 0 && T <= 64, "qam_select: bad arguments (1 <= T <= 64)");
+    hipLaunchKernelGGL(qam_select_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sim, strive, conf_partial, nblk, HW, sel, shat, score, T);
+    return ppms_check_launch("qam_select");
+}
+
+// ------------------------------------------------------------------------------------------------ attention operands
+__global__ __launch_bounds__(256) void attn_prep_q_kernel(const float* __restrict__ q, int ld, const float* __restrict__ pe,
+                                                          bf16_t* __restrict__ qb, int n, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // (frame, pixel, 8-channel group)
+    if (idx >= total) return;
+    const int g = (int)(idx & 15);
+    const int64_t pix = idx >> 4;
+    const int frame = (int)(pix / n);
+    const f32x4 a = *(const f32x4*)(q + pix * ld + g * 8), b = *(const f32x4*)(q + pix * ld + g * 8 + 4);
+    const f32x4 pa = *(const f32x4*)(pe + frame * 128 + g * 8), pb = *(const f32x4*)(pe + frame * 128 + g * 8 + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[j] = (bf16_t)(a[j] + pa[j]);
+        o[4 + j] = (bf16_t)(b[j] + pb[j]);
+    }
+    *(bf16x8*)(qb + pix * 128 + g * 8) = o;
+}
+extern "C" int ppms_attn_prep_q(const float* q, int ld, const float* pe, void* qb, int T, int n, void* stream) {
+    PPMS_REQUIRE(q && pe && qb && ld % 4 == 0, "attn_prep_q: bad arguments");
+    const int64_t total = (int64_t)T * n * 16;
+    hipLaunchKernelGGL(attn_prep_q_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, q, ld, pe, (bf16_t*)qb, n, total);
+    return ppms_check_launch("attn_prep_q");
+}
+
+__global__ __launch_bounds__(256) void attn_prep_k_kernel(const float* __restrict__ key, int ld, const float* __restrict__ pe,
+                                                          const int32_t* __restrict__ sel, const float* __restrict__ shat,
+                                                          bf16_t* __restrict__ kb, int ksel, int n, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;     // (clip, slot, pixel, 8-channel group)
+    if (idx >= total) return;
+    const int g = (int)(idx & 15);
+    const int64_t r = idx >> 4;
+    const int pin = (int)(r % n);
+    const int cs = (int)(r / n);                // clip*ksel + slot
+    const int clip = cs / ksel, slot = cs - clip * ksel;
+    const int frame = sel[clip * 5 + slot];
+    const float s = shat[clip * 5 + slot];
+    const float* kp = key + ((int64_t)frame * n + pin) * ld + g * 8;
+    const f32x4 a = *(const f32x4*)kp, b = *(const f32x4*)(kp + 4);
+    const f32x4 pa = *(const f32x4*)(pe + frame * 128 + g * 8), pb = *(const f32x4*)(pe + frame * 128 + g * 8 + 4);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        o[j] = (bf16_t)(a[j] * s + pa[j]);
+        o[4 + j] = (bf16_t)(b[j] * s + pb[j]);
+    }
+    *(bf16x8*)(kb + r * 128 + g * 8) = o;
+}
+extern "C" int ppms_attn_prep_k(const float* key, int ld, const float* pe, const int32_t* sel, const float* shat, void* kb, int T, int ksel,
+                                int n, void* stream) {
+    PPMS_REQUIRE(key && pe && sel && shat && kb && ksel >= 1 && ksel <= 5 && ld % 4 == 0, "attn_prep_k: bad arguments");
+    const int64_t total = (int64_t)T * ksel * n * 16;
+    hipLaunchKernelGGL(attn_prep_k_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, key, ld, pe, sel, shat,
+                       (bf16_t*)kb, ksel, n, total);
+    return ppms_check_launch("attn_prep_k");
+}

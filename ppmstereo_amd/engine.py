@@ -1,0 +1,423 @@
+"""Device-resident engine for one scale of the hot loop (PPMStereo.forward_update_block,
+/root/reference/models/core/ppmstereo.py:426-594).
+
+Everything between two iterations stays in HBM in the kernels' own operand format (channel-last split-bf16 "SP"
+planes, see include/ppms.h); the reference's NCHW tensors are converted once on the way in and once on the way
+out.  All buffers are allocated once per (block, T, h, w) by the caller-side PyTorch allocator, every conv
+descriptor is built once and uploaded once: an iteration is a fixed sequence of kernel launches on the current
+stream with no host synchronisation, no allocation and no host<->device copy.
+
+Stage methods mirror the reference calls one to one:
+    lookup()                  corr_fn(flow)                               ppmstereo.py:489
+    motion_and_value()        update_block.get_motion_and_value           :492   (ppmtereo_update.py:945-950)
+    uncertainty()             update_block.get_uncertainty                :495   (ppmtereo_update.py:936-938)
+    pick()                    QAM score / top-k / usage counter           :505-513
+    attend()                  play + flash_attn_func + aggregation        :517-552
+    update()                  update_block(net, inp, mf, mfg, t)          :569   (ppmtereo_update.py:971-1003)
+    upsample()                convex_upsample + prediction resize         :576-591
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib as L
+from .packing import pack_conv
+
+TOP_K = 5
+
+
+def temporal_pe(T: int, channels: int) -> torch.Tensor:
+    """get_temporal_positional_encoding(is_normalize=True, scale=1), ppmtereo_update.py:25-49 -> (T, channels).
+    Same torch op sequence as the reference (host side, once per scale); T == 1 yields NaN like the reference."""
+    pos = torch.arange(T)
+    pos = pos / pos[-1] * 1.0
+    pos = pos.unsqueeze(1)
+    div = 1.0 / (10000.0 ** (torch.arange(0, channels, 2).float() / channels))
+    ang = pos * div
+    pe = torch.zeros(T, channels)
+    pe[:, 0::2] = torch.sin(ang)
+    pe[:, 1::2] = torch.cos(ang)
+    return pe
+
+
+def softmax_scale(c: int = 128) -> float:
+    """ppmstereo.py:494: c^-0.5 * log_12000(key channels = 2c)."""
+    return c ** -0.5 * math.log(2 * c, 12000)
+
+
+class ConvOp:
+    """One implicit-GEMM launch: host descriptor (validated by the library) + its device copy."""
+
+    def __init__(self, desc: L.Conv, keep: list):
+        self.desc = desc
+        raw = bytes(desc)
+        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone().cuda()
+        self.keep = keep            # tensors whose storage the descriptor points at
+
+    def __call__(self):
+        L.check(L.load().ppms_conv_gemm(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
+
+
+def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Optional[L.SP] = None, out_f32=None, out_f32_ld=0,
+             out_vt=None, aux_sp: Optional[L.SP] = None, aux_f32=None, aux_f32_ld=0) -> L.Epilogue:
+    e = L.Epilogue()
+    e.kind, e.act, e.scale, e.n_valid = kind, act, scale, n_valid
+    if out_sp is not None:
+        e.out_sp = out_sp
+    e.out_f32 = None if out_f32 is None else out_f32.data_ptr()
+    e.out_f32_ld = out_f32_ld
+    e.out_vt = None if out_vt is None else out_vt.data_ptr()
+    if aux_sp is not None:
+        e.aux_sp = aux_sp
+    e.aux_f32 = None if aux_f32 is None else aux_f32.data_ptr()
+    e.aux_f32_ld = aux_f32_ld
+    return e
+
+
+class PackedBlock:
+    """Packed weights of one SequenceUpdateBlock3D + its Attention_qk (device tensors, built once)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)
+        self.w: Dict[str, tuple] = {}
+
+        def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
+            self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
+
+        e = "encoder."
+        put("init0", g(e + "init_conv.0.weight"), g(e + "init_conv.0.bias"), [128])
+        put("init2", g(e + "init_conv.2.weight"), g(e + "init_conv.2.bias"), [64])
+        c1 = e + "convc1."
+        put("ffn1_0", g(c1 + "ffn1.0.weight"), g(c1 + "ffn1.0.bias"), [36], [64])
+        put("ffn1_2", g(c1 + "ffn1.2.weight"), g(c1 + "ffn1.2.bias"), [54], [64])
+        put("pw", g(c1 + "pw.weight"), g(c1 + "pw.bias"), [36], [64])
+        put("ffn2_0", g(c1 + "ffn2.0.weight"), g(c1 + "ffn2.0.bias"), [36], [64])
+        put("ffn2_2", g(c1 + "ffn2.2.weight"), g(c1 + "ffn2.2.bias"), [54], [64])
+        self.dw = []
+        for i, k in ((0, 1), (1, 7)):
+            w = torch.zeros(64, k * k, device=device)
+            b = torch.zeros(64, device=device)
+            w[:36] = g(c1 + f"conv_list.{i}.weight").reshape(36, k * k)
+            b[:36] = g(c1 + f"conv_list.{i}.bias")
+            self.dw.append((w.contiguous(), b.contiguous(), k))
+        put("convc2", g(e + "convc2.weight"), g(e + "convc2.bias"), [256])
+        # convf1 (7x7 on the 2-channel flow) runs as a 1x1 GEMM over the im2col patch [tap*2 + c], 98 -> 128
+        wf1 = g(e + "convf1.weight").permute(0, 2, 3, 1).reshape(128, 98, 1, 1)
+        put("convf1", wf1, g(e + "convf1.bias"), [98], [128])
+        put("convf2", g(e + "convf2.weight"), g(e + "convf2.bias"), [128])
+        # final_conv: couts 0..125 -> motion features (rows 0..125), couts 126..189 -> motion hidden state (rows 128..191)
+        put("final", g(e + "final_conv.weight"), g(e + "final_conv.bias"), [320], None, list(range(126)) + list(range(128, 192)), 192)
+        put("to_v", g("aggregator.to_v.weight"), None, [128])
+        put("unc0", g("uncertainty.0.weight"), g("uncertainty.0.bias"), [128, 128])
+        self.unc2_w = g("uncertainty.2.weight").reshape(128).contiguous()
+        self.unc2_b = float(sd["uncertainty.2.bias"].detach().float().cpu().item())
+        gr = "gru."
+        cat = lambda a, b: torch.cat([g(a), g(b)], 0)
+        put("zr1_0", cat(gr + "convz1.0.weight", gr + "convr1.0.weight"), cat(gr + "convz1.0.bias", gr + "convr1.0.bias"), [128, 384])
+        put("z1_2", g(gr + "convz1.2.weight"), g(gr + "convz1.2.bias"), [128])
+        put("r1_2", g(gr + "convr1.2.weight"), g(gr + "convr1.2.bias"), [128])
+        put("q1", g(gr + "convq1.weight"), g(gr + "convq1.bias"), [128, 384])
+        for n in ("2", "3"):
+            put("zr" + n, cat(gr + f"convz{n}.weight", gr + f"convr{n}.weight"), cat(gr + f"convz{n}.bias", gr + f"convr{n}.bias"), [128, 384])
+            put("q" + n, g(gr + f"convq{n}.weight"), g(gr + f"convq{n}.bias"), [128, 384])
+        put("fh1", g("flow_head.conv1.weight"), g("flow_head.conv1.bias"), [128])
+        put("fh2", g("flow_head.conv2.weight"), g("flow_head.conv2.bias"), [256])
+        put("m1", g("mask_2d.0.weight"), g("mask_2d.0.bias"), [128])
+        put("m2", g("mask_2d.2.weight"), g("mask_2d.2.bias"), [256])
+        self.beta = g("aggregator.beta").contiguous()
+        self.attn = None
+        if "time_attn.temporal_fc.weight" in sd:
+            self.attn = {k: g(k) for k in sd if k.startswith("time_attn.") or k.startswith("space_attn.")}
+
+
+class ScaleEngine:
+    """All state of one forward_update_block call: buffers, descriptors, iteration stages."""
+
+    def __init__(self, pk: PackedBlock, T: int, h: int, w: int, device):
+        if T > 64:
+            raise NotImplementedError("more than 64 frames per window")
+        self.pk, self.T, self.h, self.w = pk, T, h, w
+        self.n = h * w
+        self.P = P = T * h * w
+        self.dev = device
+        self.ksel = min(TOP_K, T)
+        sp = lambda c: L.SPTensor(P, c, device)
+        f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
+        self.CORR, self.T1, self.C1, self.C2 = sp(64), sp(64), sp(64), sp(64)
+        self.COR256, self.CF, self.PATCH, self.FLO1 = sp(256), [sp(320), sp(320)], sp(128), sp(128)
+        self.X, self.VAL, self.U1 = sp(384), sp(128), sp(128)
+        self.Hb = [sp(128), sp(128), sp(128)]
+        self.ZT, self.RT, self.RH, self.FH1, self.M1 = sp(128), sp(128), sp(128), sp(256), sp(256)
+        self.Z, self.MASK, self.FLOW, self.QK = f32(P, 128), f32(P, 144), f32(P, 2), f32(P, 256)
+        self.DFLOW = f32(P, 4)
+        self.VT = torch.zeros(T, 128, self.n, dtype=torch.bfloat16, device=device)
+        self.QB = torch.zeros(T, self.n, 128, dtype=torch.bfloat16, device=device)
+        self.KB = torch.zeros(T, self.ksel, self.n, 128, dtype=torch.bfloat16, device=device)
+        self.nblk = (self.n + 255) // 256
+        self.UNC, self.PART = f32(P), f32(T, self.nblk)
+        self.SIM, self.STRIVE, self.SCORE = f32(T, T), f32(T, T), f32(T, T)
+        self.SEL = torch.zeros(T, 5, dtype=torch.int32, device=device)
+        self.SHAT = f32(T, 5)
+        self.POOL = f32(2, T, max(1, (h // 4) * (w // 4)))
+        self.PE = temporal_pe(T, 128).to(device)
+        self.FLOW_OUT = f32(T, 2, 4 * h, 4 * w)
+        self.scale = softmax_scale(128)
+        self.parity = 0             # which CF buffer holds the current motion hidden state
+        self.have_mhs = False
+        self.lib = L.load()
+        self._ev, self._ev_i = None, 0
+        self._build_descriptors()
+
+    # ------------------------------------------------------------------ descriptors
+    def _conv(self, wname, segs: List[L.SP], k3, epi0: L.Epilogue, epi1: Optional[L.Epilogue] = None, m_split: Optional[int] = None,
+              keep=()) -> ConvOp:
+        packed, bias, meta = self.pk.w[wname] if isinstance(wname, str) else wname
+        d = L.Conv()
+        for i, s in enumerate(segs):
+            d.seg[i] = s
+        d.nseg = len(segs)
+        assert [s.c for s in segs] == meta["seg_padded"], (wname, [s.c for s in segs], meta["seg_padded"])
+        assert tuple(k3) == meta["taps"] or wname == "convf1", (wname, k3, meta["taps"])
+        d.w, d.bias = packed.data_ptr(), bias.data_ptr()
+        d.T, d.H, d.W = self.T, self.h, self.w
+        d.kt, d.kh, d.kw = k3
+        d.M = meta["M"]
+        d.m_split = meta["M"] if m_split is None else m_split
+        d.epi[0] = epi0
+        if epi1 is not None:
+            d.epi[1] = epi1
+        return ConvOp(d, [packed, bias, *keep])
+
+    def _build_descriptors(self):
+        E, X, H = epilogue, self.X, self.Hb
+        k1, k3 = (1, 1, 1), (1, 3, 3)
+        inp, mf, mfg = X.view(0, 128), X.view(128, 128), X.view(256, 128)
+        self.op: Dict[str, object] = {}
+        o = self.op
+        self._qk_ops: Dict[int, ConvOp] = {}
+        o["init0"] = self._conv("init0", [inp], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=self.ZT.view(0, 64)))
+        o["ffn1_0"] = self._conv("ffn1_0", [self.CORR.view()], k1, E(act=L.ACT_GELU, n_valid=54, out_sp=self.T1.view()))
+        o["ffn1_2"] = self._conv("ffn1_2", [self.T1.view()], k1, E(L.EPI_RESID, L.ACT_GELU, n_valid=36, out_sp=self.C1.view(), aux_sp=self.CORR.view()))
+        o["pw"] = self._conv("pw", [self.C1.view()], k1, E(L.EPI_RESID, L.ACT_GELU, n_valid=36, out_sp=self.C2.view(), aux_sp=self.C1.view()))
+        o["ffn2_0"] = self._conv("ffn2_0", [self.C2.view()], k1, E(act=L.ACT_GELU, n_valid=54, out_sp=self.T1.view()))
+        o["ffn2_2"] = self._conv("ffn2_2", [self.T1.view()], k1, E(act=L.ACT_GELU, n_valid=256, out_sp=self.COR256.view()))
+        o["convf1"] = self._conv("convf1", [self.PATCH.view()], k1, E(act=L.ACT_RELU, n_valid=128, out_sp=self.FLO1.view()))
+        for par in (0, 1):
+            cf, cf_next = self.CF[par], self.CF[1 - par]
+            o[f"init2_{par}"] = self._conv("init2", [self.ZT.view(0, 64)], k3, E(n_valid=64, out_sp=cf.view(256, 64)))
+            o[f"convc2_{par}"] = self._conv("convc2", [self.COR256.view()], k3, E(act=L.ACT_RELU, n_valid=192, out_sp=cf.view(0, 192)))
+            o[f"convf2_{par}"] = self._conv("convf2", [self.FLO1.view()], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=cf.view(192, 64)))
+            o[f"final_{par}"] = self._conv("final", [cf.view()], k3, E(act=L.ACT_RELU, n_valid=126, out_sp=mf),
+                                           E(act=L.ACT_RELU, n_valid=64, out_sp=cf_next.view(256, 64)), m_split=128)
+        o["to_v"] = self._conv("to_v", [mf], k1, E(n_valid=128, out_sp=self.VAL.view(), out_vt=self.VT))
+        o["unc0"] = self._conv("unc0", [H[0].view(), self.VAL.view()], k3, E(act=L.ACT_RELU, n_valid=128, out_sp=self.U1.view()))
+        x_all = X.view()
+        # GRU pass along W (two-layer z / r), then H, then T: h cycles through Hb[0] -> Hb[1] -> Hb[2] -> Hb[0]
+        o["zr1_0"] = self._conv("zr1_0", [H[0].view(), x_all], (1, 1, 15), E(act=L.ACT_GELU, n_valid=128, out_sp=self.ZT.view()),
+                                E(act=L.ACT_GELU, n_valid=128, out_sp=self.RT.view()), m_split=128)
+        o["z1_2"] = self._conv("z1_2", [self.ZT.view()], (1, 1, 5), E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128))
+        o["r1_2"] = self._conv("r1_2", [self.RT.view()], (1, 1, 5), E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[0].view()))
+        o["q1"] = self._conv("q1", [self.RH.view(), x_all], (1, 1, 5),
+                             E(L.EPI_GRU, n_valid=128, out_sp=H[1].view(), aux_sp=H[0].view(), aux_f32=self.Z, aux_f32_ld=128))
+        for n, kk, src, dst in (("2", (1, 5, 1), 1, 2), ("3", (5, 1, 1), 2, 0)):
+            o["zr" + n] = self._conv("zr" + n, [H[src].view(), x_all], kk, E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128),
+                                     E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[src].view()), m_split=128)
+            o["q" + n] = self._conv("q" + n, [self.RH.view(), x_all], kk,
+                                    E(L.EPI_GRU, n_valid=128, out_sp=H[dst].view(), aux_sp=H[src].view(), aux_f32=self.Z, aux_f32_ld=128))
+        o["fh1"] = self._conv("fh1", [H[0].view()], (3, 3, 3), E(act=L.ACT_RELU, n_valid=256, out_sp=self.FH1.view()))
+        o["fh2"] = self._conv("fh2", [self.FH1.view()], (3, 3, 3), E(n_valid=2, out_f32=self.DFLOW, out_f32_ld=4))
+        o["m1"] = self._conv("m1", [H[0].view()], k3, E(act=L.ACT_RELU, n_valid=256, out_sp=self.M1.view()))
+        o["m2"] = self._conv("m2", [self.M1.view()], k1, E(scale=0.25, n_valid=144, out_f32=self.MASK, out_f32_ld=144))
+
+    # ------------------------------------------------------------------ loading state (reference NCHW tensors)
+    def _s(self):
+        return L.stream_ptr()
+
+    def load_nchw(self, x: torch.Tensor, dst: L.SP):
+        x = x.contiguous().float()
+        L.require_gpu(x)
+        L.check(self.lib.ppms_nchw_to_sp(x.data_ptr(), dst, x.shape[0], x.shape[1], x.shape[2] * x.shape[3], self._s()))
+
+    def store_nchw(self, src: L.SP, c: int) -> torch.Tensor:
+        out = torch.empty(self.T, c, self.h, self.w, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.ppms_sp_to_nchw(src, out.data_ptr(), self.T, c, self.n, self._s()))
+        return out
+
+    def set_inp(self, inp: torch.Tensor):
+        self.load_nchw(inp, self.X.view(0, 128))
+
+    def set_net(self, net: torch.Tensor):
+        self.load_nchw(net, self.Hb[0].view())
+
+    def set_mf(self, mf: torch.Tensor):
+        self.load_nchw(mf, self.X.view(128, 128))
+
+    def set_mfg(self, mfg: torch.Tensor):
+        self.load_nchw(mfg, self.X.view(256, 128))
+
+    def set_flow(self, flow: torch.Tensor):
+        f = flow.contiguous().float()
+        L.require_gpu(f)
+        L.check(self.lib.ppms_nchw_to_nhwc(f.data_ptr(), self.FLOW.data_ptr(), 2, self.T, 2, self.n, self._s()))
+
+    def set_mhs(self, mhs: Optional[torch.Tensor]):
+        self.parity = 0
+        self.have_mhs = mhs is not None
+        if mhs is not None:
+            self.load_nchw(mhs, self.CF[self.parity].view(256, 64))
+
+    def get_net(self):
+        return self.store_nchw(self.Hb[0].view(), 128)
+
+    def get_mhs(self):
+        return self.store_nchw(self.CF[self.parity].view(256, 64), 64)
+
+    def get_mf(self):
+        return self.store_nchw(self.X.view(128, 128), 128)
+
+    def get_mfg(self):
+        return self.store_nchw(self.X.view(256, 128), 128)
+
+    def get_value(self):
+        return self.store_nchw(self.VAL.view(), 128)
+
+    def get_flow(self):
+        out = torch.empty(self.T, 2, self.h, self.w, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.ppms_nhwc_to_nchw(self.FLOW.data_ptr(), 2, out.data_ptr(), self.T, 2, self.n, self._s()))
+        return out
+
+    def get_dflow(self):
+        out = torch.empty(self.T, 2, self.h, self.w, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.ppms_nhwc_to_nchw(self.DFLOW.data_ptr(), 4, out.data_ptr(), self.T, 2, self.n, self._s()))
+        return out
+
+    def get_mask(self):
+        out = torch.empty(self.T, 144, self.h, self.w, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.ppms_nhwc_to_nchw(self.MASK.data_ptr(), 144, out.data_ptr(), self.T, 144, self.n, self._s()))
+        return out
+
+    def get_unc(self):
+        return self.UNC.view(self.T, 1, self.h, self.w).clone()
+
+    # ------------------------------------------------------------------ once per scale
+    def begin(self, pyramid: List[torch.Tensor], qk_pack):
+        """q/k projection, Q operand, frame similarity, usage counter (ppmstereo.py:447-475).
+        pyramid: levels of CorrBlock1D; qk_pack: Attention_qk.packed(device)."""
+        self.pyr = pyramid
+        self.pyr_ptrs = (C.c_void_p * 4)(*[p.data_ptr() for p in pyramid[:4]])
+        key = qk_pack[0].data_ptr()
+        if key not in self._qk_ops:
+            self._qk_ops[key] = self._conv(qk_pack, [self.X.view(0, 128)], (1, 1, 1), epilogue(n_valid=256, out_f32=self.QK, out_f32_ld=256))
+        self._qk_ops[key]()
+        s = self._s()
+        L.check(self.lib.ppms_attn_prep_q(self.QK.data_ptr(), 256, self.PE.data_ptr(), self.QB.data_ptr(), self.T, self.n, s))
+        L.check(self.lib.ppms_qk_similarity(self.QK.data_ptr(), self.QK.data_ptr() + 128 * 4, 256, self.POOL.data_ptr(), self.SIM.data_ptr(),
+                                            self.T, self.h, self.w, s))
+        self.STRIVE.fill_(1.0)
+
+    # ------------------------------------------------------------------ iteration stages
+    def lookup(self):
+        X = self.X
+        fl = X.view(254, 2)
+        L.check(self.lib.ppms_corr_lookup(self.pyr_ptrs, self.FLOW.data_ptr(), 1, None, self.CORR.view().hi, self.CORR.view().lo, 64,
+                                          fl.hi, fl.lo, 384, self.T, self.h, self.w, self._s()))
+
+    def motion_and_value(self):
+        o, s, par = self.op, self._s(), self.parity
+        if not self.have_mhs:                     # init_conv(inp), ppmtereo_update.py:469-471
+            o["init0"]()
+            o[f"init2_{par}"]()
+            self.have_mhs = True
+        o["ffn1_0"]()
+        o["ffn1_2"]()
+        (w1, b1, _), (w7, b7, _) = self.pk.dw
+        L.check(self.lib.ppms_dwconv_gelu(self.C1.view(), self.C2.view(), w1.data_ptr(), b1.data_ptr(), 1, self.T, self.h, self.w, s))
+        L.check(self.lib.ppms_dwconv_gelu(self.C2.view(), self.C1.view(), w7.data_ptr(), b7.data_ptr(), 7, self.T, self.h, self.w, s))
+        o["pw"]()
+        o["ffn2_0"]()
+        o["ffn2_2"]()
+        o[f"convc2_{par}"]()
+        L.check(self.lib.ppms_flow_patch7(self.FLOW.data_ptr(), self.PATCH.view(), self.T, self.h, self.w, s))
+        o["convf1"]()
+        o[f"convf2_{par}"]()
+        o[f"final_{par}"]()
+        self.parity = 1 - par                     # the new motion hidden state went to the other CF buffer
+        o["to_v"]()
+
+    def uncertainty(self):
+        self.op["unc0"]()
+        L.check(self.lib.ppms_unc_tail(self.U1.view(), self.pk.unc2_w.data_ptr(), self.pk.unc2_b, self.UNC.data_ptr(), self.PART.data_ptr(),
+                                       self.T, self.n, self._s()))
+
+    def pick(self):
+        L.check(self.lib.ppms_qam_select(self.SIM.data_ptr(), self.STRIVE.data_ptr(), self.PART.data_ptr(), self.nblk, self.n, self.SEL.data_ptr(),
+                                         self.SHAT.data_ptr(), self.SCORE.data_ptr(), self.T, self._s()))
+
+    def attend(self, out_bf16: Optional[torch.Tensor] = None):
+        s = self._s()
+        L.check(self.lib.ppms_attn_prep_k(self.QK.data_ptr() + 128 * 4, 256, self.PE.data_ptr(), self.SEL.data_ptr(), self.SHAT.data_ptr(),
+                                          self.KB.data_ptr(), self.T, self.ksel, self.n, s))
+        ev = None
+        if self._ev is not None and self._ev_i < len(self._ev):
+            ev = self._ev[self._ev_i]
+            self._ev_i += 1
+            ev[0].record()
+        L.check(self.lib.ppms_mem_attn(self.QB.data_ptr(), self.KB.data_ptr(), self.VT.data_ptr(), self.SEL.data_ptr(), self.ksel, self.scale,
+                                       self.pk.beta.data_ptr(), self.X.view(128, 128), self.X.view(256, 128), L.ptr(out_bf16), self.T, self.n, s))
+        if ev is not None:
+            ev[1].record()
+
+    def enable_attn_timing(self, launches: int):
+        """HIP events (on the stream the kernel is launched on) around the next `launches` mem_attn launches."""
+        self._ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        self._ev_i = 0
+
+    def attn_times_ms(self):
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self._ev[:self._ev_i]]
+
+    def block16_attention(self):
+        """TimeAttnBlock + SpaceAttnBlock on x = [inp, mf, mfg] (update_block16 only, ppmtereo_update.py:593-631,
+        980-983): 3.6 MFLOP/px on 1/16-scale pixels only -- fp32 torch-ROCm ops on the device-resident tensor."""
+        from .attn16 import time_space_attention
+        x = self.X.to_f32()                                                     # (P, 384)
+        x = time_space_attention(self.pk.attn, x, self.T, self.h, self.w)
+        self.X.set_f32(x)
+
+    def update(self):
+        o = self.op
+        if self.pk.attn is not None:
+            self.block16_attention()
+        for k in ("zr1_0", "z1_2", "r1_2", "q1", "zr2", "q2", "zr3", "q3", "fh1", "fh2"):
+            o[k]()
+        L.check(self.lib.ppms_flow_add(self.FLOW.data_ptr(), self.DFLOW.data_ptr(), 4, self.P, self._s()))   # ppmstereo.py:571
+        o["m1"]()
+        o["m2"]()
+
+    def upsample(self) -> torch.Tensor:
+        L.check(self.lib.ppms_convex_upsample(self.FLOW.data_ptr(), self.MASK.data_ptr(), 144, self.FLOW_OUT.data_ptr(), self.T, self.h, self.w,
+                                              self._s()))
+        return self.FLOW_OUT
+
+    def iterate(self):
+        self.lookup()
+        self.motion_and_value()
+        self.uncertainty()
+        self.pick()
+        self.attend()
+        self.update()
+        return self.upsample()
+
+
+def bilinear(x: torch.Tensor, size, align_corners: bool, mul: float = 1.0) -> torch.Tensor:
+    """F.interpolate(mode="bilinear") replacement on NCHW fp32 (utils.py:10-16, ppmstereo.py:578,726)."""
+    x = x.contiguous().float()
+    L.require_gpu(x)
+    N, Cc, H, W = x.shape
+    out = torch.empty(N, Cc, size[0], size[1], dtype=torch.float32, device=x.device)
+    L.check(L.load().ppms_bilinear(x.data_ptr(), out.data_ptr(), N, Cc, H, W, size[0], size[1], int(align_corners), mul, L.stream_ptr()))
+    return out

@@ -1,0 +1,334 @@
+"""GPU parity tests, op level: every HIP kernel (called through the C ABI) against the CPU oracle / a plain
+PyTorch fp32 reference of the same op, on seeded inputs.  Run with -m gpu on an MI355X."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from golden_util import Golden
+from oracle import ppm_oracle as O
+from ppmstereo_amd import weights as Wm
+from ppmstereo_amd.synth import synth_scale_inputs
+from ppmstereo_amd.weights import hash_normal
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "these tests need the MI355X (no CPU fallback exists)"
+    from ppmstereo_amd import _lib as L
+    return L
+
+
+def maxdiff(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all(), "non-finite GPU output"
+    return (a - b).abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------------ correlation
+@pytest.mark.parametrize("B,H,W,seed,gold", [(2, 4, 32, 11, "corr_small"), (1, 3, 24, 12, "corr_odd"), (5, 20, 32, 14, None),
+                                              (2, 5, 80, 15, None), (1, 2, 320, 16, None)])
+def test_corr_build_and_lookup(lib, B, H, W, seed, gold):
+    from ppmstereo_amd.corr import CorrBlock1D
+    d = synth_scale_inputs(B, H, W, seed=seed)
+    cb = CorrBlock1D(d["fmap1"].to(DEV), d["fmap2"].to(DEV))
+    pyr = O.corr_pyramid(d["fmap1"], d["fmap2"])
+    assert len(cb.corr_pyramid) == 5
+    for i in range(5):
+        assert cb.corr_pyramid[i].shape == pyr[i].shape
+        assert maxdiff(cb.corr_pyramid[i], pyr[i]) < 3e-5, f"level {i}"
+    assert maxdiff(cb.coords, O.coords_grid(B, H, W)) == 0
+    out = cb(d["flow"].to(DEV))
+    assert out.shape == (B, 36, H, W) and out.is_contiguous()
+    assert maxdiff(out, O.corr_lookup(pyr, d["flow"])) < 5e-5
+    big = cb((d["flow"] * 20).to(DEV))                      # many taps out of range -> zeros
+    assert maxdiff(big, O.corr_lookup(pyr, d["flow"] * 20)) < 5e-5
+    if gold:
+        g = Golden(gold)
+        g.check("lookup", out, 5e-5)
+        for i in range(5):
+            g.check(f"pyr{i}", cb.corr_pyramid[i], 3e-5)
+    assert maxdiff(CorrBlock1D.corr(d["fmap1"].to(DEV), d["fmap2"].to(DEV)), O.corr_volume(d["fmap1"], d["fmap2"])[:, :, :, None]) < 3e-5
+
+
+def test_corr_rejects_narrow_maps(lib):
+    from ppmstereo_amd.corr import CorrBlock1D
+    with pytest.raises(RuntimeError):
+        CorrBlock1D(torch.zeros(1, 256, 4, 8, device=DEV), torch.zeros(1, 256, 4, 8, device=DEV))
+
+
+def test_ops_refuse_cpu_tensors(lib):
+    from ppmstereo_amd.corr import CorrBlock1D
+    with pytest.raises(RuntimeError):
+        CorrBlock1D(torch.zeros(1, 256, 4, 32), torch.zeros(1, 256, 4, 32))
+
+
+# ------------------------------------------------------------------------------------------------ conv GEMM
+def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None):
+    """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
+    from ppmstereo_amd.engine import ConvOp, epilogue
+    from ppmstereo_amd.packing import pack_conv
+    P = T * H * W
+    segs, keep = [], []
+    seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
+    for x, cp in zip(x_list, seg_pad):
+        t = L.SPTensor(P, cp, DEV)
+        t.set_f32(x.to(DEV))
+        segs.append(t.view())
+        keep.append(t)
+    packed, b, meta = pack_conv(weight.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad)
+    cout = weight.shape[0]
+    out = L.SPTensor(P, meta["M"], DEV)
+    outf = torch.zeros(P, meta["M"], device=DEV)
+    e = epilogue(kind=kind, act=act, scale=scale, n_valid=cout, out_sp=out.view(), out_f32=outf, out_f32_ld=meta["M"])
+    if aux is not None:
+        a = L.SPTensor(P, meta["M"], DEV)
+        a.set_f32(aux.to(DEV))
+        e.aux_sp = a.view()
+        keep.append(a)
+    if z is not None:
+        zt = torch.zeros(P, meta["M"], device=DEV)
+        zt[:, :cout] = z.to(DEV)
+        e.aux_f32, e.aux_f32_ld = zt.data_ptr(), meta["M"]
+        keep.append(zt)
+    d = L.Conv()
+    for i, s in enumerate(segs):
+        d.seg[i] = s
+    d.nseg, d.w, d.bias = len(segs), packed.data_ptr(), b.data_ptr()
+    d.T, d.H, d.W = T, H, W
+    d.kt, d.kh, d.kw = k3
+    d.M = d.m_split = meta["M"]
+    d.epi[0] = e
+    ConvOp(d, keep)()
+    torch.cuda.synchronize()
+    sp = out.to_f32()[:, :cout].cpu()
+    assert (sp - outf[:, :cout].cpu()).abs().max() < 2e-5 * (1 + sp.abs().max()), "SP and fp32 outputs of one launch disagree"
+    assert (out.to_f32()[:, cout:] == 0).all(), "padded couts must not be written"
+    return sp
+
+
+def _ref_conv(x_list, weight, bias, k3, T, H, W):
+    x = torch.cat(x_list, 1)                                                # (P, Cin)
+    x5 = x.reshape(1, T, H, W, -1).permute(0, 4, 1, 2, 3)
+    w5 = weight if weight.dim() == 5 else weight[:, :, None]
+    y = F.conv3d(x5, w5, bias, padding=tuple(k // 2 for k in k3))
+    return y.permute(0, 2, 3, 4, 1).reshape(T * H * W, -1)
+
+
+CONV_CASES = [
+    # name, T,H,W, segs, cout, k3
+    ("1x1_small", 2, 5, 7, [36], 54, (1, 1, 1)),
+    ("3x3_two_segs", 3, 9, 13, [128, 128], 128, (1, 3, 3)),
+    ("1x15_gru", 2, 4, 40, [128, 384], 256, (1, 1, 15)),
+    ("5x1x1_time", 5, 6, 10, [128, 64], 128, (5, 1, 1)),
+    ("1x5x1", 2, 11, 9, [64], 64, (1, 5, 1)),
+    ("3x3x3", 4, 7, 9, [128], 190, (3, 3, 3)),
+    ("one_tile_exact", 1, 8, 32, [32], 64, (1, 3, 3)),
+    ("T1_tiny", 1, 1, 3, [32], 2, (3, 3, 3)),
+]
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV_CASES)
+def test_conv_gemm_vs_torch(lib, name, T, H, W, segs, cout, k3):
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    fan = cin * k3[0] * k3[1] * k3[2]
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(fan)
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W)
+    tol = 3e-5 * max(1.0, ref.abs().max().item())           # bf16x3 split: ~2^-16 relative per product, fp32 accumulate
+    assert maxdiff(got, ref) < tol, name
+
+
+def test_conv_gemm_epilogues(lib):
+    T, H, W, cin, cout, k3 = 2, 6, 10, 64, 64, (1, 3, 3)
+    P = T * H * W
+    x = hash_normal((P, cin), 300)
+    wt = hash_normal((cout, cin, *k3), 301) / math.sqrt(cin * 9)
+    bs = hash_normal((cout,), 302) * 0.1
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    lin = _ref_conv([x], wt, bs, k3, T, H, W)
+    L = lib
+    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, act=L.ACT_RELU), F.relu(lin)) < 5e-5
+    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, act=L.ACT_GELU), F.gelu(lin)) < 5e-5
+    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, act=L.ACT_SIGMOID), torch.sigmoid(lin)) < 5e-5
+    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, act=L.ACT_TANH), torch.tanh(lin)) < 5e-5
+    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, scale=0.25), 0.25 * lin) < 5e-5
+    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + lin)) < 5e-5
+    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RH, aux=aux), torch.sigmoid(lin) * aux) < 5e-5
+    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < 5e-5
+
+
+def test_conv_gemm_rejects_bad_descriptors(lib):
+    L = lib
+    d = L.Conv()
+    with pytest.raises(RuntimeError):
+        L.check(L.load().ppms_conv_gemm(C.byref(d), None, None))
+
+
+# ------------------------------------------------------------------------------------------------ small ops
+def test_convex_upsample(lib):
+    from ppmstereo_amd.ppmstereo import convex_upsample
+    fl, mk = hash_normal((3, 2, 6, 10), 31), hash_normal((3, 144, 6, 10), 32)
+    out = convex_upsample(fl.to(DEV), mk.to(DEV))
+    assert maxdiff(out, O.convex_upsample(fl, mk)) < 5e-6
+    Golden("convex_upsample").check("out", out, 5e-6)
+
+
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("shape,size", [((2, 3, 5, 7), (10, 14)), ((1, 2, 8, 32), (32, 128)), ((2, 1, 6, 5), (9, 11)), ((1, 1, 4, 4), (4, 4))])
+def test_bilinear(lib, align, shape, size):
+    from ppmstereo_amd.engine import bilinear
+    x = hash_normal(shape, 400)
+    if align:
+        ref = F.interpolate(x, size=size, mode="bilinear", align_corners=True)
+    elif size[0] % shape[2] == 0 and size[0] // shape[2] == size[1] // shape[3]:
+        ref = F.interpolate(x, scale_factor=size[0] // shape[2], mode="bilinear")
+    else:
+        ref = F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+    assert maxdiff(bilinear(x.to(DEV), size, align, 1.0), ref) < 2e-6
+    assert maxdiff(bilinear(x.to(DEV), size, align, -0.5), -0.5 * ref) < 2e-6
+
+
+def test_layout_converters_roundtrip(lib):
+    L = lib
+    x = hash_normal((3, 36, 5, 7), 500)
+    t = L.SPTensor(3 * 35, 64, DEV)
+    xd = x.to(DEV)
+    L.check(L.load().ppms_nchw_to_sp(xd.data_ptr(), t.view(0, 36), 3, 36, 35, L.stream_ptr()))
+    back = torch.empty(3, 36, 5, 7, device=DEV)
+    L.check(L.load().ppms_sp_to_nchw(t.view(0, 36), back.data_ptr(), 3, 36, 35, L.stream_ptr()))
+    assert maxdiff(back, x) < 2e-5 and (t.to_f32()[:, 36:] == 0).all()
+    assert maxdiff(t.to_f32()[:, :36].reshape(3, 5, 7, 36).permute(0, 3, 1, 2), x) < 2e-5
+    hi = t.data[0, :, :36].float().cpu().reshape(3, 5, 7, 36).permute(0, 3, 1, 2)
+    assert torch.equal(hi, x.to(torch.bfloat16).float()), "hi plane must be the RNE bf16 cast (it doubles as the attention V operand)"
+    f = torch.empty(3 * 35, 40, device=DEV)
+    L.check(L.load().ppms_nchw_to_nhwc(xd.data_ptr(), f.data_ptr(), 40, 3, 36, 35, L.stream_ptr()))
+    b2 = torch.empty_like(back)
+    L.check(L.load().ppms_nhwc_to_nchw(f.data_ptr(), 40, b2.data_ptr(), 3, 36, 35, L.stream_ptr()))
+    assert maxdiff(b2, x) == 0
+
+
+@pytest.mark.parametrize("T,h,w", [(5, 8, 32), (8, 20, 32), (3, 46, 80), (2, 10, 18)])
+def test_qk_similarity(lib, T, h, w):
+    L = lib
+    q, k = hash_normal((T, 128, h, w), 600), hash_normal((T, 128, h, w), 601) + 0.3 * hash_normal((T, 128, h, w), 600)
+    qk = torch.cat([q, k], 1).permute(0, 2, 3, 1).reshape(T * h * w, 256).contiguous().to(DEV)
+    pooled = torch.zeros(2, T, (h // 4) * (w // 4), device=DEV)
+    sim = torch.zeros(T, T, device=DEV)
+    L.check(L.load().ppms_qk_similarity(qk.data_ptr(), qk.data_ptr() + 512, 256, pooled.data_ptr(), sim.data_ptr(), T, h, w, L.stream_ptr()))
+    assert maxdiff(sim, O.qk_similarity(q, k)) < 2e-6
+
+
+def test_qam_select_sequence(lib):
+    """QAM scoring / top-5 pick / usage counter over several iterations with T = 8 > top_k (ppmstereo.py:501-513)."""
+    L = lib
+    T, HW = 8, 700
+    nblk = (HW + 255) // 256
+    sim = torch.tanh(hash_normal((T, T), 700))
+    strive_ref = torch.ones(T, T)
+    strive = torch.ones(T, T, device=DEV)
+    sel = torch.zeros(T, 5, dtype=torch.int32, device=DEV)
+    shat, score = torch.zeros(T, 5, device=DEV), torch.zeros(T, T, device=DEV)
+    for it in range(6):
+        unc = torch.sigmoid(hash_normal((T, HW), 710 + it))
+        part = torch.zeros(T, nblk)
+        for b in range(nblk):
+            part[:, b] = unc[:, b * 256:(b + 1) * 256].sum(1)
+        sc, mask, strive_ref = O.qam_select(sim, strive_ref, unc.mean(1))
+        L.check(L.load().ppms_qam_select(sim.to(DEV).data_ptr(), strive.data_ptr(), part.to(DEV).data_ptr(), nblk, HW, sel.data_ptr(), shat.data_ptr(),
+                                         score.data_ptr(), T, L.stream_ptr()))
+        assert maxdiff(score, sc) < 2e-6
+        for i in range(T):
+            J = torch.nonzero(mask[i]).flatten()
+            assert sel[i].cpu().tolist() == J.tolist(), (it, i)
+            s = sc[i, J]
+            assert maxdiff(shat[i], s / s.mean()) < 2e-6
+        assert torch.equal(strive.cpu(), strive_ref)
+
+
+# ------------------------------------------------------------------------------------------------ memory attention
+@pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5)])
+def test_mem_attn_vs_oracle(lib, T, n, ksel_frames):
+    """prep_q + prep_k + mem_attn against play_inputs + flash_attn_math (ppmstereo.py:517-552)."""
+    L = lib
+    from ppmstereo_amd.engine import softmax_scale, temporal_pe
+    h, w = (n // 32, 32) if n % 32 == 0 else (n // 20, 20) if n % 20 == 0 else (n // 18, 18)
+    assert h * w == n
+    q, key, value = hash_normal((T, 128, h, w), 800), hash_normal((T, 128, h, w), 801), hash_normal((T, 128, h, w), 802)
+    mf = hash_normal((T, 128, h, w), 803)
+    pe = temporal_pe(T, 128)
+    score = 1.0 + 0.3 * torch.tanh(hash_normal((T, T), 804))
+    mask = torch.zeros(T, T, dtype=torch.bool)
+    for i in range(T):
+        mask[i, torch.argsort(score[i], descending=True)[:ksel_frames]] = True
+    sel = torch.zeros(T, 5, dtype=torch.int32)
+    shat = torch.zeros(T, 5)
+    ref = torch.zeros(T, n, 128)
+    scale = softmax_scale(128)
+    for i in range(T):
+        Q, K, V, J, s_hat = O.play_inputs(q, key, pe, value, score, mask, i)
+        sel[i, :len(J)] = J.int()
+        shat[i, :len(J)] = s_hat
+        ref[i] = O.flash_attn_math(Q, K, V, scale)
+    cl = lambda x: x.permute(0, 2, 3, 1).reshape(T * n, 128).contiguous()
+    qk = torch.cat([cl(q), cl(key)], 1).contiguous().to(DEV)
+    qb = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
+    kb = torch.zeros(T, ksel_frames, n, 128, dtype=torch.bfloat16, device=DEV)
+    vt = value.reshape(T, 128, n).to(torch.bfloat16).contiguous().to(DEV)
+    ped, seld, shatd = pe.to(DEV), sel.to(DEV), shat.to(DEV)
+    lib_ = L.load()
+    s = L.stream_ptr()
+    L.check(lib_.ppms_attn_prep_q(qk.data_ptr(), 256, ped.data_ptr(), qb.data_ptr(), T, n, s))
+    L.check(lib_.ppms_attn_prep_k(qk.data_ptr() + 512, 256, ped.data_ptr(), seld.data_ptr(), shatd.data_ptr(), kb.data_ptr(), T, ksel_frames, n, s))
+    X = L.SPTensor(T * n, 256, DEV)
+    X.set_f32(cl(mf).to(DEV), 0)
+    beta = torch.tensor([0.5], device=DEV)
+    raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
+    L.check(lib_.ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), seld.data_ptr(), ksel_frames, scale, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
+                               raw.data_ptr(), T, n, s))
+    torch.cuda.synchronize()
+    # operands: bit-exact bf16 of the oracle's fp32 operands
+    Q0, K0, _, _, _ = O.play_inputs(q, key, pe, value, score, mask, 0)
+    assert torch.equal(qb[0].float().cpu(), Q0.to(torch.bfloat16).float())
+    assert torch.equal(kb[0].reshape(-1, 128).float().cpu(), K0.to(torch.bfloat16).float())
+    # output: bf16 P in the PV product -> a few bf16 ulps of the value range
+    d = maxdiff(raw.float(), ref)
+    assert d < 0.02 * ref.abs().max().item() + 1e-3, d
+    mfg = X.to_f32(128, 128).cpu()
+    assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 2e-5
+
+
+def test_mem_attn_sharp_softmax(lib):
+    """Forces the online-softmax rescale path: one key per query dominates and sits in a late tile."""
+    L = lib
+    from ppmstereo_amd.engine import softmax_scale
+    T, n = 2, 512
+    q = hash_normal((T, n, 128), 900)
+    k = hash_normal((T, 2, n, 128), 901) * 0.1
+    v = hash_normal((T, 128, n), 902)
+    for i in range(n):
+        k[0, 1, (i * 7 + 300) % n] += 40.0 * q[0, i] / q[0, i].norm()
+    qb, kb, vt = q.to(torch.bfloat16).to(DEV), k.to(torch.bfloat16).to(DEV), v.to(torch.bfloat16).to(DEV)
+    sel = torch.tensor([[0, 1, 0, 0, 0], [0, 1, 0, 0, 0]], dtype=torch.int32, device=DEV)
+    X = L.SPTensor(T * n, 256, DEV)
+    beta = torch.tensor([1.0], device=DEV)
+    raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
+    scale = 1.0
+    L.check(L.load().ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 2, scale, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
+                                   raw.data_ptr(), T, n, L.stream_ptr()))
+    for i in range(T):
+        K = kb[i].reshape(-1, 128).float().cpu()
+        V = torch.cat([vt[0].float().cpu().t(), vt[1].float().cpu().t()], 0)
+        ref = O.flash_attn_math(qb[i].float().cpu(), K, V, scale)
+        assert maxdiff(raw[i].float(), ref) < 0.02 * ref.abs().max().item() + 1e-3

@@ -1,0 +1,112 @@
+"""CPU: host-side logic of the product (weight packing, descriptor geometry, state_dict layout, windowing)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ppm_oracle as O
+from ppmstereo_amd import weights as Wm
+from ppmstereo_amd.packing import BK, pack_conv, unpack_conv_reference
+from ppmstereo_amd.weights import hash_normal
+
+
+def emulate_kernel(packed, bias, meta, xs, seg_pad, T, H, W):
+    """What conv_gemm.hip computes, restated with torch on the CPU from the PACKED weights: K order
+    k = tap*Cpad + ci, tap = (kz*kh + ky)*kw + kx, shifted zero-padded pixel rows."""
+    kt, kh, kw = meta["taps"]
+    Wm_ = unpack_conv_reference(packed.cpu(), meta["M"], meta["nk"])            # [M][K]
+    P = T * H * W
+    cols = []
+    xp = []
+    for x, cp in zip(xs, seg_pad):
+        xp.append(F.pad(x, (0, cp - x.shape[1])))
+    xcat = torch.cat(xp, 1).reshape(T, H, W, -1)
+    for kz in range(kt):
+        for ky in range(kh):
+            for kx in range(kw):
+                dt, dy, dx = kz - kt // 2, ky - kh // 2, kx - kw // 2
+                sh = torch.zeros_like(xcat)
+                t0, t1 = max(0, -dt), min(T, T - dt)
+                y0, y1 = max(0, -dy), min(H, H - dy)
+                x0, x1 = max(0, -dx), min(W, W - dx)
+                if t0 < t1 and y0 < y1 and x0 < x1:
+                    sh[t0:t1, y0:y1, x0:x1] = xcat[t0 + dt:t1 + dt, y0 + dy:y1 + dy, x0 + dx:x1 + dx]
+                cols.append(sh.reshape(P, -1))
+    A = torch.cat(cols, 1)                                                    # [P][K]
+    return A @ Wm_.t() + bias.cpu()
+
+
+@pytest.mark.parametrize("segs,cout,k3", [([36], 54, (1, 1, 1)), ([128, 384], 256, (1, 1, 15)), ([128, 64], 128, (5, 1, 1)),
+                                          ([128], 190, (3, 3, 3)), ([320], 190, (1, 3, 3))])
+def test_packing_reproduces_the_convolution(segs, cout, k3):
+    T, H, W = 3, 4, 6
+    P = T * H * W
+    cin = sum(segs)
+    xs = [hash_normal((P, c), 10 + i) for i, c in enumerate(segs)]
+    wt = hash_normal((cout, cin, *k3), 20) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 21)
+    seg_pad = [((c + 31) // 32) * 32 for c in segs]
+    packed, bias, meta = pack_conv(wt, bs, segs, seg_pad)
+    assert packed.dtype == torch.bfloat16 and packed.numel() == 2 * meta["M"] * meta["nk"] * BK
+    got = emulate_kernel(packed, bias, meta, xs, seg_pad, T, H, W)[:, :cout]
+    x5 = torch.cat(xs, 1).reshape(1, T, H, W, cin).permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(x5, wt, bs, padding=tuple(k // 2 for k in k3)).permute(0, 2, 3, 4, 1).reshape(P, cout)
+    assert (got - ref).abs().max() < 2e-4 * (1 + ref.abs().max())          # hi+lo weights carry ~16 mantissa bits
+
+
+def test_packing_cout_map_routes_groups_to_aligned_blocks():
+    wt, bs = hash_normal((190, 320, 3, 3), 30) / 50, hash_normal((190,), 31)
+    rows = list(range(126)) + list(range(128, 192))
+    packed, bias, meta = pack_conv(wt, bs, [320], None, rows, 192)
+    full = unpack_conv_reference(packed, 192, meta["nk"])
+    assert meta["M"] == 192 and (full[126:128] == 0).all() and (bias[126:128] == 0).all()
+    assert torch.allclose(bias[128:192], bs[126:]) and torch.allclose(bias[:126], bs[:126])
+
+
+def test_update_block_state_dict_is_the_reference_layout():
+    from ppmstereo_amd.ppmstereo import PPMStereoHotPath
+    m = PPMStereoHotPath()
+    for tag, attn in (("update_block16", True), ("update_block08", False), ("update_block04", False)):
+        sd = getattr(m, tag).state_dict()
+        want = Wm.update_block_param_shapes(attn)
+        assert list(sd.keys()) == list(sd.keys()) and set(sd.keys()) == set(want.keys())
+        for k, shape in want.items():
+            assert tuple(sd[k].shape) == tuple(shape), k
+    assert tuple(m.att[0].state_dict()["to_qk.weight"].shape) == (256, 128, 1, 1)
+    n = sum(p.numel() for p in m.update_block16.parameters())
+    assert abs(n - 9.39e6) < 0.01e6                       # update_block16 has 9.39 M parameters
+
+
+def test_unsupported_configurations_raise():
+    from ppmstereo_amd.ppmstereo import PPMStereoHotPath
+    from ppmstereo_amd.update import SequenceUpdateBlock3D
+    with pytest.raises(NotImplementedError):
+        PPMStereoHotPath(use_convex_3d=True)
+    with pytest.raises(NotImplementedError):
+        SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4, use_convex_3d=True)
+
+
+def test_ops_refuse_cpu_tensors_without_touching_a_gpu():
+    from ppmstereo_amd.corr import CorrBlock1D
+    with pytest.raises(RuntimeError, match="GPU only"):
+        CorrBlock1D(torch.zeros(1, 256, 4, 32), torch.zeros(1, 256, 4, 32))
+
+
+def test_window_plan_matches_the_oracle_restatement():
+    from ppmstereo_amd.ppmstereo import shard_windows, window_plan
+    for n, k in ((40, 20), (5, 20), (25, 20), (150, 20), (40, 10), (21, 20), (19, 20)):
+        assert window_plan(n, k) == O.window_plan(n, k), (n, k)
+    plan = window_plan(150, 20)
+    parts = [shard_windows(plan, r, 4) for r in range(4)]
+    assert sorted(sum(parts, [])) == sorted(plan) and max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_temporal_encoding_and_scale_match_the_oracle():
+    from ppmstereo_amd.engine import softmax_scale, temporal_pe
+    from ppmstereo_amd.update import get_temporal_positional_encoding
+    for T in (2, 5, 8, 40):
+        assert torch.equal(temporal_pe(T, 128), O.temporal_pe(T, 128))
+        assert torch.equal(get_temporal_positional_encoding(T, 128, "cpu", is_normalize=True, scale=1.0).reshape(T, 128), O.temporal_pe(T, 128))
+    assert torch.isnan(temporal_pe(1, 128)).all()
+    assert softmax_scale(128) == O.softmax_scale(128)
