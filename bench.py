@@ -119,7 +119,9 @@ def main():
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(T, H, W, iters, os.cpu_count() or 1)
+            # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+            cores = min(16, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else min(16, os.cpu_count() or 1)
+            cpu = cpu_baseline(T, H, W, iters, cores)
         out = dict(metric="disparity-px/s", value=round(value, 1), unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", precision="attention: bf16 MFMA, fp32 softmax/accumulate; convs: bf16x3 split MFMA (fp32-accurate); correlation: fp32 MFMA",
                    data="synthetic", frames_per_s=round(world * args.steps * T / elapsed, 2),

@@ -48,7 +48,7 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
-        case PPMS_ACT_RELU: return fmaxf(x, 0.0f);
+        case PPMS_ACT_RELU: return x < 0.0f ? 0.0f : x;   // not fmaxf: NaN must propagate like torch.relu (T == 1 case)
         case PPMS_ACT_GELU: return gelu_erf(x);
         case PPMS_ACT_SIGMOID: return sigmoid_f(x);
         case PPMS_ACT_TANH: return tanhf(x);

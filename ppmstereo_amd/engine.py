@@ -150,6 +150,9 @@ class ScaleEngine:
         self.CORR, self.T1, self.C1, self.C2 = sp(64), sp(64), sp(64), sp(64)
         self.COR256, self.CF, self.PATCH, self.FLO1 = sp(256), [sp(320), sp(320)], sp(128), sp(128)
         self.X, self.VAL, self.U1 = sp(384), sp(128), sp(128)
+        # update_block16 runs time / space attention on a COPY of x = [inp, mf, mfg] (the reference's inp_tensor is a
+        # local of SequenceUpdateBlock3D.forward, ppmtereo_update.py:976-983: inp itself must survive the iteration)
+        self.XA = sp(384) if pk.attn is not None else self.X
         self.Hb = [sp(128), sp(128), sp(128)]
         self.ZT, self.RT, self.RH, self.FH1, self.M1 = sp(128), sp(128), sp(128), sp(256), sp(256)
         self.Z, self.MASK, self.FLOW, self.QK = f32(P, 128), f32(P, 144), f32(P, 2), f32(P, 256)
@@ -215,7 +218,7 @@ class ScaleEngine:
                                            E(act=L.ACT_RELU, n_valid=64, out_sp=cf_next.view(256, 64)), m_split=128)
         o["to_v"] = self._conv("to_v", [mf], k1, E(n_valid=128, out_sp=self.VAL.view(), out_vt=self.VT))
         o["unc0"] = self._conv("unc0", [H[0].view(), self.VAL.view()], k3, E(act=L.ACT_RELU, n_valid=128, out_sp=self.U1.view()))
-        x_all = X.view()
+        x_all = self.XA.view()
         # GRU pass along W (two-layer z / r), then H, then T: h cycles through Hb[0] -> Hb[1] -> Hb[2] -> Hb[0]
         o["zr1_0"] = self._conv("zr1_0", [H[0].view(), x_all], (1, 1, 15), E(act=L.ACT_GELU, n_valid=128, out_sp=self.ZT.view()),
                                 E(act=L.ACT_GELU, n_valid=128, out_sp=self.RT.view()), m_split=128)
@@ -386,7 +389,7 @@ class ScaleEngine:
         from .attn16 import time_space_attention
         x = self.X.to_f32()                                                     # (P, 384)
         x = time_space_attention(self.pk.attn, x, self.T, self.h, self.w)
-        self.X.set_f32(x)
+        self.XA.set_f32(x)
 
     def update(self):
         o = self.op

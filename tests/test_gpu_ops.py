@@ -246,7 +246,8 @@ def test_qam_select_sequence(lib):
         for b in range(nblk):
             part[:, b] = unc[:, b * 256:(b + 1) * 256].sum(1)
         sc, mask, strive_ref = O.qam_select(sim, strive_ref, unc.mean(1))
-        L.check(L.load().ppms_qam_select(sim.to(DEV).data_ptr(), strive.data_ptr(), part.to(DEV).data_ptr(), nblk, HW, sel.data_ptr(), shat.data_ptr(),
+        simd, partd = sim.to(DEV), part.to(DEV)             # keep the device copies alive across the launch
+        L.check(L.load().ppms_qam_select(simd.data_ptr(), strive.data_ptr(), partd.data_ptr(), nblk, HW, sel.data_ptr(), shat.data_ptr(),
                                          score.data_ptr(), T, L.stream_ptr()))
         assert maxdiff(score, sc) < 2e-6
         for i in range(T):
@@ -306,7 +307,8 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames):
     d = maxdiff(raw.float(), ref)
     assert d < 0.02 * ref.abs().max().item() + 1e-3, d
     mfg = X.to_f32(128, 128).cpu()
-    assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 2e-5
+    # mfg is stored split (hi + lo): ~2^-16 relative
+    assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 1e-4
 
 
 def test_mem_attn_sharp_softmax(lib):
