@@ -1,0 +1,323 @@
+// Implicit-GEMM convolution, second generation: data-reuse tiling for gfx950.
+//
+// Same math and descriptor as conv_gemm.hip (bf16x3 split MFMA, fp32 accumulate, fused epilogues) but the operand
+// traffic is cut to what the 32 MiB of L2 can deliver:
+//   * one workgroup owns ALL output channels of its pixel tile (BM = 64*WM couts, WM in 1..4), so the activation
+//     tile is fetched once instead of once per 64-cout block;
+//   * the pixel tile is an R x C patch (R*C = 128) and the activations of one (dt, dy, 32-channel chunk) are staged
+//     in LDS as a halo'd window of R x (C + kw - 1) pixel rows; the kw taps along x then sweep that window from LDS
+//     (15 taps of the GRU's (1,1,15) conv re-read 1 window instead of 15 tiles);
+//   * per k-step only the weight tile (BM x 32, contiguous, pre-swizzled) streams in: it is the same for every
+//     workgroup, so it comes out of L2.
+// Bytes per k-step drop from 40 KiB per 1.05 MFLOP (v1) to <= (8*WM + 16/kw..16) KiB per 0.26*WM MFLOP.
+//
+// Waves: 2*WM waves, wave (wm, wn) computes couts [64 wm, 64 wm + 64) x pixels [64 wn, 64 wn + 64) = 2x2 MFMA
+// 32x32x16 tiles.  LDS: weight stages 2 x WM x 8 KiB, window stages 2 x 2 planes x rows x 64 B (XOR-swizzled rows).
+// Packed weights (ppmstereo_amd/packing.py pack_conv2): [k-step][M/64][hi,lo][64][32] with
+// k-step = ((kz*kh + ky) * nchunk + chunk) * kw + kx.
+#include "common.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int A_BLK = 64 * BK * 2 * 2;       // one 64-cout block, hi + lo planes: 8 KiB
+
+struct Geo2 {
+    int C, R, logC;          // patch: R rows x C cols, R*C = 128
+    int tiles_x, tiles_y;    // per frame
+    int WR;                  // window row length in pixels = C + kw - 1
+    int Wr;                  // window rows = R * WR
+    int nchunk, n0;          // 32-channel chunks per tap (all segments), chunks of segment 0
+    int nk;                  // k-steps = kt*kh*nchunk*kw
+    int mgroups;             // M / (64*WM)
+};
+
+__device__ __forceinline__ int swz2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+template <int WM>
+__global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __restrict__ pd, const Geo2 g) {
+    constexpr int NT = 128 * WM;
+    constexpr int MAXSLOT = (WM == 4) ? 2 : (WM == 3) ? 3 : (WM == 2) ? 4 : 8;      // window 16-B chunks per thread and plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ppms_conv& p = *pd;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+    const int mgrp = blockIdx.x % g.mgroups;
+    int tile = blockIdx.x / g.mgroups;
+    const int tx = tile % g.tiles_x;
+    tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y;
+    const int tf = tile / g.tiles_y;                       // frame
+    const int x0 = tx * g.C, y0 = ty * g.R;
+    const int H = p.H, W = p.W, T = p.T;
+    const int HW = H * W;
+    const int hx = p.kw >> 1, hy = p.kh >> 1, ht = p.kt >> 1;
+
+    char* sA = smem;                                       // 2 stages x WM x 8 KiB
+    const int bplane = g.Wr * 64;
+    char* sB = smem + 2 * WM * A_BLK;                      // 2 stages x 2 planes x Wr x 64 B
+
+    // ---- window slots of this thread (fixed for the whole kernel) ------------------------------------------
+    int sl_off[MAXSLOT];          // pixel offset (t*H + y)*W + x of the slot at (dt, dy) = 0, or -1: x outside the image
+    int sl_y[MAXSLOT];
+    int sl_lds[MAXSLOT];          // swizzled LDS byte offset inside a plane, -1: slot unused
+    const int nslot_total = g.Wr * 4;
+#pragma unroll
+    for (int i = 0; i < MAXSLOT; ++i) {
+        const int j = tid + i * NT;
+        sl_lds[i] = -1;
+        sl_off[i] = -1;
+        sl_y[i] = 0;
+        if (j < nslot_total) {
+            const int wrow = j >> 2, c = j & 3;
+            const int wy = wrow / g.WR, wx = wrow - wy * g.WR;
+            const int x = x0 + wx - hx, y = y0 + wy;
+            sl_lds[i] = swz2(wrow, c);
+            sl_y[i] = y;
+            if ((unsigned)x < (unsigned)W) sl_off[i] = (tf * H + y) * W + x;
+        }
+    }
+    const int cB = tid & 3;       // 16-B chunk inside the 64-B channel group (j & 3 == tid & 3 because NT % 4 == 0)
+
+    const char* wbase = (const char*)p.w + (int64_t)mgrp * WM * A_BLK + tid * 16;
+    const int64_t wstep = (int64_t)(p.M / 64) * A_BLK;
+
+    u32x4 ra[4], rbh[MAXSLOT], rbl[MAXSLOT];
+    auto load_a = [&](int ks) {
+        const char* wp = wbase + (int64_t)ks * wstep;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = gload16(wp + i * NT * 16);
+    };
+    auto store_a = [&](int stage) {
+        char* s = sA + stage * WM * A_BLK + tid * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(s + i * NT * 16) = ra[i];
+    };
+    auto load_b = [&](int trow, int chunk) {
+        const int ky = trow % p.kh, kz = trow / p.kh;
+        const int dy = ky - hy, dt = kz - ht;
+        const int s = (chunk >= g.n0) ? 1 : 0;
+        const int c0 = (chunk - (s ? g.n0 : 0)) * BK + cB * 8;
+        const bf16_t* sh = (const bf16_t*)p.seg[s].hi;
+        const bf16_t* sl = (const bf16_t*)p.seg[s].lo;
+        const int ld = p.seg[s].ld;
+        const bool tok = (unsigned)(tf + dt) < (unsigned)T;
+        const int shift = (dt * H + dy) * W;
+#pragma unroll
+        for (int i = 0; i < MAXSLOT; ++i) {
+            const bool ok = tok && sl_off[i] >= 0 && (unsigned)(sl_y[i] + dy) < (unsigned)H;
+            if (ok) {
+                const int64_t off = (int64_t)(sl_off[i] + shift) * ld + c0;
+                rbh[i] = gload16(sh + off);
+                rbl[i] = gload16(sl + off);
+            } else {
+                rbh[i] = (u32x4){0, 0, 0, 0};
+                rbl[i] = (u32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    auto store_b = [&](int stage) {
+        char* s = sB + stage * 2 * bplane;
+#pragma unroll
+        for (int i = 0; i < MAXSLOT; ++i)
+            if (sl_lds[i] >= 0) {
+                *(u32x4*)(s + sl_lds[i]) = rbh[i];
+                *(u32x4*)(s + bplane + sl_lds[i]) = rbl[i];
+            }
+    };
+
+    // ---- this lane's two B-operand pixels (patch-linear id -> window row at kx = 0) ------------------------------
+    int brow[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int pid = wn * 64 + nb * 32 + r;
+        brow[nb] = (pid >> g.logC) * g.WR + (pid & (g.C - 1));
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x16){0};
+
+    // k-step state of the step being LOADED: (trow, chunk, kx)
+    int l_trow = 0, l_chunk = 0, l_kx = 0;
+    load_a(0);
+    load_b(0, 0);
+    store_a(0);
+    store_b(0);
+    __syncthreads();
+    int bsel = 0, kx = 0;
+    for (int ks = 0; ks < g.nk; ++ks) {
+        const bool more = ks + 1 < g.nk;
+        bool need_b = false;
+        if (more) {
+            if (++l_kx == p.kw) {
+                l_kx = 0;
+                need_b = true;
+                if (++l_chunk == g.nchunk) {
+                    l_chunk = 0;
+                    ++l_trow;
+                }
+            }
+            load_a(ks + 1);
+            if (need_b) load_b(l_trow, l_chunk);
+        }
+        const char* a_s = sA + (ks & 1) * WM * A_BLK + wm * A_BLK;
+        const char* b_s = sB + bsel * 2 * bplane;
+#pragma unroll
+        for (int k16 = 0; k16 < 2; ++k16) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int off = swz2(mb * 32 + r, 2 * k16 + h);
+                ah[mb] = *(const bf16x8*)(a_s + off);
+                al[mb] = *(const bf16x8*)(a_s + 4096 + off);
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int off = swz2(brow[nb] + kx, 2 * k16 + h);
+                bh[nb] = *(const bf16x8*)(b_s + off);
+                bl[nb] = *(const bf16x8*)(b_s + bplane + off);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bl[nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mb], bh[nb], acc[mb][nb], 0, 0, 0);
+                }
+        }
+        if (more) {
+            store_a((ks + 1) & 1);
+            if (need_b) store_b(bsel ^ 1);
+        }
+        __syncthreads();
+        if (need_b) {
+            bsel ^= 1;
+            kx = 0;
+        } else {
+            ++kx;
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    const int cblock = (mgrp * WM + wm) * 64;
+    const int half = (cblock >= p.m_split) ? 1 : 0;
+    const ppms_epilogue& e = p.epi[half];
+    const int cbase = cblock - (half ? p.m_split : 0);
+    for (int it = 0; it < 16; ++it) {
+        const int nb = it >> 3, mb = (it >> 2) & 1, gq = it & 3;
+        float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int s_nb = 0; s_nb < 2; ++s_nb)
+#pragma unroll
+            for (int s_mb = 0; s_mb < 2; ++s_mb)
+#pragma unroll
+                for (int s_g = 0; s_g < 4; ++s_g)
+                    if (it == s_nb * 8 + s_mb * 4 + s_g) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a4[j] = acc[s_mb][s_nb][4 * s_g + j];
+                    }
+        const int pid = wn * 64 + nb * 32 + r;
+        const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+        if (px < W && py < H) {
+            const int64_t pix = (int64_t)(tf * H + py) * W + px;
+            const int c4 = mb * 32 + 8 * gq + 4 * h;
+            const f32x4 b4 = *(const f32x4*)(p.bias + cblock + c4);
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = a4[j] + b4[j];
+            epilogue_group(e, v, pix, cbase + c4, HW);
+        }
+    }
+}
+
+template <int WM>
+int launch2(const ppms_conv* d, const ppms_conv* dev_desc, const Geo2& g, int ntiles, hipStream_t stream) {
+    const size_t lds = (size_t)2 * WM * A_BLK + (size_t)2 * 2 * g.Wr * 64;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute((const void*)conv2_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        lds_set = 160 * 1024;
+    }
+    hipLaunchKernelGGL(conv2_kernel<WM>, dim3(ntiles * g.mgroups), dim3(128 * WM), lds, stream, dev_desc, g);
+    return ppms_check_launch("conv_gemm2");
+}
+
+}  // namespace
+
+// wm_hint: 0 = choose (all couts per workgroup when the grid still fills the chip, otherwise 64-cout blocks)
+extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, void* stream) {
+    PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm2: null descriptor (host copy and device copy are both required)");
+    PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm2: nseg=%d", d->nseg);
+    PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm2: bad volume %dx%dx%d", d->T, d->H, d->W);
+    PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15, "conv_gemm2: kernel extents must be odd, kw <= 15");
+    PPMS_REQUIRE(d->M > 0 && d->M % 64 == 0 && d->m_split % 64 == 0, "conv_gemm2: M=%d / m_split=%d not multiples of 64", d->M, d->m_split);
+    PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm2: weights/bias missing");
+    PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 31) / 512, "conv_gemm2: volume too large for 32-bit pixel offsets");
+    int nchunk = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        PPMS_REQUIRE(d->seg[s].hi && d->seg[s].lo && d->seg[s].c > 0 && d->seg[s].c % BK == 0 && d->seg[s].ld % 8 == 0,
+                     "conv_gemm2: segment %d needs hi/lo planes, c %% 32 == 0 and ld %% 8 == 0 (c=%d ld=%d)", s, d->seg[s].c, d->seg[s].ld);
+        PPMS_REQUIRE(((uintptr_t)d->seg[s].hi & 15) == 0 && ((uintptr_t)d->seg[s].lo & 15) == 0, "conv_gemm2: segment %d not 16-B aligned", s);
+        nchunk += d->seg[s].c / BK;
+    }
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const ppms_epilogue& e = d->epi[hlf];
+        if (hlf == 1 && d->m_split >= d->M) break;
+        PPMS_REQUIRE(e.n_valid > 0, "conv_gemm2: epilogue %d has n_valid=%d", hlf, e.n_valid);
+        if (e.out_sp.hi) PPMS_REQUIRE(e.out_sp.lo && e.out_sp.ld % 4 == 0 && ((uintptr_t)e.out_sp.hi & 7) == 0 && ((uintptr_t)e.out_sp.lo & 7) == 0,
+                                      "conv_gemm2: epilogue %d SP output misaligned", hlf);
+        if (e.out_f32) PPMS_REQUIRE(e.out_f32_ld % 4 == 0 || e.kind == PPMS_EPI_ADDF32, "conv_gemm2: epilogue %d f32 ld", hlf);
+        if (e.kind == PPMS_EPI_RESID || e.kind == PPMS_EPI_RH || e.kind == PPMS_EPI_GRU)
+            PPMS_REQUIRE(e.aux_sp.hi && e.aux_sp.lo && e.aux_sp.ld % 4 == 0, "conv_gemm2: epilogue %d needs aux_sp", hlf);
+        if (e.kind == PPMS_EPI_GRU) PPMS_REQUIRE(e.aux_f32 != nullptr, "conv_gemm2: GRU epilogue needs z");
+        if (e.kind == PPMS_EPI_ADDF32) PPMS_REQUIRE(e.out_f32 != nullptr, "conv_gemm2: ADDF32 epilogue needs out_f32");
+    }
+    // patch width: the power of two in [16,128] wasting the fewest pixels of the 128-pixel tile (ties: the widest)
+    Geo2 g;
+    int bestC = 16;
+    double bestw = 1e30;
+    for (int C = 16; C <= 128; C *= 2) {
+        const int R = 128 / C;
+        const double waste = (double)((d->W + C - 1) / C * C) * ((d->H + R - 1) / R * R) / ((double)d->W * d->H);
+        if (waste <= bestw + 1e-9) {
+            bestw = waste;
+            bestC = C;
+        }
+    }
+    g.C = bestC;
+    g.R = 128 / bestC;
+    g.logC = 0;
+    while ((1 << g.logC) < g.C) ++g.logC;
+    g.tiles_x = (d->W + g.C - 1) / g.C;
+    g.tiles_y = (d->H + g.R - 1) / g.R;
+    g.WR = g.C + d->kw - 1;
+    g.Wr = g.R * g.WR;
+    g.nchunk = nchunk;
+    g.n0 = d->seg[0].c / BK;
+    g.nk = d->kt * d->kh * nchunk * d->kw;
+    const int ntiles = g.tiles_x * g.tiles_y * d->T;
+    const int mblocks = d->M / 64;
+    int wm = wm_hint;
+    if (wm <= 0) {
+        wm = mblocks <= 4 ? mblocks : 4;
+        if (ntiles < 160 && mblocks > 1) wm = 1;          // small maps: spread cout blocks over more workgroups
+    }
+    PPMS_REQUIRE(wm >= 1 && wm <= 4 && mblocks % wm == 0, "conv_gemm2: wm=%d does not divide M/64=%d", wm, mblocks);
+    g.mgroups = mblocks / wm;
+    const int maxslot = wm == 4 ? 2 : wm == 3 ? 3 : wm == 2 ? 4 : 8;
+    PPMS_REQUIRE(g.Wr * 4 <= 128 * wm * maxslot, "conv_gemm2: window of %d rows does not fit the staging slots", g.Wr);
+    PPMS_REQUIRE(2 * wm * A_BLK + 4 * g.Wr * 64 <= 160 * 1024, "conv_gemm2: LDS budget exceeded");
+    hipStream_t st = (hipStream_t)stream;
+    switch (wm) {
+        case 1: return launch2<1>(d, dev_desc, g, ntiles, st);
+        case 2: return launch2<2>(d, dev_desc, g, ntiles, st);
+        case 3: return launch2<3>(d, dev_desc, g, ntiles, st);
+        default: return launch2<4>(d, dev_desc, g, ntiles, st);
+    }
+}

@@ -20,14 +20,21 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
 
 from . import _lib as L
-from .packing import pack_conv
+from . import packing as _packing
 
 TOP_K = 5
+# 2 = data-reuse tiling (conv_gemm2.hip, default); 1 = first-generation kernel (conv_gemm.hip), kept for A/B checks
+CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
+
+
+def pack_conv(*a, **k):
+    return (_packing.pack_conv2 if CONV_VERSION == 2 else _packing.pack_conv)(*a, **k)
 
 
 def temporal_pe(T: int, channels: int) -> torch.Tensor:
@@ -52,14 +59,17 @@ def softmax_scale(c: int = 128) -> float:
 class ConvOp:
     """One implicit-GEMM launch: host descriptor (validated by the library) + its device copy."""
 
-    def __init__(self, desc: L.Conv, keep: list):
-        self.desc = desc
+    def __init__(self, desc: L.Conv, keep: list, version: int = 1, wm_hint: int = 0):
+        self.desc, self.version, self.wm_hint = desc, version, wm_hint
         raw = bytes(desc)
         self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone().cuda()
         self.keep = keep            # tensors whose storage the descriptor points at
 
     def __call__(self):
-        L.check(L.load().ppms_conv_gemm(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
+        if self.version == 2:
+            L.check(L.load().ppms_conv_gemm2(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
+        else:
+            L.check(L.load().ppms_conv_gemm(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
 
 
 def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Optional[L.SP] = None, out_f32=None, out_f32_ld=0,
@@ -193,7 +203,7 @@ class ScaleEngine:
         d.epi[0] = epi0
         if epi1 is not None:
             d.epi[1] = epi1
-        return ConvOp(d, [packed, bias, *keep])
+        return ConvOp(d, [packed, bias, *keep], meta.get("version", 1))
 
     def _build_descriptors(self):
         E, X, H = epilogue, self.X, self.Hb

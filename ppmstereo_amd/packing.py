@@ -73,6 +73,63 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: 
     return packed.reshape(-1), b, meta
 
 
+def pack_conv2(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
+               seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
+               m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+    """Layout of the second-generation kernel (ppmstereo_amd/csrc/conv_gemm2.hip):
+    bf16 [k-step][M/64][2 planes][64][32], k-step = ((kz*kh + ky) * nchunk + chunk) * kw + kx -- the kw taps along x
+    of one (dt, dy, 32-channel chunk) are consecutive k-steps (they sweep one LDS activation window) and all cout
+    blocks of a k-step are contiguous (one workgroup stages them with a single linear copy).  Same swizzle as v1."""
+    w = weight.detach().float()
+    if w.dim() == 4:
+        w = w[:, :, None]
+    cout, cin, kt, kh, kw = w.shape
+    assert sum(seg_channels) == cin, (seg_channels, cin)
+    seg_padded = [_pad_to(c, BK) for c in seg_channels] if seg_padded is None else list(seg_padded)
+    assert all(p % BK == 0 and p >= c for p, c in zip(seg_padded, seg_channels))
+    cpad = sum(seg_padded)
+    nchunk = cpad // BK
+    rows = list(range(cout)) if cout_map is None else list(cout_map)
+    M = _pad_to(max(rows) + 1, BM) if m_pad is None else m_pad
+    assert M % BM == 0 and max(rows) < M
+    wk = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh, kw, cin)              # [cout][trow][kx][ci]
+    full = torch.zeros(M, kt * kh, kw, cpad, dtype=torch.float32, device=w.device)
+    ridx = torch.tensor(rows, device=w.device)
+    src = dst = 0
+    for c, p in zip(seg_channels, seg_padded):
+        full[ridx, :, :, dst:dst + c] = wk[:, :, :, src:src + c]
+        src += c
+        dst += p
+    nk = kt * kh * nchunk * kw
+    t = full.reshape(M // BM, BM, kt * kh, kw, nchunk, 4, 8).permute(2, 4, 3, 0, 1, 5, 6).contiguous()   # [trow][chunk][kx][mblk][m][c][8]
+    t = t.reshape(nk, M // BM, BM, 4, 8)
+    m = torch.arange(BM, device=w.device)
+    chunk = torch.arange(4, device=w.device)
+    pos = chunk[None, :] ^ ((m[:, None] >> 2) & 3)
+    sw = torch.empty_like(t)
+    sw[:, :, m[:, None].expand(BM, 4), pos] = t
+    hi, lo = split_bf16(sw)
+    packed = torch.stack([hi, lo], dim=2).contiguous()                    # [ks][mblk][2][64][4][8]
+    b = torch.zeros(M, dtype=torch.float32, device=w.device)
+    if bias is not None:
+        b[ridx] = bias.detach().float()
+    meta = dict(M=M, nk=nk, taps=(kt, kh, kw), cpad=cpad, seg_padded=seg_padded, version=2)
+    return packed.reshape(-1), b, meta
+
+
+def unpack_conv2_reference(packed: torch.Tensor, M: int, nk: int, taps, nchunk: int) -> torch.Tensor:
+    """Inverse of pack_conv2 -> fp32 [M][K] in the v1 K order (k = tap*Cpad + ci), for the host-logic tests."""
+    kt, kh, kw = taps
+    t = packed.reshape(nk, M // BM, 2, BM, 4, 8).float()
+    t = t[:, :, 0] + t[:, :, 1]
+    m = torch.arange(BM)
+    chunk = torch.arange(4)
+    pos = chunk[None, :] ^ ((m[:, None] >> 2) & 3)
+    un = t[:, :, m[:, None].expand(BM, 4), pos]                            # [ks][mblk][m][c][8]
+    un = un.reshape(kt * kh, nchunk, kw, M // BM, BM, 32).permute(3, 4, 0, 2, 1, 5)      # [mblk][m][trow][kx][chunk][32]
+    return un.reshape(M, kt * kh * kw * nchunk * 32)
+
+
 def unpack_conv_reference(packed: torch.Tensor, M: int, nk: int) -> torch.Tensor:
     """Inverse of the tiling/swizzle (hi + lo, fp32 [M][nk*32]); used by the host-logic tests."""
     t = packed.reshape(M // BM, nk, 2, BM, 4, 8).float()

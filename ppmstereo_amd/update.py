@@ -14,8 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .engine import PackedBlock, ScaleEngine, temporal_pe
-from .packing import pack_conv
+from .engine import PackedBlock, ScaleEngine, pack_conv, temporal_pe
 
 
 @torch.no_grad()

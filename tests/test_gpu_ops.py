@@ -71,10 +71,11 @@ def test_ops_refuse_cpu_tensors(lib):
 
 
 # ------------------------------------------------------------------------------------------------ conv GEMM
-def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None):
+def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0):
     """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
     from ppmstereo_amd.engine import ConvOp, epilogue
-    from ppmstereo_amd.packing import pack_conv
+    from ppmstereo_amd.packing import pack_conv as pack1, pack_conv2
+    pack_conv = pack_conv2 if version == 2 else pack1
     P = T * H * W
     segs, keep = [], []
     seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
@@ -106,7 +107,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     d.kt, d.kh, d.kw = k3
     d.M = d.m_split = meta["M"]
     d.epi[0] = e
-    ConvOp(d, keep)()
+    ConvOp(d, keep, version, wm)()
     torch.cuda.synchronize()
     sp = out.to_f32()[:, :cout].cpu()
     assert (sp - outf[:, :cout].cpu()).abs().max() < 2e-5 * (1 + sp.abs().max()), "SP and fp32 outputs of one launch disagree"
@@ -135,8 +136,12 @@ CONV_CASES = [
 ]
 
 
+CONV_CASES += [("wide_1x15", 1, 3, 300, [64], 128, (1, 1, 15)), ("w80_3x3", 2, 46, 80, [32], 64, (1, 3, 3)), ("w18_1x5", 2, 10, 18, [64, 32], 192, (1, 1, 5))]
+
+
+@pytest.mark.parametrize("version,wm", [(2, 0), (2, 1), (1, 0)])
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV_CASES)
-def test_conv_gemm_vs_torch(lib, name, T, H, W, segs, cout, k3):
+def test_conv_gemm_vs_torch(lib, name, T, H, W, segs, cout, k3, version, wm):
     P = T * H * W
     xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
     cin = sum(segs)
@@ -144,12 +149,16 @@ def test_conv_gemm_vs_torch(lib, name, T, H, W, segs, cout, k3):
     wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(fan)
     bs = hash_normal((cout,), 201) * 0.1
     ref = _ref_conv(xs, wt, bs, k3, T, H, W)
-    got = _run_conv(lib, xs, wt, bs, k3, T, H, W)
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=version, wm=wm)
     tol = 3e-5 * max(1.0, ref.abs().max().item())           # bf16x3 split: ~2^-16 relative per product, fp32 accumulate
     assert maxdiff(got, ref) < tol, name
 
 
-def test_conv_gemm_epilogues(lib):
+@pytest.mark.parametrize("version", [2, 1])
+def test_conv_gemm_epilogues(lib, version):
+    import functools
+    global _run_conv
+    run = functools.partial(_run_conv, version=version)
     T, H, W, cin, cout, k3 = 2, 6, 10, 64, 64, (1, 3, 3)
     P = T * H * W
     x = hash_normal((P, cin), 300)
@@ -159,14 +168,14 @@ def test_conv_gemm_epilogues(lib):
     z = torch.sigmoid(hash_normal((P, cout), 304))
     lin = _ref_conv([x], wt, bs, k3, T, H, W)
     L = lib
-    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, act=L.ACT_RELU), F.relu(lin)) < 5e-5
-    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, act=L.ACT_GELU), F.gelu(lin)) < 5e-5
-    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, act=L.ACT_SIGMOID), torch.sigmoid(lin)) < 5e-5
-    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, act=L.ACT_TANH), torch.tanh(lin)) < 5e-5
-    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, scale=0.25), 0.25 * lin) < 5e-5
-    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + lin)) < 5e-5
-    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RH, aux=aux), torch.sigmoid(lin) * aux) < 5e-5
-    assert maxdiff(_run_conv(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < 5e-5
+    assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, act=L.ACT_RELU), F.relu(lin)) < 5e-5
+    assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, act=L.ACT_GELU), F.gelu(lin)) < 5e-5
+    assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, act=L.ACT_SIGMOID), torch.sigmoid(lin)) < 5e-5
+    assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, act=L.ACT_TANH), torch.tanh(lin)) < 5e-5
+    assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, scale=0.25), 0.25 * lin) < 5e-5
+    assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + lin)) < 5e-5
+    assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RH, aux=aux), torch.sigmoid(lin) * aux) < 5e-5
+    assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < 5e-5
 
 
 def test_conv_gemm_rejects_bad_descriptors(lib):

@@ -7,15 +7,19 @@ import torch.nn.functional as F
 
 from oracle import ppm_oracle as O
 from ppmstereo_amd import weights as Wm
-from ppmstereo_amd.packing import BK, pack_conv, unpack_conv_reference
+from ppmstereo_amd.packing import BK, pack_conv, pack_conv2, unpack_conv2_reference, unpack_conv_reference
 from ppmstereo_amd.weights import hash_normal
 
 
 def emulate_kernel(packed, bias, meta, xs, seg_pad, T, H, W):
+    """(for the v2 layout the weight matrix is first brought back to the v1 K order)"""
     """What conv_gemm.hip computes, restated with torch on the CPU from the PACKED weights: K order
     k = tap*Cpad + ci, tap = (kz*kh + ky)*kw + kx, shifted zero-padded pixel rows."""
     kt, kh, kw = meta["taps"]
-    Wm_ = unpack_conv_reference(packed.cpu(), meta["M"], meta["nk"])            # [M][K]
+    if meta.get("version") == 2:
+        Wm_ = unpack_conv2_reference(packed.cpu(), meta["M"], meta["nk"], meta["taps"], meta["cpad"] // BK)
+    else:
+        Wm_ = unpack_conv_reference(packed.cpu(), meta["M"], meta["nk"])        # [M][K]
     P = T * H * W
     cols = []
     xp = []
@@ -39,7 +43,8 @@ def emulate_kernel(packed, bias, meta, xs, seg_pad, T, H, W):
 
 @pytest.mark.parametrize("segs,cout,k3", [([36], 54, (1, 1, 1)), ([128, 384], 256, (1, 1, 15)), ([128, 64], 128, (5, 1, 1)),
                                           ([128], 190, (3, 3, 3)), ([320], 190, (1, 3, 3))])
-def test_packing_reproduces_the_convolution(segs, cout, k3):
+@pytest.mark.parametrize("packer", [pack_conv, pack_conv2])
+def test_packing_reproduces_the_convolution(segs, cout, k3, packer):
     T, H, W = 3, 4, 6
     P = T * H * W
     cin = sum(segs)
@@ -47,7 +52,7 @@ def test_packing_reproduces_the_convolution(segs, cout, k3):
     wt = hash_normal((cout, cin, *k3), 20) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
     bs = hash_normal((cout,), 21)
     seg_pad = [((c + 31) // 32) * 32 for c in segs]
-    packed, bias, meta = pack_conv(wt, bs, segs, seg_pad)
+    packed, bias, meta = packer(wt, bs, segs, seg_pad)
     assert packed.dtype == torch.bfloat16 and packed.numel() == 2 * meta["M"] * meta["nk"] * BK
     got = emulate_kernel(packed, bias, meta, xs, seg_pad, T, H, W)[:, :cout]
     x5 = torch.cat(xs, 1).reshape(1, T, H, W, cin).permute(0, 4, 1, 2, 3)
