@@ -31,6 +31,7 @@ struct Geo2 {
     int nchunk, n0;          // 32-channel chunks per tap (all segments), chunks of segment 0
     int nk;                  // k-steps = kt*kh*nchunk*kw
     int mgroups;             // M / (64*WM)
+    int bstages;             // 2: window double-buffered; 1: single window + one extra barrier per window switch
 };
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -193,11 +194,18 @@ __global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __rest
         }
         if (more) {
             store_a((ks + 1) & 1);
-            if (need_b) store_b(bsel ^ 1);
+            if (need_b) {
+                if (g.bstages == 1) {
+                    __syncthreads();          // every wave is done sweeping the single window before it is replaced
+                    store_b(0);
+                } else {
+                    store_b(bsel ^ 1);
+                }
+            }
         }
         __syncthreads();
         if (need_b) {
-            bsel ^= 1;
+            bsel = (g.bstages == 1) ? 0 : (bsel ^ 1);
             kx = 0;
         } else {
             ++kx;
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __rest
 
 template <int WM>
 int launch2(const ppms_conv* d, const ppms_conv* dev_desc, const Geo2& g, int ntiles, hipStream_t stream) {
-    const size_t lds = (size_t)2 * WM * A_BLK + (size_t)2 * 2 * g.Wr * 64;
+    const size_t lds = (size_t)2 * WM * A_BLK + (size_t)g.bstages * 2 * g.Wr * 64;
     static size_t lds_set = 0;
     if (lds > lds_set) {
         (void)hipFuncSetAttribute((const void*)conv2_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -305,14 +313,19 @@ extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, in
     const int mblocks = d->M / 64;
     int wm = wm_hint;
     if (wm <= 0) {
-        wm = mblocks <= 4 ? mblocks : 4;
+        // <= 3 cout blocks: one group; 4 blocks (M = 256): two 128-cout groups (measured 8 % faster than one 8-wave group)
+        wm = mblocks <= 3 ? mblocks : 2;
+        if (mblocks % wm) wm = 1;
         if (ntiles < 160 && mblocks > 1) wm = 1;          // small maps: spread cout blocks over more workgroups
     }
     PPMS_REQUIRE(wm >= 1 && wm <= 4 && mblocks % wm == 0, "conv_gemm2: wm=%d does not divide M/64=%d", wm, mblocks);
     g.mgroups = mblocks / wm;
+    // kw > 1: the window changes every kw-th k-step -> keep ONE copy (extra barrier per switch) so that three 4-wave
+    // workgroups fit a CU's LDS; kw == 1: it changes every k-step -> double-buffer it
+    g.bstages = (d->kw == 1) ? 2 : 1;
     const int maxslot = wm == 4 ? 2 : wm == 3 ? 3 : wm == 2 ? 4 : 8;
     PPMS_REQUIRE(g.Wr * 4 <= 128 * wm * maxslot, "conv_gemm2: window of %d rows does not fit the staging slots", g.Wr);
-    PPMS_REQUIRE(2 * wm * A_BLK + 4 * g.Wr * 64 <= 160 * 1024, "conv_gemm2: LDS budget exceeded");
+    PPMS_REQUIRE(2 * wm * A_BLK + g.bstages * 2 * g.Wr * 64 <= 160 * 1024, "conv_gemm2: LDS budget exceeded");
     hipStream_t st = (hipStream_t)stream;
     switch (wm) {
         case 1: return launch2<1>(d, dev_desc, g, ntiles, st);

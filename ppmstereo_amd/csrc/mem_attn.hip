@@ -9,6 +9,7 @@
 // to_v conv epilogue) so both MFMA operands are plain 8/16-byte LDS reads.  K rows are XOR-swizzled on 16-B chunks,
 // V^T rows on 8-B granules: all fragment reads are bank-conflict free.  Two LDS stages, register-staged prefetch.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -30,6 +31,8 @@ __device__ __forceinline__ u32x4 load16_guard(const bf16_t* row, int e0, int lim
     return v;
 }
 
+// TAIL = (n % 64 != 0): only that instantiation carries the per-key masking of a frame's last tile
+template <bool TAIL>
 __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
                                                           const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
                                                           float scale_log2, const float* __restrict__ beta_p, ppms_sp mf, ppms_sp mfg,
@@ -89,23 +92,24 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // V^T row d holds 64 keys as 4 groups of 16; inside a group the keys are stored [0-3, 8-11 | 4-7, 12-15] so
+            // that lane half h of the PV MFMA reads its 8 keys (4h..4h+3, 8+4h..8+4h+3) as ONE 16-byte chunk.
+            // This thread holds keys 8e..8e+7 of group G: the low 8 bytes go to chunk 2G, the high 8 bytes to chunk 2G+1,
+            // both at byte 8e.  Chunks are XOR-swizzled by (d>>1)&7: conflict-free for ds_read_b128.
             const int d = (tid >> 3) + 32 * i;
-            const int f = (d >> 1) & 15;
-            u32x4 v = rv[i];
-            if (f & 1) v = (u32x4){v[2], v[3], v[0], v[1]};     // the 8-B granule swizzle swaps the halves of a chunk
-            *(u32x4*)(vs + d * 128 + (((tid & 7) ^ (f >> 1)) << 4)) = v;
+            const int G = (tid & 7) >> 1, e = tid & 1;
+            const int f = (d >> 1) & 7;
+            typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+            const u32x4 v = rv[i];
+            *(u32x2*)(vs + d * 128 + (((2 * G) ^ f) << 4) + 8 * e) = (u32x2){v[0], v[1]};
+            *(u32x2*)(vs + d * 128 + (((2 * G + 1) ^ f) << 4) + 8 * e) = (u32x2){v[2], v[3]};
         }
     };
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int it = 0; it < ntile; ++it) {
-        const bool more = it + 1 < ntile;
-        if (more) load_tile(it + 1);
-        const char* ks = smem + (it & 1) * ATT_STAGE;
-        const char* vs = ks + K_TILE;
-
+    // one KV tile; MASKED is only instantiated for the last tile of a frame when n % 64 != 0, so the steady-state
+    // loop carries no per-key compare/select work (the softmax VALU stream, not the MFMA pipe, is the critical path:
+    // every v_cndmask / range fix-up removed here is ~1 % of the kernel)
+    auto process_tile = [&](const char* ks, const char* vs, int key0) {
         // ---- S^T[key][query] = K Q^T ---------------------------------------------------------------
         f32x16 st[2];
         st[0] = (f32x16){0};
@@ -119,9 +123,7 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
                 st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kblk], 0, 0, 0);
             }
         }
-        // ---- mask keys beyond the frame (last tile of a frame when n % 64 != 0) -----------------------
-        const int key0 = (it % tpf) * KT;
-        if (key0 + KT > n) {
+        if (TAIL && key0 + KT > n) {
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
@@ -138,20 +140,27 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
             for (int g = 0; g < 16; ++g) mx = fmaxf(mx, st[kblk][g]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx * scale_log2);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        // rescale O and l only when some query of the wave raised its running max (wave-uniform branch); NaN scores
+        // (T == 1) must still poison the output, hence the unordered compare
+        if (__any(!(m_new <= m_run))) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] *= alpha;
+            m_run = m_new;
+        }
+        const float neg_m = -m_run;
         float psum = 0.0f;
 #pragma unroll
         for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                const float p = exp2f(st[kblk][g] * scale_log2 - m_new);
+                // raw v_exp_f32: arguments are <= 0, results in [0,1]; values below 2^-126 flush to 0 (irrelevant for P)
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kblk][g], scale_log2, neg_m));
                 st[kblk][g] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+        l_run += psum;
 
         // ---- O^T[d][query] += V^T P^T ; P^T fragments come straight from the S^T accumulators -------------
 #pragma unroll
@@ -161,23 +170,27 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
                 bf16x8 pf;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kblk][8 * s2 + j];
-                const int g1 = kblk * 8 + 4 * s2 + h;          // 8-B granule of keys 16 s2 + 4 h .. +3 ; +2 granules: keys +8
+                const int chunk = (kblk * 2 + s2) * 2 + h;
 #pragma unroll
                 for (int dblk = 0; dblk < 4; ++dblk) {
                     const int d = dblk * 32 + r;
-                    const int f = (d >> 1) & 15;
-                    const bf16x4 v0 = *(const bf16x4*)(vs + d * 128 + ((g1 ^ f) << 3));
-                    const bf16x4 v1 = *(const bf16x4*)(vs + d * 128 + (((g1 + 2) ^ f) << 3));
-                    bf16x8 vf;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        vf[j] = v0[j];
-                        vf[4 + j] = v1[j];
-                    }
+                    const bf16x8 vf = *(const bf16x8*)(vs + d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4));
                     o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dblk], 0, 0, 0);
                 }
             }
         }
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int it = 0; it < ntile; ++it) {
+        const bool more = it + 1 < ntile;
+        if (more) load_tile(it + 1);
+        const char* ks = smem + (it & 1) * ATT_STAGE;
+        const char* vs = ks + K_TILE;
+        const int key0 = (it % tpf) * KT;
+        process_tile(ks, vs, key0);
         if (more) store_tile((it + 1) & 1);
         __syncthreads();
     }
@@ -225,12 +238,17 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
     PPMS_REQUIRE(mf.hi && mf.lo && mfg.hi && mfg.lo && mf.ld % 4 == 0 && mfg.ld % 4 == 0, "mem_attn: mf / mfg must be 8-B aligned SP views");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)mem_attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)mem_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)mem_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         attr_set = true;
     }
     const float scale_log2 = scale * 1.4426950408889634f;
     dim3 grid(ceil_div(n, QW * NW), T);
-    hipLaunchKernelGGL(mem_attn_kernel, grid, dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, (const bf16_t*)qb, (const bf16_t*)kb,
-                       (const bf16_t*)vt, sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n);
+    if (n % KT)
+        hipLaunchKernelGGL(mem_attn_kernel<true>, grid, dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, (const bf16_t*)qb, (const bf16_t*)kb,
+                           (const bf16_t*)vt, sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n);
+    else
+        hipLaunchKernelGGL(mem_attn_kernel<false>, grid, dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, (const bf16_t*)qb, (const bf16_t*)kb,
+                           (const bf16_t*)vt, sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n);
     return ppms_check_launch("mem_attn");
 }
