@@ -279,6 +279,38 @@ extern "C" int ppms_sp_to_f32(ppms_sp src, float* dst, int dst_ld, int64_t pixel
     return ppms_check_launch("sp_to_f32");
 }
 
+// ------------------------------------------------------------------------------------------------ tap gather-sum
+// Tail of a conv with very few output channels computed as a 1x1 GEMM to (taps x cout) channels:
+//   out[p][c] = bias[c] + sum_tap y[p + d(tap)][tap*cout + c],  d(tap) = (kz - kt/2, ky - kh/2, kx - kw/2), zero outside.
+// Used for FlowHead3D.conv2 (256 -> 2, 3x3x3, ppmtereo_update.py:674): 8 GEMM k-steps instead of 216.
+__global__ __launch_bounds__(256) void tap_gather_sum_kernel(const float* __restrict__ y, int y_ld, const float* __restrict__ bias,
+                                                             float* __restrict__ out, int out_ld, int cout, int kt, int kh, int kw, int T,
+                                                             int H, int W, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cout);
+    const int64_t pix = idx / cout;
+    const int x = (int)(pix % W), yy = (int)((pix / W) % H), t = (int)(pix / ((int64_t)W * H));
+    float acc = bias ? bias[c] : 0.0f;
+    int tap = 0;
+    for (int kz = 0; kz < kt; ++kz)
+        for (int ky = 0; ky < kh; ++ky)
+            for (int kx = 0; kx < kw; ++kx, ++tap) {
+                const int tt = t + kz - kt / 2, y2 = yy + ky - kh / 2, x2 = x + kx - kw / 2;
+                if ((unsigned)tt < (unsigned)T && (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
+                    acc += y[(((int64_t)tt * H + y2) * W + x2) * y_ld + tap * cout + c];
+            }
+    out[pix * out_ld + c] = acc;
+}
+extern "C" int ppms_tap_gather_sum(const float* y, int y_ld, const float* bias, float* out, int out_ld, int cout, int kt, int kh, int kw,
+                                   int T, int H, int W, void* stream) {
+    PPMS_REQUIRE(y && out && cout > 0 && kt * kh * kw * cout <= y_ld && out_ld >= cout, "tap_gather_sum: bad arguments");
+    const int64_t total = (int64_t)T * H * W * cout;
+    hipLaunchKernelGGL(tap_gather_sum_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, y, y_ld, bias, out, out_ld, cout,
+                       kt, kh, kw, T, H, W, total);
+    return ppms_check_launch("tap_gather_sum");
+}
+
 // ------------------------------------------------------------------------------------------------ flow += delta_flow
 __global__ __launch_bounds__(256) void flow_add_kernel(float* __restrict__ flow, const float* __restrict__ dflow, int dflow_ld, int64_t P) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -135,7 +135,10 @@ class PackedBlock:
             put("zr" + n, cat(gr + f"convz{n}.weight", gr + f"convr{n}.weight"), cat(gr + f"convz{n}.bias", gr + f"convr{n}.bias"), [128, 384])
             put("q" + n, g(gr + f"convq{n}.weight"), g(gr + f"convq{n}.bias"), [128, 384])
         put("fh1", g("flow_head.conv1.weight"), g("flow_head.conv1.bias"), [128])
-        put("fh2", g("flow_head.conv2.weight"), g("flow_head.conv2.bias"), [256])
+        # flow_head.conv2 (256 -> 2, 3x3x3) as a 1x1 GEMM to 27*2 = 54 channels + shifted sum (ppms_tap_gather_sum)
+        w2 = g("flow_head.conv2.weight")                                     # (2, 256, 3, 3, 3)
+        put("fh2", w2.permute(2, 3, 4, 0, 1).reshape(54, 256, 1, 1, 1).contiguous(), None, [256])
+        self.fh2_bias = g("flow_head.conv2.bias").contiguous()
         put("m1", g("mask_2d.0.weight"), g("mask_2d.0.bias"), [128])
         put("m2", g("mask_2d.2.weight"), g("mask_2d.2.bias"), [256])
         self.beta = g("aggregator.beta").contiguous()
@@ -167,6 +170,7 @@ class ScaleEngine:
         self.ZT, self.RT, self.RH, self.FH1, self.M1 = sp(128), sp(128), sp(128), sp(256), sp(256)
         self.Z, self.MASK, self.FLOW, self.QK = f32(P, 128), f32(P, 144), f32(P, 2), f32(P, 256)
         self.DFLOW = f32(P, 4)
+        self.FH2Y = f32(P, 64)
         self.VT = torch.zeros(T, 128, self.n, dtype=torch.bfloat16, device=device)
         self.QB = torch.zeros(T, self.n, 128, dtype=torch.bfloat16, device=device)
         self.KB = torch.zeros(T, self.ksel, self.n, 128, dtype=torch.bfloat16, device=device)
@@ -242,7 +246,7 @@ class ScaleEngine:
             o["q" + n] = self._conv("q" + n, [self.RH.view(), x_all], kk,
                                     E(L.EPI_GRU, n_valid=128, out_sp=H[dst].view(), aux_sp=H[src].view(), aux_f32=self.Z, aux_f32_ld=128))
         o["fh1"] = self._conv("fh1", [H[0].view()], (3, 3, 3), E(act=L.ACT_RELU, n_valid=256, out_sp=self.FH1.view()))
-        o["fh2"] = self._conv("fh2", [self.FH1.view()], (3, 3, 3), E(n_valid=2, out_f32=self.DFLOW, out_f32_ld=4))
+        o["fh2"] = self._conv("fh2", [self.FH1.view()], k1, E(n_valid=54, out_f32=self.FH2Y, out_f32_ld=64))
         o["m1"] = self._conv("m1", [H[0].view()], k3, E(act=L.ACT_RELU, n_valid=256, out_sp=self.M1.view()))
         o["m2"] = self._conv("m2", [self.M1.view()], k1, E(scale=0.25, n_valid=144, out_f32=self.MASK, out_f32_ld=144))
 
@@ -407,6 +411,8 @@ class ScaleEngine:
             self.block16_attention()
         for k in ("zr1_0", "z1_2", "r1_2", "q1", "zr2", "q2", "zr3", "q3", "fh1", "fh2"):
             o[k]()
+        L.check(self.lib.ppms_tap_gather_sum(self.FH2Y.data_ptr(), 64, self.pk.fh2_bias.data_ptr(), self.DFLOW.data_ptr(), 4, 2, 3, 3, 3,
+                                             self.T, self.h, self.w, self._s()))
         L.check(self.lib.ppms_flow_add(self.FLOW.data_ptr(), self.DFLOW.data_ptr(), 4, self.P, self._s()))   # ppmstereo.py:571
         o["m1"]()
         o["m2"]()
