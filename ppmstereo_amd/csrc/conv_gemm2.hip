@@ -36,13 +36,19 @@ struct Geo2 {
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
-template <int WM>
-__global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __restrict__ pd, const Geo2 g) {
-    constexpr int NT = 128 * WM;
+// KG > 1: intra-workgroup split-K for small maps (too few tiles to fill 256 CUs): KG wave groups, each with its own
+// LDS stages, take the (dt, dy, chunk) row-steps kg, kg+KG, ... of the SAME output tile, so KG k-step pipelines run
+// concurrently in one workgroup; partial accumulators are summed through LDS in fixed order (deterministic) and wave
+// group 0 runs the epilogue.
+template <int WM, int KG>
+__global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* __restrict__ pd, const Geo2 g) {
+    constexpr int NT = 128 * WM;              // threads of one K-group
     constexpr int MAXSLOT = (WM == 4) ? 2 : (WM == 3) ? 3 : (WM == 2) ? 4 : 8;      // window 16-B chunks per thread and plane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ppms_conv& p = *pd;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kg = (KG > 1) ? (int)threadIdx.x / NT : 0;
+    const int tid = (KG > 1) ? (int)threadIdx.x % NT : (int)threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const int mgrp = blockIdx.x % g.mgroups;
@@ -56,9 +62,9 @@ __global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __rest
     const int HW = H * W;
     const int hx = p.kw >> 1, hy = p.kh >> 1, ht = p.kt >> 1;
 
-    char* sA = smem;                                       // 2 stages x WM x 8 KiB
     const int bplane = g.Wr * 64;
-    char* sB = smem + 2 * WM * A_BLK;                      // 2 stages x 2 planes x Wr x 64 B
+    char* sA = smem + kg * (2 * WM * A_BLK + g.bstages * 2 * bplane);      // this K-group's stages: 2 x WM x 8 KiB weights,
+    char* sB = sA + 2 * WM * A_BLK;                                        // then bstages x 2 planes x Wr x 64 B window
 
     // ---- window slots of this thread (fixed for the whole kernel) ------------------------------------------
     int sl_off[MAXSLOT];          // pixel offset (t*H + y)*W + x of the slot at (dt, dy) = 0, or -1: x outside the image
@@ -148,31 +154,31 @@ __global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __rest
     // (T = 5: 24 % of the (5,1,1) GRU pass, 13 % of the 3x3x3 flow head).  Valid kz form one contiguous range.
     const int kz0 = (ht - tf) > 0 ? (ht - tf) : 0;
     const int kz1 = (ht + T - 1 - tf) < (p.kt - 1) ? (ht + T - 1 - tf) : (p.kt - 1);
-    const int per_kz = p.kh * g.nchunk * p.kw;
-    const int ks0 = kz0 * per_kz, ks1 = (kz1 + 1) * per_kz;
-    int l_trow = kz0 * p.kh, l_chunk = 0, l_kx = 0;
-    load_a(ks0);
-    load_b(l_trow, 0);
-    store_a(ks0 & 1);
+    const int rs_per_kz = p.kh * g.nchunk;
+    const int rs_end = (kz1 + 1) * rs_per_kz;
+    int rs = kz0 * rs_per_kz + kg;            // row-step = trow * nchunk + chunk; this K-group takes every KG-th one
+    const int nsteps = ((rs_end - kz0 * rs_per_kz) / KG) * p.kw;     // identical for every K-group (nchunk % KG == 0)
+    {
+        const int trow = rs / g.nchunk;
+        load_a(rs * p.kw);
+        load_b(trow, rs - trow * g.nchunk);
+    }
+    store_a(0);
     store_b(0);
     __syncthreads();
     int bsel = 0, kx = 0;
-    for (int ks = ks0; ks < ks1; ++ks) {
-        const bool more = ks + 1 < ks1;
-        bool need_b = false;
+    for (int j = 0; j < nsteps; ++j) {
+        const bool more = j + 1 < nsteps;
+        const bool need_b = more && (kx + 1 == p.kw);
         if (more) {
-            if (++l_kx == p.kw) {
-                l_kx = 0;
-                need_b = true;
-                if (++l_chunk == g.nchunk) {
-                    l_chunk = 0;
-                    ++l_trow;
-                }
+            const int nrs = need_b ? rs + KG : rs;
+            load_a(nrs * p.kw + (need_b ? 0 : kx + 1));
+            if (need_b) {
+                const int trow = nrs / g.nchunk;
+                load_b(trow, nrs - trow * g.nchunk);
             }
-            load_a(ks + 1);
-            if (need_b) load_b(l_trow, l_chunk);
         }
-        const char* a_s = sA + (ks & 1) * WM * A_BLK + wm * A_BLK;
+        const char* a_s = sA + (j & 1) * WM * A_BLK + wm * A_BLK;
         const char* b_s = sB + bsel * 2 * bplane;
 #pragma unroll
         for (int k16 = 0; k16 < 2; ++k16) {
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __rest
                 }
         }
         if (more) {
-            store_a((ks + 1) & 1);
+            store_a((j + 1) & 1);
             if (need_b) {
                 if (g.bstages == 1) {
                     __syncthreads();          // every wave is done sweeping the single window before it is replaced
@@ -213,8 +219,42 @@ __global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __rest
         if (need_b) {
             bsel = (g.bstages == 1) ? 0 : (bsel ^ 1);
             kx = 0;
+            rs += KG;
         } else {
             ++kx;
+        }
+    }
+
+    // ---- intra-workgroup split-K: fixed-order sum of the K-groups' partial tiles through LDS ----------------------
+    if (KG > 1) {
+        // (the loop's last barrier guarantees nobody still reads the staging area that is reused here)
+        float* red = (float*)smem;
+        const int slot = ((kg - 1) * 2 * WM + wave) * 64 * 64;              // 64 regs x 64 lanes per wave
+        if (kg > 0) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v4 = {acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]};
+                        *(f32x4*)(red + slot + (((mb * 2 + nb) * 4 + q) * 64 + lane) * 4) = v4;
+                    }
+        }
+        __syncthreads();
+        if (kg > 0) return;
+        for (int k = 1; k < KG; ++k) {
+            const int src = ((k - 1) * 2 * WM + wave) * 64 * 64;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v4 = *(const f32x4*)(red + src + (((mb * 2 + nb) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] += v4[e];
+                    }
         }
     }
 
@@ -250,15 +290,21 @@ __global__ __launch_bounds__(128 * WM) void conv2_kernel(const ppms_conv* __rest
     }
 }
 
-template <int WM>
+template <int WM, int KG>
 int launch2(const ppms_conv* d, const ppms_conv* dev_desc, const Geo2& g, int ntiles, hipStream_t stream) {
-    const size_t lds = (size_t)2 * WM * A_BLK + (size_t)g.bstages * 2 * g.Wr * 64;
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute((const void*)conv2_kernel<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        lds_set = 160 * 1024;
+    size_t lds = (size_t)KG * ((size_t)2 * WM * A_BLK + (size_t)g.bstages * 2 * g.Wr * 64);
+    const size_t red = (size_t)(KG - 1) * 2 * WM * 64 * 64 * 4;          // partial-accumulator exchange reuses the staging area
+    if (red > lds) lds = red;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv2_kernel<WM, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
     }
-    hipLaunchKernelGGL(conv2_kernel<WM>, dim3(ntiles * g.mgroups), dim3(128 * WM), lds, stream, dev_desc, g);
+    if (lds > 160 * 1024) {
+        ppms_set_error("conv_gemm2: LDS budget exceeded (%zu B)", lds);
+        return PPMS_EINVAL;
+    }
+    hipLaunchKernelGGL((conv2_kernel<WM, KG>), dim3(ntiles * g.mgroups), dim3(128 * WM * KG), lds, stream, dev_desc, g);
     return ppms_check_launch("conv_gemm2");
 }
 
@@ -333,10 +379,20 @@ extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, in
     PPMS_REQUIRE(g.Wr * 4 <= 128 * wm * maxslot, "conv_gemm2: window of %d rows does not fit the staging slots", g.Wr);
     PPMS_REQUIRE(2 * wm * A_BLK + g.bstages * 2 * g.Wr * 64 <= 160 * 1024, "conv_gemm2: LDS budget exceeded");
     hipStream_t st = (hipStream_t)stream;
+    // small maps: split K inside the workgroup so that more waves work on the few tiles there are
+    const int nwg = ntiles * g.mgroups;
+    int kgs = 1;
+    if (wm == 1 && wm_hint <= 0) {
+        if (nwg <= 128 && nchunk % 4 == 0) kgs = 4;
+        else if (nwg <= 320 && nchunk % 2 == 0) kgs = 2;
+    }
+    if (kgs > 1) g.bstages = 1;                // K-groups keep ONE window copy each (LDS budget), at one more barrier per window
+    if (kgs == 4) return launch2<1, 4>(d, dev_desc, g, ntiles, st);
+    if (kgs == 2) return launch2<1, 2>(d, dev_desc, g, ntiles, st);
     switch (wm) {
-        case 1: return launch2<1>(d, dev_desc, g, ntiles, st);
-        case 2: return launch2<2>(d, dev_desc, g, ntiles, st);
-        case 3: return launch2<3>(d, dev_desc, g, ntiles, st);
-        default: return launch2<4>(d, dev_desc, g, ntiles, st);
+        case 1: return launch2<1, 1>(d, dev_desc, g, ntiles, st);
+        case 2: return launch2<2, 1>(d, dev_desc, g, ntiles, st);
+        case 3: return launch2<3, 1>(d, dev_desc, g, ntiles, st);
+        default: return launch2<4, 1>(d, dev_desc, g, ntiles, st);
     }
 }
