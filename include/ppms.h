@@ -150,7 +150,10 @@ int ppms_attn_prep_k(const float* key, int ld, const float* pe, const int32_t* s
  * qb: bf16 [T][n][128]; kb: bf16 [T][ksel][n][128]; vt: bf16 [T][128][n] (per-frame transposed values, picked through
  * sel); mf / mfg: SP views (128 channels).  out_bf16 (optional): bf16 [T][n][128] raw attention output. */
 int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
-                  ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* stream);
+                  ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, void* stream);
+/* split_ws (optional, caller-owned, ppms_mem_attn_workspace_bytes(T, ksel, n) bytes): when given, the picked frames are
+ * processed by separate workgroups (ksel x more, smaller work units) and merged by a combine kernel; NULL = fused. */
+int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
 
 #ifdef __cplusplus
 }

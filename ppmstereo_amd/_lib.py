@@ -61,7 +61,8 @@ _SIGS = {
     "ppms_qam_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppms_attn_prep_q": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_attn_prep_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p]),
+    "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ppms_mem_attn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
 }
 EXPORTS = tuple(_SIGS)
 

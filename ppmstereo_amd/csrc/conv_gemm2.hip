@@ -384,7 +384,7 @@ extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, in
     int kgs = 1;
     if (wm == 1 && wm_hint <= 0) {
         if (nwg <= 128 && nchunk % 4 == 0) kgs = 4;
-        else if (nwg <= 320 && nchunk % 2 == 0) kgs = 2;
+        else if (nwg <= 512 && nchunk % 2 == 0) kgs = 2;   // ~68 KiB of LDS each: two such workgroups share a CU
     }
     if (kgs > 1) g.bstages = 1;                // K-groups keep ONE window copy each (LDS budget), at one more barrier per window
     if (kgs == 4) return launch2<1, 4>(d, dev_desc, g, ntiles, st);

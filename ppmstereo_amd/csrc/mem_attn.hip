@@ -36,7 +36,8 @@ template <bool TAIL>
 __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
                                                           const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
                                                           float scale_log2, const float* __restrict__ beta_p, ppms_sp mf, ppms_sp mfg,
-                                                          bf16_t* __restrict__ out_bf16, int n) {
+                                                          bf16_t* __restrict__ out_bf16, int n, float* __restrict__ part_o,
+                                                          float* __restrict__ part_ml) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -60,7 +61,13 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
     float m_run = -INFINITY, l_run = 0.0f;
 
     const int tpf = (n + KT - 1) / KT;           // tiles per frame
-    const int ntile = ksel * tpf;
+    // split mode (part_o != null): gridDim.z = ksel, this workgroup reads ONE picked frame and writes unnormalised
+    // partials; a combine kernel merges them (more, smaller work units: 400 -> 2000 at 320x512, and the small scales
+    // get ksel x the parallelism)
+    const int nsplit = gridDim.z;
+    const int slot0 = (nsplit > 1) ? (int)blockIdx.z : 0;
+    const int it0 = slot0 * tpf;
+    const int ntile = (nsplit > 1) ? it0 + tpf : ksel * tpf;
 
     u32x4 rk[4], rv[4];
     auto load_tile = [&](int it) {
@@ -181,10 +188,10 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
         }
     };
 
-    load_tile(0);
-    store_tile(0);
+    load_tile(it0);
+    store_tile(it0 & 1);
     __syncthreads();
-    for (int it = 0; it < ntile; ++it) {
+    for (int it = it0; it < ntile; ++it) {
         const bool more = it + 1 < ntile;
         if (more) load_tile(it + 1);
         const char* ks = smem + (it & 1) * ATT_STAGE;
@@ -198,6 +205,22 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
     // ---- epilogue: hid = bf16(O / l); mfg = mf + beta * hid ---------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     if (qi >= n) return;
+    if (part_o != nullptr) {
+        const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
+        float* po = part_o + row * D;
+#pragma unroll
+        for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v4 = {o[dblk][4 * g], o[dblk][4 * g + 1], o[dblk][4 * g + 2], o[dblk][4 * g + 3]};
+                *(f32x4*)(po + dblk * 32 + 8 * g + 4 * h) = v4;
+            }
+        if (h == 0) {
+            part_ml[row * 2] = m_run;
+            part_ml[row * 2 + 1] = l_tot;
+        }
+        return;
+    }
     const float inv_l = 1.0f / l_tot;
     const float beta = beta_p[0];
     const int64_t pix = (int64_t)clip * n + qi;
@@ -229,13 +252,57 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
         }
 }
 
+// merges the per-frame partials of split mode: O = sum_s O_s 2^(m_s - m), l = sum_s l_s 2^(m_s - m); then the same
+// epilogue as the fused kernel (hid = bf16(O / l), mfg = mf + beta * hid).  One thread = one query x 8 channels.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int nsplit,
+                                                           const float* __restrict__ beta_p, ppms_sp mf, ppms_sp mfg,
+                                                           bf16_t* __restrict__ out_bf16, int n, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int g8 = (int)(idx & 15);
+    const int64_t pix = idx >> 4;                       // clip * n + query
+    const int64_t clip = pix / n;
+    const int64_t q = pix - clip * n;
+    float m = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) m = fmaxf(m, part_ml[(((clip * nsplit + s) * n) + q) * 2]);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, l = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+        const int64_t row = (clip * nsplit + s) * n + q;
+        const float ms = part_ml[row * 2];
+        const float wgt = (ms == m) ? 1.0f : __builtin_amdgcn_exp2f(ms - m);      // NaN partials (T == 1) stay NaN
+        l += part_ml[row * 2 + 1] * wgt;
+        const f32x4 a = *(const f32x4*)(part_o + row * D + g8 * 8), b = *(const f32x4*)(part_o + row * D + g8 * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[j] += a[j] * wgt;
+            acc[4 + j] += b[j] * wgt;
+        }
+    }
+    const float inv_l = 1.0f / l, beta = beta_p[0];
+    const int d = g8 * 8;
+    const bf16x8 mh = *(const bf16x8*)((const bf16_t*)mf.hi + pix * mf.ld + d), ml = *(const bf16x8*)((const bf16_t*)mf.lo + pix * mf.ld + d);
+    bf16x8 hid, oh, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        hid[j] = (bf16_t)(acc[j] * inv_l);
+        const float y = join_bf16(mh[j], ml[j]) + beta * (float)hid[j];
+        bf16_t hh, ll;
+        split_bf16(y, hh, ll);
+        oh[j] = hh;
+        ol[j] = ll;
+    }
+    if (out_bf16) *(bf16x8*)(out_bf16 + pix * D + d) = hid;
+    *(bf16x8*)((bf16_t*)mfg.hi + pix * mfg.ld + d) = oh;
+    *(bf16x8*)((bf16_t*)mfg.lo + pix * mfg.ld + d) = ol;
+}
+
 }  // namespace
 
 extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
-                             ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* stream) {
+                             ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, void* stream) {
     PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
     PPMS_REQUIRE(ksel >= 1 && ksel <= 5 && T >= 1 && n >= 1, "mem_attn: bad sizes ksel=%d T=%d n=%d", ksel, T, n);
-    PPMS_REQUIRE(mf.hi && mf.lo && mfg.hi && mfg.lo && mf.ld % 4 == 0 && mfg.ld % 4 == 0, "mem_attn: mf / mfg must be 8-B aligned SP views");
+    PPMS_REQUIRE(mf.hi && mf.lo && mfg.hi && mfg.lo && mf.ld % 8 == 0 && mfg.ld % 8 == 0, "mem_attn: mf / mfg must be 16-B aligned SP views");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)mem_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
@@ -243,12 +310,24 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         attr_set = true;
     }
     const float scale_log2 = scale * 1.4426950408889634f;
-    dim3 grid(ceil_div(n, QW * NW), T);
+    // split over the picked frames when a workspace is given (ppms_mem_attn_workspace_bytes) and there is more than one
+    const bool split = split_ws != nullptr && ksel > 1;
+    float* part_o = split ? (float*)split_ws : nullptr;
+    float* part_ml = split ? part_o + (size_t)T * ksel * n * D : nullptr;
+    dim3 grid(ceil_div(n, QW * NW), T, split ? ksel : 1);
+    hipStream_t st = (hipStream_t)stream;
     if (n % KT)
-        hipLaunchKernelGGL(mem_attn_kernel<true>, grid, dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, (const bf16_t*)qb, (const bf16_t*)kb,
-                           (const bf16_t*)vt, sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n);
+        hipLaunchKernelGGL(mem_attn_kernel<true>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt, sel,
+                           ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml);
     else
-        hipLaunchKernelGGL(mem_attn_kernel<false>, grid, dim3(256), 2 * ATT_STAGE, (hipStream_t)stream, (const bf16_t*)qb, (const bf16_t*)kb,
-                           (const bf16_t*)vt, sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n);
+        hipLaunchKernelGGL(mem_attn_kernel<false>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt, sel,
+                           ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml);
+    if (split) {
+        const int64_t total = (int64_t)T * n * 16;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, part_o, part_ml, ksel, beta, mf, mfg,
+                           (bf16_t*)out_bf16, n, total);
+    }
     return ppms_check_launch("mem_attn");
 }
+
+extern "C" int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n) { return (int64_t)T * ksel * n * (D + 2) * 4; }

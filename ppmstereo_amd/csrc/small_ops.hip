@@ -45,20 +45,27 @@ extern "C" int ppms_device_info(char* name, int name_cap, int* cu_count, int* cl
 
 // ------------------------------------------------------------------------------------------------ depthwise conv
 // y = gelu(x + dw_k(x) + b), PCBlock4_Deep_nopool_res.forward (ppmtereo_update.py:1026-1027)
+// one thread = one pixel x 8 channels: 16-byte loads of the hi and lo planes per tap (channel-last rows are contiguous)
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_gelu_kernel(ppms_sp x, ppms_sp y, const float* __restrict__ w, const float* __restrict__ b,
-                                                          int H, int W, int64_t P) {
-    const int C = x.c;
+                                                          int H, int W, int64_t P, int groups) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P * C) return;
-    const int c = (int)(idx % C);
-    const int64_t pix = idx / C;
+    if (idx >= P * groups) return;
+    const int c0 = (int)(idx % groups) * 8;
+    const int64_t pix = idx / groups;
     const int px = (int)(pix % W);
     const int py = (int)((pix / W) % H);
-    const bf16_t* xh = (const bf16_t*)x.hi;
-    const bf16_t* xl = (const bf16_t*)x.lo;
-    const float x0 = join_bf16(xh[pix * x.ld + c], xl[pix * x.ld + c]);
-    float acc = b[c];
+    const bf16_t* xh = (const bf16_t*)x.hi + c0;
+    const bf16_t* xl = (const bf16_t*)x.lo + c0;
+    float acc[8], x0[8];
+    {
+        const bf16x8 h8 = *(const bf16x8*)(xh + pix * x.ld), l8 = *(const bf16x8*)(xl + pix * x.ld);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x0[j] = join_bf16(h8[j], l8[j]);
+            acc[j] = b[c0 + j];
+        }
+    }
     constexpr int R = K / 2;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
@@ -69,24 +76,34 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(ppms_sp x, ppms_sp y, 
             const int xx = px + kx - R;
             if ((unsigned)xx >= (unsigned)W) continue;
             const int64_t q = pix + (int64_t)(ky - R) * W + (kx - R);
-            acc += w[c * K * K + ky * K + kx] * join_bf16(xh[q * x.ld + c], xl[q * x.ld + c]);
+            const bf16x8 h8 = *(const bf16x8*)(xh + q * x.ld), l8 = *(const bf16x8*)(xl + q * x.ld);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w[(c0 + j) * K * K + ky * K + kx] * join_bf16(h8[j], l8[j]);
         }
     }
-    bf16_t hi, lo;
-    split_bf16(gelu_erf(x0 + acc), hi, lo);
-    ((bf16_t*)y.hi)[pix * y.ld + c] = hi;
-    ((bf16_t*)y.lo)[pix * y.ld + c] = lo;
+    bf16x8 oh, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        bf16_t hi, lo;
+        split_bf16(gelu_erf(x0[j] + acc[j]), hi, lo);
+        oh[j] = hi;
+        ol[j] = lo;
+    }
+    *(bf16x8*)((bf16_t*)y.hi + pix * y.ld + c0) = oh;
+    *(bf16x8*)((bf16_t*)y.lo + pix * y.ld + c0) = ol;
 }
 
 extern "C" int ppms_dwconv_gelu(ppms_sp x, ppms_sp y, const float* w, const float* b, int k, int BT, int H, int W, void* stream) {
     PPMS_REQUIRE(k == 1 || k == 7, "dwconv_gelu: k=%d (only 1 and 7)", k);
-    PPMS_REQUIRE(x.hi && x.lo && y.hi && y.lo && x.c == y.c && x.c > 0, "dwconv_gelu: bad views");
+    PPMS_REQUIRE(x.hi && x.lo && y.hi && y.lo && x.c == y.c && x.c > 0 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0,
+                 "dwconv_gelu: views must have c, ld multiples of 8");
     const int64_t P = (int64_t)BT * H * W;
-    const dim3 grid(ceil_div(P * x.c, 256));
+    const int groups = x.c / 8;
+    const dim3 grid(ceil_div(P * groups, 256));
     if (k == 1)
-        hipLaunchKernelGGL(dwconv_gelu_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P);
+        hipLaunchKernelGGL(dwconv_gelu_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P, groups);
     else
-        hipLaunchKernelGGL(dwconv_gelu_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P);
+        hipLaunchKernelGGL(dwconv_gelu_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P, groups);
     return ppms_check_launch("dwconv_gelu");
 }
 

@@ -174,6 +174,7 @@ class ScaleEngine:
         self.VT = torch.zeros(T, 128, self.n, dtype=torch.bfloat16, device=device)
         self.QB = torch.zeros(T, self.n, 128, dtype=torch.bfloat16, device=device)
         self.KB = torch.zeros(T, self.ksel, self.n, 128, dtype=torch.bfloat16, device=device)
+        self.ATT_WS = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, self.ksel, self.n)), dtype=torch.uint8, device=device)
         self.nblk = (self.n + 255) // 256
         self.UNC, self.PART = f32(P), f32(T, self.nblk)
         self.SIM, self.STRIVE, self.SCORE = f32(T, T), f32(T, T), f32(T, T)
@@ -352,8 +353,8 @@ class ScaleEngine:
         o["ffn1_0"]()
         o["ffn1_2"]()
         (w1, b1, _), (w7, b7, _) = self.pk.dw
-        L.check(self.lib.ppms_dwconv_gelu(self.C1.view(), self.C2.view(), w1.data_ptr(), b1.data_ptr(), 1, self.T, self.h, self.w, s))
-        L.check(self.lib.ppms_dwconv_gelu(self.C2.view(), self.C1.view(), w7.data_ptr(), b7.data_ptr(), 7, self.T, self.h, self.w, s))
+        L.check(self.lib.ppms_dwconv_gelu(self.C1.view(0, 40), self.C2.view(0, 40), w1.data_ptr(), b1.data_ptr(), 1, self.T, self.h, self.w, s))
+        L.check(self.lib.ppms_dwconv_gelu(self.C2.view(0, 40), self.C1.view(0, 40), w7.data_ptr(), b7.data_ptr(), 7, self.T, self.h, self.w, s))
         o["pw"]()
         o["ffn2_0"]()
         o["ffn2_2"]()
@@ -384,7 +385,8 @@ class ScaleEngine:
             self._ev_i += 1
             ev[0].record()
         L.check(self.lib.ppms_mem_attn(self.QB.data_ptr(), self.KB.data_ptr(), self.VT.data_ptr(), self.SEL.data_ptr(), self.ksel, self.scale,
-                                       self.pk.beta.data_ptr(), self.X.view(128, 128), self.X.view(256, 128), L.ptr(out_bf16), self.T, self.n, s))
+                                       self.pk.beta.data_ptr(), self.X.view(128, 128), self.X.view(256, 128), L.ptr(out_bf16), self.T, self.n,
+                                       self.ATT_WS.data_ptr(), s))
         if ev is not None:
             ev[1].record()
 

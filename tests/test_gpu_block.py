@@ -152,8 +152,9 @@ def test_attention_is_a_convex_combination(model):
     X = L.SPTensor(T * n, 256, DEV)
     beta = torch.tensor([1.0], device=DEV)
     raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, 5, n)), dtype=torch.uint8, device=DEV)
     L.check(L.load().ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 5, 0.05, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                                   raw.data_ptr(), T, n, L.stream_ptr()))
+                                   raw.data_ptr(), T, n, ws.data_ptr(), L.stream_ptr()))
     want = cvec.to(torch.bfloat16).float()
     got = raw.float().cpu()
     assert (got - want).abs().max() <= 0.01 * want.abs().max(), "softmax weights do not sum to one"

@@ -268,8 +268,9 @@ def test_qam_select_sequence(lib):
 
 
 # ------------------------------------------------------------------------------------------------ memory attention
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5)])
-def test_mem_attn_vs_oracle(lib, T, n, ksel_frames):
+def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split):
     """prep_q + prep_k + mem_attn against play_inputs + flash_attn_math (ppmstereo.py:517-552)."""
     L = lib
     from ppmstereo_amd.engine import softmax_scale, temporal_pe
@@ -305,8 +306,9 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames):
     X.set_f32(cl(mf).to(DEV), 0)
     beta = torch.tensor([0.5], device=DEV)
     raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(int(lib_.ppms_mem_attn_workspace_bytes(T, ksel_frames, n)), dtype=torch.uint8, device=DEV) if split else None
     L.check(lib_.ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), seld.data_ptr(), ksel_frames, scale, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                               raw.data_ptr(), T, n, s))
+                               raw.data_ptr(), T, n, L.ptr(ws), s))
     torch.cuda.synchronize()
     # operands: bit-exact bf16 of the oracle's fp32 operands
     Q0, K0, _, _, _ = O.play_inputs(q, key, pe, value, score, mask, 0)
@@ -336,8 +338,9 @@ def test_mem_attn_sharp_softmax(lib):
     beta = torch.tensor([1.0], device=DEV)
     raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
     scale = 1.0
+    ws = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, 2, n)), dtype=torch.uint8, device=DEV)
     L.check(L.load().ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 2, scale, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                                   raw.data_ptr(), T, n, L.stream_ptr()))
+                                   raw.data_ptr(), T, n, ws.data_ptr(), L.stream_ptr()))
     for i in range(T):
         K = kb[i].reshape(-1, 128).float().cpu()
         V = torch.cat([vt[0].float().cpu().t(), vt[1].float().cpu().t()], 0)
