@@ -188,6 +188,10 @@ class ScaleEngine:
         self.have_mhs = False
         self.lib = L.load()
         self._ev, self._ev_i = None, 0
+        # independent branches of an iteration (flow encoder || correlation encoder, r-gate || z-gate, mask head || flow
+        # head) run on a second HIP stream, fork/joined with events: they fill each other's launch tails
+        self._side = torch.cuda.Stream(device=device)
+        self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         self._build_descriptors()
 
     # ------------------------------------------------------------------ descriptors
@@ -344,8 +348,21 @@ class ScaleEngine:
         L.check(self.lib.ppms_corr_lookup(self.pyr_ptrs, self.FLOW.data_ptr(), 1, None, self.CORR.view().hi, self.CORR.view().lo, 64,
                                           fl.hi, fl.lo, 384, self.T, self.h, self.w, self._s()))
 
+    def _fork(self):
+        self._ev_fork.record()
+        self._side.wait_event(self._ev_fork)
+        return torch.cuda.stream(self._side)
+
+    def _join(self):
+        self._ev_join.record(self._side)
+        torch.cuda.current_stream().wait_event(self._ev_join)
+
     def motion_and_value(self):
         o, s, par = self.op, self._s(), self.parity
+        with self._fork():                        # flow branch: convf1 (7x7 via im2col) -> convf2
+            L.check(self.lib.ppms_flow_patch7(self.FLOW.data_ptr(), self.PATCH.view(), self.T, self.h, self.w, self._s()))
+            o["convf1"]()
+            o[f"convf2_{par}"]()
         if not self.have_mhs:                     # init_conv(inp), ppmtereo_update.py:469-471
             o["init0"]()
             o[f"init2_{par}"]()
@@ -359,9 +376,7 @@ class ScaleEngine:
         o["ffn2_0"]()
         o["ffn2_2"]()
         o[f"convc2_{par}"]()
-        L.check(self.lib.ppms_flow_patch7(self.FLOW.data_ptr(), self.PATCH.view(), self.T, self.h, self.w, s))
-        o["convf1"]()
-        o[f"convf2_{par}"]()
+        self._join()
         o[f"final_{par}"]()
         self.parity = 1 - par                     # the new motion hidden state went to the other CF buffer
         o["to_v"]()
@@ -411,13 +426,22 @@ class ScaleEngine:
         o = self.op
         if self.pk.attn is not None:
             self.block16_attention()
-        for k in ("zr1_0", "z1_2", "r1_2", "q1", "zr2", "q2", "zr3", "q3", "fh1", "fh2"):
+        o["zr1_0"]()
+        with self._fork():
+            o["r1_2"]()
+        o["z1_2"]()
+        self._join()
+        for k in ("q1", "zr2", "q2", "zr3", "q3"):
             o[k]()
+        with self._fork():                        # mask head || flow head
+            o["m1"]()
+            o["m2"]()
+        o["fh1"]()
+        o["fh2"]()
         L.check(self.lib.ppms_tap_gather_sum(self.FH2Y.data_ptr(), 64, self.pk.fh2_bias.data_ptr(), self.DFLOW.data_ptr(), 4, 2, 3, 3, 3,
                                              self.T, self.h, self.w, self._s()))
         L.check(self.lib.ppms_flow_add(self.FLOW.data_ptr(), self.DFLOW.data_ptr(), 4, self.P, self._s()))   # ppmstereo.py:571
-        o["m1"]()
-        o["m2"]()
+        self._join()
 
     def upsample(self) -> torch.Tensor:
         L.check(self.lib.ppms_convex_upsample(self.FLOW.data_ptr(), self.MASK.data_ptr(), 144, self.FLOW_OUT.data_ptr(), self.T, self.h, self.w,
