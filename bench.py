@@ -113,9 +113,14 @@ def main():
         ms = eng4.attn_times_ms()
         avg = sum(ms) / len(ms)
         ach = attn_flop / (avg * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="mem_attn_kernel (1/4 scale, all T clips per launch)", achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS,
-                    unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=None, launches=len(ms), avg_ms=round(avg, 4),
-                    flop_per_launch=attn_flop)
+        traffic = None            # HBM bytes per launch from the committed PMC passes (same kernel, same shape), if present
+        tfile = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+        if os.path.exists(tfile) and (T, H, W) == (5, 320, 512):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+        roof = dict(bound="mfma", kernel="mem_attn_kernel + attn_combine_kernel (1/4 scale, all T clips and picked frames per launch)",
+                    achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
+                    traffic=traffic, traffic_source="profiles/r01_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                    launches=len(ms), avg_ms=round(avg, 4), flop_per_launch=attn_flop)
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -69,6 +69,48 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, int iters) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[(i + r) & 3], b2[i], acc[i], 0, 0, 0);
         }
+    } else if (MODE == 4 || MODE == 5) {
+        // 64x128 wave tile: 8 A-side + 16 B-side reads (24 ds_read_b128) per 48 MFMA; MODE 5 adds a barrier per step
+        f32x16 acc2[4];
+        for (int i = 0; i < 4; ++i) acc2[i] = (f32x16){0};
+        bf16x8 bb[8];
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k16 = 0; k16 < 2; ++k16) {
+                const char* p = base + ((it + k16) & 1) * 1024;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(p + i * 2048);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bb[i] = *(const bf16x8*)(p + 32768 + i * 2048 + (i >> 2) * 512);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + r) & 3], bb[i], acc[i], 0, 0, 0);
+                        acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + r) & 3], bb[4 + i], acc2[i], 0, 0, 0);
+                    }
+            }
+            if (MODE == 5) __syncthreads();
+        }
+        for (int i = 0; i < 4; ++i) acc[i][0] += acc2[i][3];
+    } else if (MODE == 6) {
+        // conv2 ratio (16 reads / 24 MFMA) with one workgroup barrier per step
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int k16 = 0; k16 < 2; ++k16) {
+                const char* p = base + ((it + k16) & 1) * 1024;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    a[i] = *(const bf16x8*)(p + i * 2048);
+                    b[i] = *(const bf16x8*)(p + 32768 + i * 2048);
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[(i + r) & 3], b[i], acc[i], 0, 0, 0);
+            }
+            __syncthreads();
+        }
     } else {
         f32x4 c[8];
         for (int i = 0; i < 8; ++i) c[i] = (f32x4){0};
@@ -108,11 +150,14 @@ void run(const char* name, int blocks, int iters, double flop_per_iter_per_wave)
 
 int main() {
     const double f32 = 2.0 * 32 * 32 * 16, f16 = 2.0 * 16 * 16 * 32;
-    for (int blocks : {256, 512}) {
+    for (int blocks : {256, 512, 768}) {
         run<0>("mfma32x32x16 only (24/iter)", blocks, 4000, 24 * f32);
         run<3>("mfma16x16x32 only (48/iter)", blocks, 4000, 48 * f16);
         run<1>("16 ds_read_b128 + 24 mfma, read-then-compute", blocks, 4000, 24 * f32);
         run<2>("16 ds_read_b128 + 24 mfma, pipelined", blocks, 4000, 24 * f32);
+        run<6>("16 ds_read_b128 + 24 mfma + barrier/step", blocks, 4000, 24 * f32);
+        run<4>("24 ds_read_b128 + 48 mfma (64x128 wave tile)", blocks, 2000, 48 * f32);
+        run<5>("24 ds_read_b128 + 48 mfma + barrier/step", blocks, 2000, 48 * f32);
     }
     return 0;
 }
