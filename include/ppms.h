@@ -96,6 +96,11 @@ int ppms_conv_gemm(const ppms_conv* desc, const ppms_conv* dev_desc, void* strea
  * by the kw taps).  Same descriptor; desc->w must be in the pack_conv2 layout (ppmstereo_amd/packing.py).
  * wm_hint: 64-cout blocks per workgroup (1..4), 0 = let the library choose from the grid size. */
 int ppms_conv_gemm2(const ppms_conv* desc, const ppms_conv* dev_desc, int wm_hint, void* stream);
+/* Large-map variant (128 couts x 256 pixels per workgroup, LDS-DMA operands, x- or y-swept activation window).
+ * ppms_conv_gemm3_applicable() tells whether it serves a descriptor (M % 128 == 0, kw > 1 or kh > 1, enough tiles);
+ * weights in pack_conv2 order -- for kw == 1 convs (swept along y) packed with the kh / kw axes swapped. */
+int ppms_conv_gemm3_applicable(const ppms_conv* desc);
+int ppms_conv_gemm3(const ppms_conv* desc, const ppms_conv* dev_desc, void* stream);
 /* sizeof(ppms_sp), sizeof(ppms_epilogue), sizeof(ppms_conv) as compiled: lets a foreign-language binding check its
  * struct layout at load time */
 int ppms_struct_sizes(int* sp, int* epilogue, int* conv);

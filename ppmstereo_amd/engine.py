@@ -31,6 +31,7 @@ from . import packing as _packing
 TOP_K = 5
 # 2 = data-reuse tiling (conv_gemm2.hip, default); 1 = first-generation kernel (conv_gemm.hip), kept for A/B checks
 CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
+USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 
 
 def pack_conv(*a, **k):
@@ -66,7 +67,9 @@ class ConvOp:
         self.keep = keep            # tensors whose storage the descriptor points at
 
     def __call__(self):
-        if self.version == 2:
+        if self.version == 3:
+            L.check(L.load().ppms_conv_gemm3(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
+        elif self.version == 2:
             L.check(L.load().ppms_conv_gemm2(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         else:
             L.check(L.load().ppms_conv_gemm(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
@@ -134,6 +137,9 @@ class PackedBlock:
         for n in ("2", "3"):
             put("zr" + n, cat(gr + f"convz{n}.weight", gr + f"convr{n}.weight"), cat(gr + f"convz{n}.bias", gr + f"convr{n}.bias"), [128, 384])
             put("q" + n, g(gr + f"convq{n}.weight"), g(gr + f"convq{n}.bias"), [128, 384])
+        # the (1,5,1) pass again with kh / kw swapped: k-step order of the y-swept large-map kernel (conv_gemm3.hip)
+        put("zr2_y", cat(gr + "convz2.weight", gr + "convr2.weight").transpose(3, 4).contiguous(), cat(gr + "convz2.bias", gr + "convr2.bias"), [128, 384])
+        put("q2_y", g(gr + "convq2.weight").transpose(3, 4).contiguous(), g(gr + "convq2.bias"), [128, 384])
         put("fh1", g("flow_head.conv1.weight"), g("flow_head.conv1.bias"), [128])
         # flow_head.conv2 (256 -> 2, 3x3x3) as a 1x1 GEMM to 27*2 = 54 channels + shifted sum (ppms_tap_gather_sum)
         w2 = g("flow_head.conv2.weight")                                     # (2, 256, 3, 3, 3)
@@ -203,7 +209,6 @@ class ScaleEngine:
             d.seg[i] = s
         d.nseg = len(segs)
         assert [s.c for s in segs] == meta["seg_padded"], (wname, [s.c for s in segs], meta["seg_padded"])
-        assert tuple(k3) == meta["taps"] or wname == "convf1", (wname, k3, meta["taps"])
         d.w, d.bias = packed.data_ptr(), bias.data_ptr()
         d.T, d.H, d.W = self.T, self.h, self.w
         d.kt, d.kh, d.kw = k3
@@ -212,7 +217,16 @@ class ScaleEngine:
         d.epi[0] = epi0
         if epi1 is not None:
             d.epi[1] = epi1
-        return ConvOp(d, [packed, bias, *keep], meta.get("version", 1))
+        version = meta.get("version", 1)
+        if version == 2 and USE_CONV3 and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
+            if k3[2] == 1 and k3[1] > 1:                                   # y sweep: needs the axis-swapped pack
+                if wname + "_y" in self.pk.w:
+                    packed_y, bias_y, _ = self.pk.w[wname + "_y"]
+                    d.w, d.bias = packed_y.data_ptr(), bias_y.data_ptr()
+                    return ConvOp(d, [packed_y, bias_y, *keep], 3)
+            else:
+                return ConvOp(d, [packed, bias, *keep], 3)
+        return ConvOp(d, [packed, bias, *keep], version)
 
     def _build_descriptors(self):
         E, X, H = epilogue, self.X, self.Hb

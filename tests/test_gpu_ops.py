@@ -75,7 +75,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
     from ppmstereo_amd.engine import ConvOp, epilogue
     from ppmstereo_amd.packing import pack_conv as pack1, pack_conv2
-    pack_conv = pack_conv2 if version == 2 else pack1
+    pack_conv = pack_conv2 if version >= 2 else pack1
     P = T * H * W
     segs, keep = [], []
     seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
@@ -84,7 +84,10 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
         t.set_f32(x.to(DEV))
         segs.append(t.view())
         keep.append(t)
-    packed, b, meta = pack_conv(weight.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad)
+    wpack = weight
+    if version == 3 and k3[2] == 1 and k3[1] > 1:            # y-swept large-map kernel: pack with kh / kw swapped
+        wpack = (weight if weight.dim() == 5 else weight[:, :, None]).transpose(3, 4).contiguous()
+    packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad)
     cout = weight.shape[0]
     out = L.SPTensor(P, meta["M"], DEV)
     outf = torch.zeros(P, meta["M"], device=DEV)
@@ -176,6 +179,34 @@ def test_conv_gemm_epilogues(lib, version):
     assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + lin)) < 5e-5
     assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RH, aux=aux), torch.sigmoid(lin) * aux) < 5e-5
     assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < 5e-5
+
+
+CONV3_CASES = [
+    ("gru_1x15", 2, 6, 128, [128, 384], 256, (1, 1, 15)),
+    ("q_1x5", 1, 5, 128, [128, 64], 128, (1, 1, 5)),
+    ("3x3_m128", 3, 20, 32, [128, 128], 128, (1, 3, 3)),
+    ("3x3x3_m256", 4, 9, 64, [128], 256, (3, 3, 3)),
+    ("y_1x5x1", 2, 40, 32, [128, 32], 256, (1, 5, 1)),
+    ("y_w80", 1, 23, 80, [64], 128, (1, 5, 1)),
+    ("x_w80_1x5", 2, 7, 80, [64], 128, (1, 1, 5)),
+]
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV3_CASES)
+def test_conv_gemm3_vs_torch(lib, name, T, H, W, segs, cout, k3):
+    """Large-map kernel (64x128 wave tiles, LDS-DMA operands, x / y swept windows) vs torch conv3d."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=3)
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=3, kind=lib.EPI_GRU, aux=aux, z=z)
+    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
 def test_conv_gemm_rejects_bad_descriptors(lib):
