@@ -62,7 +62,7 @@ enum {                            /* epilogue kinds */
     PPMS_EPI_GRU = 3,             /* y = (1 - z) * aux_sp + z * tanh(acc + bias), z = aux_f32      */
     PPMS_EPI_ADDF32 = 4           /* out_f32 += acc + bias (in place)              (flow += dflow) */
 };
-enum { PPMS_ACT_NONE = 0, PPMS_ACT_RELU = 1, PPMS_ACT_GELU = 2, PPMS_ACT_SIGMOID = 3, PPMS_ACT_TANH = 4 };
+enum { PPMS_ACT_NONE = 0, PPMS_ACT_RELU = 1, PPMS_ACT_GELU = 2, PPMS_ACT_SIGMOID = 3, PPMS_ACT_TANH = 4, PPMS_ACT_ELU1 = 5 /* elu(x)+1 */ };
 
 typedef struct ppms_epilogue {
     int32_t kind, act;
@@ -159,6 +159,17 @@ int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t*
 /* split_ws (optional, caller-owned, ppms_mem_attn_workspace_bytes(T, ksel, n) bytes): when given, the picked frames are
  * processed by separate workgroups (ksel x more, smaller work units) and merged by a combine kernel; NULL = fused. */
 int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
+
+/* ---------------------------------------------------------------- update_block16 time / space attention pieces */
+/* TimeAttnBlock core (ppmtereo_update.py:603-606 with Attention.forward :409-417): per pixel, tokens = its T frames;
+ * y = LayerNorm(x); out_t = sum_t2 softmax(y_t . y_t2 / sqrt(48)) y_t2 per head (q = k = v = y).  x, out: SP, 384 channels. */
+int ppms_time_attn(ppms_sp x, const float* ln_w, const float* ln_b, ppms_sp out, int T, int n, int heads, void* stream);
+/* out = resid + LayerNorm(x) (resid.hi == NULL: no residual); x fp32 [pixel][ld]; C = 384 (attention.py:186-190) */
+int ppms_layernorm(const float* x, int ld, const float* w, const float* b, ppms_sp resid, ppms_sp out, int64_t pixels, int C, void* stream);
+/* LinearAttention.forward (attention.py:73-100) per frame and head: Q, K already elu()+1, V already / n;
+ * kv_ws: fp32 workspace of 4*T*heads*dh*(dh+1) floats; out (SP) = (Q KV) / (Q . sum K + 1e-6) * n */
+int ppms_linear_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* kv_ws, ppms_sp out, int T, int n,
+                          int heads, int dh, void* stream);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ from . import build as _build
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 EPI_STORE, EPI_RESID, EPI_RH, EPI_GRU, EPI_ADDF32 = range(5)
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_TANH = range(5)
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_TANH, ACT_ELU1 = range(6)
 
 
 class SP(C.Structure):
@@ -63,6 +63,9 @@ _SIGS = {
     "ppms_qam_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppms_attn_prep_q": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_attn_prep_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppms_time_attn": (c_int, [SP, c_void_p, c_void_p, SP, c_int, c_int, c_int, c_void_p]),
+    "ppms_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, SP, SP, c_int64, c_int, c_void_p]),
+    "ppms_linear_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, SP, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ppms_mem_attn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
 }

@@ -1,0 +1,227 @@
+// update_block16's TimeAttnBlock / SpaceAttnBlock pieces that are not plain GEMMs
+// (/root/reference/models/core/ppmtereo_update.py:593-631 with Attention :400-420, and the LoFTR linear attention of
+// /root/reference/models/core/attention.py:73-100,164-190).  The Linear layers run on the implicit-GEMM kernel; these
+// kernels are the LayerNorms, the per-pixel T x T temporal attention and the per-(frame, head) linear-attention sums.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------ time attention core
+// One wave per pixel.  tokens = the T frames of that pixel; y = LayerNorm(x) (eps 1e-5, affine); per head (dh = C/heads
+// channels): o_t = sum_t2 softmax_t2(y_t . y_t2 / sqrt(dh)) y_t2   (q = k = v = y: the reference never applies qkv).
+// Lane l owns channels [l*CPL, (l+1)*CPL), CPL = C/64; a head = 64/heads consecutive lanes.
+template <int CPL>
+__global__ __launch_bounds__(64) void time_attn_kernel(ppms_sp x, const float* __restrict__ lnw, const float* __restrict__ lnb, ppms_sp out,
+                                                       int T, int n, int lanes_per_head, float scale) {
+    extern __shared__ float ysh[];                     // [T][64*CPL]
+    const int lane = threadIdx.x;
+    const int pin = blockIdx.x;
+    const int C = 64 * CPL;
+    float w[CPL], b[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        w[j] = lnw[lane * CPL + j];
+        b[j] = lnb[lane * CPL + j];
+    }
+    for (int t = 0; t < T; ++t) {
+        const int64_t pix = (int64_t)t * n + pin;
+        float v[CPL], s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            v[j] = join_bf16(((const bf16_t*)x.hi)[pix * x.ld + lane * CPL + j], ((const bf16_t*)x.lo)[pix * x.ld + lane * CPL + j]);
+            s += v[j];
+        }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) q += (v[j] - mean) * (v[j] - mean);
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) ysh[t * C + lane * CPL + j] = (v[j] - mean) * rstd * w[j] + b[j];
+    }
+    __syncthreads();
+    for (int t1 = 0; t1 < T; ++t1) {
+        float y1[CPL], o[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            y1[j] = ysh[t1 * C + lane * CPL + j];
+            o[j] = 0.0f;
+        }
+        // two passes over t2 (max, then exp / sum): T is small, the scores are recomputed instead of stored
+        float mx = -INFINITY;
+        for (int t2 = 0; t2 < T; ++t2) {
+            float d = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) d += y1[j] * ysh[t2 * C + lane * CPL + j];
+            for (int of = 1; of < lanes_per_head; of <<= 1) d += __shfl_xor(d, of);
+            mx = fmaxf(mx, d * scale);
+        }
+        float den = 0.0f;
+        for (int t2 = 0; t2 < T; ++t2) {
+            float d = 0.0f;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) d += y1[j] * ysh[t2 * C + lane * CPL + j];
+            for (int of = 1; of < lanes_per_head; of <<= 1) d += __shfl_xor(d, of);
+            const float e = expf(d * scale - mx);
+            den += e;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) o[j] += e * ysh[t2 * C + lane * CPL + j];
+        }
+        const int64_t pix = (int64_t)t1 * n + pin;
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            bf16_t hi, lo;
+            split_bf16(o[j] / den, hi, lo);
+            ((bf16_t*)out.hi)[pix * out.ld + lane * CPL + j] = hi;
+            ((bf16_t*)out.lo)[pix * out.ld + lane * CPL + j] = lo;
+        }
+    }
+}
+
+extern "C" int ppms_time_attn(ppms_sp x, const float* ln_w, const float* ln_b, ppms_sp out, int T, int n, int heads, void* stream) {
+    PPMS_REQUIRE(x.hi && x.lo && out.hi && out.lo && ln_w && ln_b, "time_attn: null operand");
+    PPMS_REQUIRE(x.c == 384 && out.c == 384 && heads == 8, "time_attn: C = 384, 8 heads (update_block16) expected, got C=%d heads=%d", x.c, heads);
+    PPMS_REQUIRE(T >= 1 && T <= 64 && n >= 1, "time_attn: bad T=%d n=%d", T, n);
+    const int lanes_per_head = 64 / heads;
+    const float scale = 1.0f / sqrtf((float)(x.c / heads));
+    hipLaunchKernelGGL(time_attn_kernel<6>, dim3(n), dim3(64), (size_t)T * 384 * 4, (hipStream_t)stream, x, ln_w, ln_b, out, T, n, lanes_per_head,
+                       scale);
+    return ppms_check_launch("time_attn");
+}
+
+// ------------------------------------------------------------------------------------------------ layer norm (+ residual)
+// out = resid + LN(x) (resid optional); x: fp32 [pixel][ld], one wave per pixel, C = 64*CPL channels
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w, const float* __restrict__ b,
+                                                        ppms_sp resid, ppms_sp out, int64_t pixels) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= pixels) return;
+    const int C = 64 * CPL;
+    float v[CPL], s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        v[j] = x[pix * ld + lane * CPL + j];
+        s += v[j];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) q += (v[j] - mean) * (v[j] - mean);
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int c = lane * CPL + j;
+        float y = (v[j] - mean) * rstd * w[c] + b[c];
+        if (resid.hi) y += join_bf16(((const bf16_t*)resid.hi)[pix * resid.ld + c], ((const bf16_t*)resid.lo)[pix * resid.ld + c]);
+        bf16_t hi, lo;
+        split_bf16(y, hi, lo);
+        ((bf16_t*)out.hi)[pix * out.ld + c] = hi;
+        ((bf16_t*)out.lo)[pix * out.ld + c] = lo;
+    }
+}
+
+extern "C" int ppms_layernorm(const float* x, int ld, const float* w, const float* b, ppms_sp resid, ppms_sp out, int64_t pixels, int C,
+                              void* stream) {
+    PPMS_REQUIRE(x && w && b && out.hi && out.lo && C == 384 && ld >= C, "layernorm: C = 384 expected (got %d)", C);
+    hipLaunchKernelGGL(layernorm_kernel<6>, dim3(ceil_div(pixels, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, w, b, resid, out, pixels);
+    return ppms_check_launch("layernorm");
+}
+
+// ------------------------------------------------------------------------------------------------ linear attention
+// kv[f][hd][d][v] = sum_s K[f,s,hd,d] V[f,s,hd,v];  ksum[f][hd][d] = sum_s K[f,s,hd,d].
+// Grid (head, frame, pixel split): each workgroup reduces n/NSPLIT pixels into its own partial (fixed order: deterministic),
+// each thread owns a 3 x 3 block of the 48 x 48 outer product (6 LDS reads per 9 FMAs).
+constexpr int LA_NSPLIT = 4;
+__global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
+                                                         float* __restrict__ kv, float* __restrict__ ksum, int n, int heads) {
+    constexpr int DH = 48, CH = 32;                    // pixels staged per pass
+    __shared__ float ks[CH][DH + 1], vs[CH][DH + 1];
+    const int hd = blockIdx.x, f = blockIdx.y, sp_id = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int d0 = (tid >> 4) * 3, v0 = (tid & 15) * 3;
+    float acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    float ksacc = 0.0f;                                // threads 0..47
+    const int per = (n + LA_NSPLIT - 1) / LA_NSPLIT;
+    const int s_begin = sp_id * per, s_end = (s_begin + per < n) ? s_begin + per : n;
+    for (int s0 = s_begin; s0 < s_end; s0 += CH) {
+        for (int i = tid; i < CH * DH; i += 256) {
+            const int sp = i / DH, c = i % DH;
+            const bool ok = s0 + sp < s_end;
+            const int64_t pix = (int64_t)f * n + s0 + sp;
+            ks[sp][c] = ok ? K[pix * ldk + hd * DH + c] : 0.0f;
+            vs[sp][c] = ok ? V[pix * ldv + hd * DH + c] : 0.0f;
+        }
+        __syncthreads();
+        for (int sp = 0; sp < CH; ++sp) {
+            const float k0 = ks[sp][d0], k1 = ks[sp][d0 + 1], k2 = ks[sp][d0 + 2];
+            const float a0 = vs[sp][v0], a1 = vs[sp][v0 + 1], a2 = vs[sp][v0 + 2];
+            acc[0][0] += k0 * a0; acc[0][1] += k0 * a1; acc[0][2] += k0 * a2;
+            acc[1][0] += k1 * a0; acc[1][1] += k1 * a1; acc[1][2] += k1 * a2;
+            acc[2][0] += k2 * a0; acc[2][1] += k2 * a1; acc[2][2] += k2 * a2;
+        }
+        if (tid < DH)
+            for (int sp = 0; sp < CH; ++sp) ksacc += ks[sp][tid];
+        __syncthreads();
+    }
+    float* o = kv + (((int64_t)sp_id * gridDim.y + f) * heads + hd) * DH * DH;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) o[(d0 + i) * DH + v0 + j] = acc[i][j];
+    if (tid < DH) ksum[(((int64_t)sp_id * gridDim.y + f) * heads + hd) * DH + tid] = ksacc;
+}
+
+// msg[f,l,hd,v] = (sum_d Q[f,l,hd,d] kv[f,hd,d,v]) * (1 / (Q . ksum + eps)) * n   (one workgroup = 32 pixels of one frame x head)
+__global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ kv,
+                                                            const float* __restrict__ ksum, ppms_sp out, int n, int heads, float eps) {
+    constexpr int DH = 48, PX = 32;
+    __shared__ float kvs[DH][DH + 1], kss[DH], qs[PX][DH];
+    const int hd = blockIdx.y, f = blockIdx.z, p0 = blockIdx.x * PX;
+    const int tid = threadIdx.x;
+    const int64_t pstride_kv = (int64_t)gridDim.z * heads * DH * DH, pstride_ks = (int64_t)gridDim.z * heads * DH;
+    const float* kvp = kv + ((int64_t)f * heads + hd) * DH * DH;
+    for (int i = tid; i < DH * DH; i += 256) {
+        float a = 0.0f;
+        for (int sp = 0; sp < LA_NSPLIT; ++sp) a += kvp[sp * pstride_kv + i];
+        kvs[i / DH][i % DH] = a;
+    }
+    if (tid < DH) {
+        float a = 0.0f;
+        for (int sp = 0; sp < LA_NSPLIT; ++sp) a += ksum[sp * pstride_ks + ((int64_t)f * heads + hd) * DH + tid];
+        kss[tid] = a;
+    }
+    for (int i = tid; i < PX * DH; i += 256) {
+        const int sp = i / DH, c = i % DH;
+        qs[sp][c] = (p0 + sp < n) ? Q[((int64_t)f * n + p0 + sp) * ldq + hd * DH + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = tid; i < PX * DH; i += 256) {
+        const int sp = i / DH, v = i % DH;
+        if (p0 + sp >= n) continue;
+        float z = 0.0f, a = 0.0f;
+        for (int d = 0; d < DH; ++d) {
+            z += qs[sp][d] * kss[d];
+            a += qs[sp][d] * kvs[d][v];
+        }
+        const float y = a * (1.0f / (z + eps)) * (float)n;
+        bf16_t hi, lo;
+        split_bf16(y, hi, lo);
+        const int64_t pix = (int64_t)f * n + p0 + sp;
+        ((bf16_t*)out.hi)[pix * out.ld + hd * DH + v] = hi;
+        ((bf16_t*)out.lo)[pix * out.ld + hd * DH + v] = lo;
+    }
+}
+
+extern "C" int ppms_linear_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* kv_ws, ppms_sp out,
+                                     int T, int n, int heads, int dh, void* stream) {
+    PPMS_REQUIRE(Q && K && V && kv_ws && out.hi && out.lo && heads == 8 && dh == 48, "linear_attention: 8 heads x 48 channels expected");
+    float* kv = kv_ws;
+    float* ksum = kv_ws + (size_t)LA_NSPLIT * T * heads * dh * dh;
+    hipLaunchKernelGGL(linattn_kv_kernel, dim3(heads, T, LA_NSPLIT), dim3(256), 0, (hipStream_t)stream, K, ldk, V, ldv, kv, ksum, n, heads);
+    hipLaunchKernelGGL(linattn_apply_kernel, dim3(ceil_div(n, 32), heads, T), dim3(256), 0, (hipStream_t)stream, Q, ldq, kv, ksum, out, n, heads,
+                       1e-6f);
+    return ppms_check_launch("linear_attention");
+}

@@ -52,6 +52,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
         case PPMS_ACT_GELU: return gelu_erf(x);
         case PPMS_ACT_SIGMOID: return sigmoid_f(x);
         case PPMS_ACT_TANH: return tanhf(x);
+        case PPMS_ACT_ELU1: return x > 0.0f ? x + 1.0f : expf(x);      // elu(x) + 1 (attention.py:14-15)
         default: return x;
     }
 }

@@ -93,75 +93,18 @@ __global__ __launch_bounds__(256) void dwconv_gelu_kernel(ppms_sp x, ppms_sp y, 
     *(bf16x8*)((bf16_t*)y.lo + pix * y.ld + c0) = ol;
 }
 
-// 7x7 variant with an LDS tile: a 16x16 pixel patch (+3 halo) of one 8-channel group is staged once as fp32, then every
-// thread sweeps its 49 taps from LDS (the global-memory version above re-reads each input 49 times through L1/L2)
-__global__ __launch_bounds__(256) void dwconv7_lds_kernel(ppms_sp x, ppms_sp y, const float* __restrict__ w, const float* __restrict__ b,
-                                                          int H, int W, int tiles_x, int tiles_y) {
-    __shared__ float tile[22 * 22][8 + 1];                 // +1: the 8-float rows would otherwise stride 32 B onto 8 banks
-    __shared__ float wsh[8][49];
-    const int grp = blockIdx.y;                            // 8-channel group
-    int t = blockIdx.x;
-    const int tx = t % tiles_x;
-    t /= tiles_x;
-    const int ty = t % tiles_y;
-    const int frame = t / tiles_y;
-    const int x0 = tx * 16, y0 = ty * 16, c0 = grp * 8;
-    const bf16_t* xh = (const bf16_t*)x.hi + c0;
-    const bf16_t* xl = (const bf16_t*)x.lo + c0;
-    for (int i = threadIdx.x; i < 8 * 49; i += 256) wsh[i / 49][i % 49] = w[(c0 + i / 49) * 49 + i % 49];
-    for (int i = threadIdx.x; i < 22 * 22; i += 256) {
-        const int yy = y0 + i / 22 - 3, xx = x0 + i % 22 - 3;
-        float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
-            const int64_t q = ((int64_t)frame * H + yy) * W + xx;
-            const bf16x8 h8 = *(const bf16x8*)(xh + q * x.ld), l8 = *(const bf16x8*)(xl + q * x.ld);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = join_bf16(h8[j], l8[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tile[i][j] = v[j];
-    }
-    __syncthreads();
-    const int px = threadIdx.x & 15, py = threadIdx.x >> 4;
-    if (x0 + px >= W || y0 + py >= H) return;
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = b[c0 + j];
-#pragma unroll
-    for (int ky = 0; ky < 7; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 7; ++kx) {
-            const float* tp = tile[(py + ky) * 22 + px + kx];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += wsh[j][ky * 7 + kx] * tp[j];
-        }
-    const float* ctr = tile[(py + 3) * 22 + px + 3];
-    bf16x8 oh, ol;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bf16_t hi, lo;
-        split_bf16(gelu_erf(ctr[j] + acc[j]), hi, lo);
-        oh[j] = hi;
-        ol[j] = lo;
-    }
-    const int64_t pix = ((int64_t)frame * H + y0 + py) * W + x0 + px;
-    *(bf16x8*)((bf16_t*)y.hi + pix * y.ld + c0) = oh;
-    *(bf16x8*)((bf16_t*)y.lo + pix * y.ld + c0) = ol;
-}
-
 extern "C" int ppms_dwconv_gelu(ppms_sp x, ppms_sp y, const float* w, const float* b, int k, int BT, int H, int W, void* stream) {
     PPMS_REQUIRE(k == 1 || k == 7, "dwconv_gelu: k=%d (only 1 and 7)", k);
     PPMS_REQUIRE(x.hi && x.lo && y.hi && y.lo && x.c == y.c && x.c > 0 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0,
                  "dwconv_gelu: views must have c, ld multiples of 8");
     const int64_t P = (int64_t)BT * H * W;
     const int groups = x.c / 8;
-    if (k == 1) {
-        hipLaunchKernelGGL(dwconv_gelu_kernel<1>, dim3(ceil_div(P * groups, 256)), dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P, groups);
-    } else {
-        const int tiles_x = ceil_div(W, 16), tiles_y = ceil_div(H, 16);
-        hipLaunchKernelGGL(dwconv7_lds_kernel, dim3(tiles_x * tiles_y * BT, groups), dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W,
-                           tiles_x, tiles_y);
-    }
+    const dim3 grid(ceil_div(P * groups, 256));
+    // (an LDS-tiled 7x7 variant was measured 2.3x SLOWER than these L1/L2-served 16-byte loads: scalar LDS reads dominate)
+    if (k == 1)
+        hipLaunchKernelGGL(dwconv_gelu_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P, groups);
+    else
+        hipLaunchKernelGGL(dwconv_gelu_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P, groups);
     return ppms_check_launch("dwconv_gelu");
 }
 

@@ -32,6 +32,7 @@ TOP_K = 5
 # 2 = data-reuse tiling (conv_gemm2.hip, default); 1 = first-generation kernel (conv_gemm.hip), kept for A/B checks
 CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
+ATTN16_TORCH = os.environ.get("PPMS_ATTN16", "hip") == "torch"   # update_block16 time/space attention: HIP (default) or torch ops
 
 
 def pack_conv(*a, **k):
@@ -151,6 +152,17 @@ class PackedBlock:
         self.attn = None
         if "time_attn.temporal_fc.weight" in sd:
             self.attn = {k: g(k) for k in sd if k.startswith("time_attn.") or k.startswith("space_attn.")}
+            lin = lambda k: g(k)[:, :, None, None]                       # nn.Linear (out, in) as a 1x1 conv
+            ta, sa = "time_attn.", "space_attn.encoder_layer."
+            put("ta_proj", lin(ta + "temporal_attn.proj.weight"), g(ta + "temporal_attn.proj.bias"), [384])
+            put("ta_fc", lin(ta + "temporal_fc.weight"), g(ta + "temporal_fc.bias"), [384])
+            put("sa_qk", torch.cat([lin(sa + "q_proj.weight"), lin(sa + "k_proj.weight")], 0), None, [384])
+            put("sa_v", lin(sa + "v_proj.weight"), None, [384])
+            put("sa_merge", lin(sa + "merge.weight"), None, [384])
+            put("sa_mlp0", lin(sa + "mlp.0.weight"), None, [384, 384])
+            put("sa_mlp2", lin(sa + "mlp.2.weight"), None, [768])
+            self.ln = {k: (g(p_ + ".weight").contiguous(), g(p_ + ".bias").contiguous())
+                       for k, p_ in (("ta", ta + "temporal_norm1"), ("n1", sa + "norm1"), ("n2", sa + "norm2"))}
 
 
 class ScaleEngine:
@@ -172,6 +184,10 @@ class ScaleEngine:
         # update_block16 runs time / space attention on a COPY of x = [inp, mf, mfg] (the reference's inp_tensor is a
         # local of SequenceUpdateBlock3D.forward, ppmtereo_update.py:976-983: inp itself must survive the iteration)
         self.XA = sp(384) if pk.attn is not None else self.X
+        if pk.attn is not None:
+            self.O1, self.O2, self.XT, self.MSG, self.MSGN, self.H1 = sp(384), sp(384), sp(384), sp(384), sp(384), sp(768)
+            self.QKF, self.VF, self.M2, self.M3 = f32(P, 768), f32(P, 384), f32(P, 384), f32(P, 384)
+            self.KVWS = f32(4 * T * 8 * 48 * 49)
         self.Hb = [sp(128), sp(128), sp(128)]
         self.ZT, self.RT, self.RH, self.FH1, self.M1 = sp(128), sp(128), sp(128), sp(256), sp(256)
         self.Z, self.MASK, self.FLOW, self.QK = f32(P, 128), f32(P, 144), f32(P, 2), f32(P, 256)
@@ -251,6 +267,14 @@ class ScaleEngine:
                                            E(act=L.ACT_RELU, n_valid=64, out_sp=cf_next.view(256, 64)), m_split=128)
         o["to_v"] = self._conv("to_v", [mf], k1, E(n_valid=128, out_sp=self.VAL.view(), out_vt=self.VT))
         o["unc0"] = self._conv("unc0", [H[0].view(), self.VAL.view()], k3, E(act=L.ACT_RELU, n_valid=128, out_sp=self.U1.view()))
+        if self.pk.attn is not None:                 # update_block16: time / space attention on x = [inp, mf, mfg]
+            o["ta_proj"] = self._conv("ta_proj", [self.O1.view()], k1, E(n_valid=384, out_sp=self.O2.view()))
+            o["ta_fc"] = self._conv("ta_fc", [self.O2.view()], k1, E(L.EPI_RESID, n_valid=384, out_sp=self.XT.view(), aux_sp=X.view()))
+            o["sa_qk"] = self._conv("sa_qk", [self.XT.view()], k1, E(act=L.ACT_ELU1, n_valid=768, out_f32=self.QKF, out_f32_ld=768))
+            o["sa_v"] = self._conv("sa_v", [self.XT.view()], k1, E(scale=1.0 / self.n, n_valid=384, out_f32=self.VF, out_f32_ld=384))
+            o["sa_merge"] = self._conv("sa_merge", [self.MSG.view()], k1, E(n_valid=384, out_f32=self.M2, out_f32_ld=384))
+            o["sa_mlp0"] = self._conv("sa_mlp0", [self.XT.view(), self.MSGN.view()], k1, E(act=L.ACT_RELU, n_valid=768, out_sp=self.H1.view()))
+            o["sa_mlp2"] = self._conv("sa_mlp2", [self.H1.view()], k1, E(n_valid=384, out_f32=self.M3, out_f32_ld=384))
         x_all = self.XA.view()
         # GRU pass along W (two-layer z / r), then H, then T: h cycles through Hb[0] -> Hb[1] -> Hb[2] -> Hb[0]
         o["zr1_0"] = self._conv("zr1_0", [H[0].view(), x_all], (1, 1, 15), E(act=L.ACT_GELU, n_valid=128, out_sp=self.ZT.view()),
@@ -430,11 +454,29 @@ class ScaleEngine:
 
     def block16_attention(self):
         """TimeAttnBlock + SpaceAttnBlock on x = [inp, mf, mfg] (update_block16 only, ppmtereo_update.py:593-631,
-        980-983): 3.6 MFLOP/px on 1/16-scale pixels only -- fp32 torch-ROCm ops on the device-resident tensor."""
-        from .attn16 import time_space_attention
-        x = self.X.to_f32()                                                     # (P, 384)
-        x = time_space_attention(self.pk.attn, x, self.T, self.h, self.w)
-        self.XA.set_f32(x)
+        980-983): LayerNorm / temporal attention / linear-attention kernels (attn16.hip) + seven 1x1 GEMMs."""
+        if ATTN16_TORCH:                           # A/B path: fp32 torch-ROCm tensor ops (ppmstereo_amd/attn16.py)
+            from .attn16 import time_space_attention
+            x = self.X.to_f32()                                                 # (P, 384)
+            x = time_space_attention(self.pk.attn, x, self.T, self.h, self.w)
+            self.XA.set_f32(x)
+            return
+        o, s, lib, ln = self.op, self._s(), self.lib, self.pk.ln
+        none_sp = L.SP(None, None, 0, 0)
+        # TimeAttnBlock: x + fc(proj(attn_T(LN(x))))                                      ppmtereo_update.py:603-618
+        L.check(lib.ppms_time_attn(self.X.view(), ln["ta"][0].data_ptr(), ln["ta"][1].data_ptr(), self.O1.view(), self.T, self.n, 8, s))
+        o["ta_proj"]()
+        o["ta_fc"]()
+        # SpaceAttnBlock = LoFTR encoder layer with linear attention, x = source                 attention.py:164-190
+        o["sa_qk"]()
+        o["sa_v"]()
+        L.check(lib.ppms_linear_attention(self.QKF.data_ptr(), 768, self.QKF.data_ptr() + 384 * 4, 768, self.VF.data_ptr(), 384,
+                                          self.KVWS.data_ptr(), self.MSG.view(), self.T, self.n, 8, 48, s))
+        o["sa_merge"]()
+        L.check(lib.ppms_layernorm(self.M2.data_ptr(), 384, ln["n1"][0].data_ptr(), ln["n1"][1].data_ptr(), none_sp, self.MSGN.view(), self.P, 384, s))
+        o["sa_mlp0"]()
+        o["sa_mlp2"]()
+        L.check(lib.ppms_layernorm(self.M3.data_ptr(), 384, ln["n2"][0].data_ptr(), ln["n2"][1].data_ptr(), self.XT.view(), self.XA.view(), self.P, 384, s))
 
     def update(self):
         o = self.op
