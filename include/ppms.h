@@ -160,6 +160,13 @@ int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t*
  * processed by separate workgroups (ksel x more, smaller work units) and merged by a combine kernel; NULL = fused. */
 int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
 
+/* Fused chain of up to three per-pixel (1x1, <= 64 input channels) layers with GELU, optional residual from the chain
+ * input and optional depthwise-1x1 post step: the ffn1 / pw / ffn2 parts of PCBlock4_Deep_nopool_res
+ * (ppmtereo_update.py:1024-1030).  dev_params: device copy of the parameter block built by the host
+ * (ppmstereo_amd/engine.py: PwChain; layout checked with ppms_pwchain_param_bytes). */
+int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream);
+int ppms_pwchain_param_bytes(void);
+
 /* ---------------------------------------------------------------- update_block16 time / space attention pieces */
 /* TimeAttnBlock core (ppmtereo_update.py:603-606 with Attention.forward :409-417): per pixel, tokens = its T frames;
  * y = LayerNorm(x); out_t = sum_t2 softmax(y_t . y_t2 / sqrt(48)) y_t2 per head (q = k = v = y).  x, out: SP, 384 channels. */

@@ -34,6 +34,15 @@ class Conv(C.Structure):
                 ("M", C.c_int32), ("m_split", C.c_int32), ("epi", Epilogue * 2)]
 
 
+class ChainLayer(C.Structure):
+    _fields_ = [("w", c_void_p), ("bias", c_void_p), ("post_s", c_void_p), ("post_t", c_void_p),
+                ("M", C.c_int32), ("n_valid", C.c_int32), ("resid", C.c_int32)]
+
+
+class ChainParams(C.Structure):
+    _fields_ = [("inp", SP), ("out", SP), ("layer", ChainLayer * 3), ("nlayers", C.c_int32), ("P", C.c_int64)]
+
+
 _SIGS = {
     "ppms_version": (c_int, []),
     "ppms_last_error": (C.c_char_p, []),
@@ -63,6 +72,8 @@ _SIGS = {
     "ppms_qam_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppms_attn_prep_q": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_attn_prep_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppms_pwchain": (c_int, [c_void_p, c_int64, c_void_p]),
+    "ppms_pwchain_param_bytes": (c_int, []),
     "ppms_time_attn": (c_int, [SP, c_void_p, c_void_p, SP, c_int, c_int, c_int, c_void_p]),
     "ppms_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, SP, SP, c_int64, c_int, c_void_p]),
     "ppms_linear_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, SP, c_int, c_int, c_int, c_int, c_void_p]),
@@ -98,6 +109,8 @@ def load() -> C.CDLL:
     lib.ppms_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
     if (a.value, b.value, c.value) != (C.sizeof(SP), C.sizeof(Epilogue), C.sizeof(Conv)):
         raise RuntimeError("ppmstereo_amd: ctypes struct layout differs from include/ppms.h")
+    if lib.ppms_pwchain_param_bytes() != C.sizeof(ChainParams):
+        raise RuntimeError("ppmstereo_amd: ChainParams layout differs from pwchain.hip")
     _lib = lib
     return lib
 

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppms.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["corr.hip", "conv_gemm.hip", "conv_gemm2.hip", "conv_gemm3.hip", "small_ops.hip", "mem_attn.hip", "attn16.hip"]
+SOURCES = ["corr.hip", "conv_gemm.hip", "conv_gemm2.hip", "conv_gemm3.hip", "small_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 

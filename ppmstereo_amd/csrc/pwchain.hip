@@ -1,0 +1,160 @@
+// Fused chain of per-pixel (1x1) layers of PCBlock4_Deep_nopool_res (/root/reference/models/core/ppmtereo_update.py:1024-1030):
+//   chain A:  x1 = gelu(x + ffn1.2(gelu(ffn1.0 x)));  x2 = gelu(x1 + dw1x1(x1))            (ffn1 + first conv_list entry)
+//   chain B:  x4 = gelu(x3 + pw x3);  cor = gelu(ffn2.2(gelu(ffn2.0 x4)))                      (pw + ffn2 + the encoder's outer gelu)
+// Every layer has <= 64 input channels, so a 128-pixel tile keeps its activations in LDS (split bf16 rows, the MFMA B
+// operand format) from layer to layer: one launch replaces three implicit-GEMM launches plus the depthwise 1x1 kernel.
+// Same arithmetic as the unfused path (bf16x3 split MFMA, fp32 accumulate, erf GELU).
+#include "common.h"
+
+namespace {
+
+constexpr int TP = 128;                      // pixels per workgroup
+constexpr int ROWB = 64;                     // bytes per LDS row: 32 channels x bf16
+constexpr int ACT_PLANE = TP * ROWB;         // one 32-channel half (k-step) of one plane: 8 KiB
+constexpr int ACT_BUF = 4 * ACT_PLANE;       // [kstep 2][plane 2][128 px][64 B] = 32 KiB
+constexpr int W_BLK = 2 * 2 * 64 * 64;       // one 64-cout block x K = 64: [kstep 2][plane 2][64][64 B] = 16 KiB
+
+__device__ __forceinline__ int swzp(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+
+struct Layer {
+    const void* w;          // packed [kstep 2][M/64][plane 2][64][32] (pack_conv2 of a 1x1 conv with 64 padded inputs)
+    const float* bias;      // [M]
+    const float* post_s;    // optional per-channel affine applied after the activation: y = gelu(y + y*s + t)   (dw 1x1)
+    const float* post_t;
+    int M;                  // padded couts (64 or 256)
+    int n_valid;            // real couts
+    int resid;              // 1: add the layer-chain INPUT x (same channel) before the activation
+};
+
+struct ChainParams {
+    ppms_sp in, out;
+    Layer layer[3];
+    int nlayers;
+    int64_t P;
+};
+
+__global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restrict__ cp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ChainParams& c = *cp;
+    char* bufX = smem;                        // chain input (kept for the residual)
+    char* bufA = smem + ACT_BUF;              // ping
+    char* bufB = smem + 2 * ACT_BUF;          // pong
+    char* wsm = smem + 3 * ACT_BUF;           // one 64-cout weight block
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * TP;
+
+    // ---- stage the input tile: [kstep][plane][px][64 B], 16-B chunks swizzled ------------------------------------
+    for (int q = tid; q < TP * 8; q += 256) {                  // 8 chunks (64 channels) per pixel and plane
+        const int px = q >> 3, ch = q & 7;
+        const int64_t pix = p0 + px;
+        u32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
+        if (pix < c.P) {
+            vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
+            vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
+        }
+        const int off = (ch >> 2) * 2 * ACT_PLANE + swzp(px, ch & 3);
+        *(u32x4*)(bufX + off) = vh;
+        *(u32x4*)(bufX + ACT_PLANE + off) = vl;
+    }
+    const char* src = bufX;
+    for (int l = 0; l < c.nlayers; ++l) {
+        const Layer& L = c.layer[l];
+        const bool last = (l == c.nlayers - 1);
+        char* dst = (src == bufA) ? bufB : bufA;
+        const int mblocks = L.M / 64;
+        for (int mblk = 0; mblk < mblocks; ++mblk) {
+            __syncthreads();                                      // previous users of wsm / producers of src are done
+            // weight block: k-step ks of block mblk lives at ((ks * mblocks + mblk) * 8 KiB) in the packed tensor
+            for (int q = tid; q < W_BLK / 16; q += 256) {
+                const int ks = q >> 9, rem = q & 511;             // 512 chunks (8 KiB) per k-step
+                *(u32x4*)(wsm + q * 16) = gload16((const char*)L.w + ((int64_t)(ks * mblocks + mblk) * 512 + rem) * 16);
+            }
+            __syncthreads();
+            // wave w: 64 couts x pixels [32 w, 32 w + 32)
+            f32x16 acc[2];
+            acc[0] = (f32x16){0};
+            acc[1] = (f32x16){0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int k16 = 0; k16 < 2; ++k16) {
+                    const int boff = ks * 2 * ACT_PLANE + swzp(wave * 32 + r, 2 * k16 + h);
+                    const bf16x8 bh = *(const bf16x8*)(src + boff);
+                    const bf16x8 bl = *(const bf16x8*)(src + ACT_PLANE + boff);
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb) {
+                        const int aoff = ks * 8192 + swzp(mb * 32 + r, 2 * k16 + h);
+                        const bf16x8 ah = *(const bf16x8*)(wsm + aoff);
+                        const bf16x8 al = *(const bf16x8*)(wsm + 4096 + aoff);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[mb], 0, 0, 0);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[mb], 0, 0, 0);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[mb], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- epilogue of this 64-cout block: lane = pixel wave*32 + r, couts cl = mb*32 + 8 g + 4 h + j -------------
+            const int px = wave * 32 + r;
+            const int64_t pix = p0 + px;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = mb * 32 + 8 * g + 4 * h;          // within the block
+                    const int cg = mblk * 64 + cl;                    // global cout
+                    const f32x4 b4 = *(const f32x4*)(L.bias + cg);
+                    float y[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = acc[mb][4 * g + j] + b4[j];
+                    if (L.resid) {                                     // chain input x at the same channels (M == 64 here)
+                        const int xo = (cl >> 5) * 2 * ACT_PLANE + swzp(px, (cl & 31) >> 3) + (cl & 7) * 2;
+                        const bf16x4 xh = *(const bf16x4*)(bufX + xo), xl = *(const bf16x4*)(bufX + ACT_PLANE + xo);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] += join_bf16(xh[j], xl[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = gelu_erf(y[j]);
+                    if (L.post_s != nullptr) {
+                        const f32x4 s4 = *(const f32x4*)(L.post_s + cg), t4 = *(const f32x4*)(L.post_t + cg);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) y[j] = gelu_erf(y[j] + (y[j] * s4[j] + t4[j]));
+                    }
+                    bf16x4 oh, ol;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bf16_t hh = (bf16_t)0.0f, ll = (bf16_t)0.0f;
+                        if (cg + j < L.n_valid) split_bf16(y[j], hh, ll);   // padded couts stay exactly zero
+                        oh[j] = hh;
+                        ol[j] = ll;
+                    }
+                    if (last) {
+                        if (pix < c.P && cg < L.n_valid) {
+                            *(bf16x4*)((bf16_t*)c.out.hi + pix * c.out.ld + cg) = oh;
+                            *(bf16x4*)((bf16_t*)c.out.lo + pix * c.out.ld + cg) = ol;
+                        }
+                    } else {
+                        const int xo = (cl >> 5) * 2 * ACT_PLANE + swzp(px, (cl & 31) >> 3) + (cl & 7) * 2;
+                        *(bf16x4*)(dst + xo) = oh;
+                        *(bf16x4*)(dst + ACT_PLANE + xo) = ol;
+                    }
+                }
+        }
+        src = dst;
+    }
+}
+
+}  // namespace
+
+extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
+    PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");
+    constexpr size_t lds = 3 * ACT_BUF + W_BLK;                // 112 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)pwchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params);
+    return ppms_check_launch("pwchain");
+}
+
+extern "C" int ppms_pwchain_param_bytes(void) { return (int)sizeof(ChainParams); }

@@ -32,6 +32,7 @@ TOP_K = 5
 # 2 = data-reuse tiling (conv_gemm2.hip, default); 1 = first-generation kernel (conv_gemm.hip), kept for A/B checks
 CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
+USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
 ATTN16_TORCH = os.environ.get("PPMS_ATTN16", "hip") == "torch"   # update_block16 time/space attention: HIP (default) or torch ops
 
 
@@ -90,6 +91,27 @@ def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Opt
     e.aux_f32 = None if aux_f32 is None else aux_f32.data_ptr()
     e.aux_f32_ld = aux_f32_ld
     return e
+
+
+class PwChain:
+    """One fused per-pixel layer chain launch (pwchain.hip): host parameter block + device copy."""
+
+    def __init__(self, inp: L.SP, out: L.SP, layers, pixels: int, keep: list):
+        cp = L.ChainParams()
+        cp.inp, cp.out, cp.nlayers, cp.P = inp, out, len(layers), pixels
+        for i, (pack, n_valid, resid, post) in enumerate(layers):
+            packed, bias, meta = pack
+            assert meta["nk"] == 2 and meta["version"] == 2, "chain layers are 1x1 convs with 64 (padded) input channels"
+            ly = cp.layer[i]
+            ly.w, ly.bias, ly.M, ly.n_valid, ly.resid = packed.data_ptr(), bias.data_ptr(), meta["M"], n_valid, int(resid)
+            ly.post_s = None if post is None else post[0].data_ptr()
+            ly.post_t = None if post is None else post[1].data_ptr()
+            keep += [packed, bias]
+        self.pixels, self.keep = pixels, keep
+        self.dev = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).clone().cuda()
+
+    def __call__(self):
+        L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
 
 
 class PackedBlock:
@@ -252,6 +274,15 @@ class ScaleEngine:
         o = self.op
         self._qk_ops: Dict[int, ConvOp] = {}
         o["init0"] = self._conv("init0", [inp], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=self.ZT.view(0, 64)))
+        if USE_PWCHAIN and CONV_VERSION == 2:
+            w = self.pk.w
+            (w1, b1, _), _ = self.pk.dw
+            dw1 = (w1.reshape(64).contiguous(), b1)
+            # chain A: x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))      CORR -> C2
+            o["chainA"] = PwChain(self.CORR.view(), self.C2.view(), [(w["ffn1_0"], 54, False, None), (w["ffn1_2"], 36, True, dw1)], self.P, [dw1[0]])
+            # chain B: x4 = gelu(x3 + pw x3); cor = gelu(ffn2(x4))              C1 -> COR256
+            o["chainB"] = PwChain(self.C1.view(), self.COR256.view(), [(w["pw"], 36, True, None), (w["ffn2_0"], 54, False, None),
+                                                                       (w["ffn2_2"], 256, False, None)], self.P, [])
         o["ffn1_0"] = self._conv("ffn1_0", [self.CORR.view()], k1, E(act=L.ACT_GELU, n_valid=54, out_sp=self.T1.view()))
         o["ffn1_2"] = self._conv("ffn1_2", [self.T1.view()], k1, E(L.EPI_RESID, L.ACT_GELU, n_valid=36, out_sp=self.C1.view(), aux_sp=self.CORR.view()))
         o["pw"] = self._conv("pw", [self.C1.view()], k1, E(L.EPI_RESID, L.ACT_GELU, n_valid=36, out_sp=self.C2.view(), aux_sp=self.C1.view()))
@@ -405,14 +436,19 @@ class ScaleEngine:
             o["init0"]()
             o[f"init2_{par}"]()
             self.have_mhs = True
-        o["ffn1_0"]()
-        o["ffn1_2"]()
         (w1, b1, _), (w7, b7, _) = self.pk.dw
-        L.check(self.lib.ppms_dwconv_gelu(self.C1.view(0, 40), self.C2.view(0, 40), w1.data_ptr(), b1.data_ptr(), 1, self.T, self.h, self.w, s))
-        L.check(self.lib.ppms_dwconv_gelu(self.C2.view(0, 40), self.C1.view(0, 40), w7.data_ptr(), b7.data_ptr(), 7, self.T, self.h, self.w, s))
-        o["pw"]()
-        o["ffn2_0"]()
-        o["ffn2_2"]()
+        if "chainA" in o:                          # fused per-pixel chains around the depthwise 7x7 (pwchain.hip)
+            o["chainA"]()
+            L.check(self.lib.ppms_dwconv_gelu(self.C2.view(0, 40), self.C1.view(0, 40), w7.data_ptr(), b7.data_ptr(), 7, self.T, self.h, self.w, s))
+            o["chainB"]()
+        else:
+            o["ffn1_0"]()
+            o["ffn1_2"]()
+            L.check(self.lib.ppms_dwconv_gelu(self.C1.view(0, 40), self.C2.view(0, 40), w1.data_ptr(), b1.data_ptr(), 1, self.T, self.h, self.w, s))
+            L.check(self.lib.ppms_dwconv_gelu(self.C2.view(0, 40), self.C1.view(0, 40), w7.data_ptr(), b7.data_ptr(), 7, self.T, self.h, self.w, s))
+            o["pw"]()
+            o["ffn2_0"]()
+            o["ffn2_2"]()
         o[f"convc2_{par}"]()
         self._join()
         o[f"final_{par}"]()
