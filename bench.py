@@ -89,10 +89,12 @@ def main():
     torch.cuda.synchronize()
     assert torch.isfinite(disp).all()
 
-    # HIP events around every launch of the dominant kernel (memory attention at the 1/4 scale), on the stream it runs on
-    eng4 = model.update_block04.engine(T, H // 4, W // 4, dev)
+    # HIP events around EVERY launch of the dominant kernel (memory attention, all three scales), on the stream it runs on
+    engs = [(model.update_block16.engine(T, H // 16, W // 16, dev), iters // 2), (model.update_block08.engine(T, H // 8, W // 8, dev), iters // 2),
+            (model.update_block04.engine(T, H // 4, W // 4, dev), iters)]
     if not args.no_kernel_timing:
-        eng4.enable_attn_timing(args.steps * iters)
+        for e, n_it in engs:
+            e.enable_attn_timing(args.steps * n_it)
 
     D.barrier()
     torch.cuda.synchronize()
@@ -105,22 +107,29 @@ def main():
 
     px = T * H * W
     value = world * args.steps * px / elapsed
-    n4 = (H // 4) * (W // 4)
     ksel = min(5, T)
-    attn_flop = 4.0 * n4 * (ksel * n4) * 128 * T                 # one launch = all T clips
     roof = None
     if not args.no_kernel_timing:
-        ms = eng4.attn_times_ms()
-        avg = sum(ms) / len(ms)
-        ach = attn_flop / (avg * 1e-3) / 1e12
-        traffic = None            # HBM bytes per launch from the committed PMC passes (same kernel, same shape), if present
+        # algorithmic FLOPs of one launch = 4 * n * (ksel * n) * 128 * T (all T clips per launch)
+        tot_flop, tot_ms, n_launch, per_scale = 0.0, 0.0, 0, {}
+        for (e, n_it), sc in zip(engs, (16, 8, 4)):
+            ms = e.attn_times_ms()
+            fl = 4.0 * e.n * (ksel * e.n) * 128 * T
+            tot_flop += fl * len(ms)
+            tot_ms += sum(ms)
+            n_launch += len(ms)
+            per_scale[f"1/{sc}"] = dict(launches=len(ms), avg_ms=round(sum(ms) / len(ms), 4), flop_per_launch=fl,
+                                        tflops=round(fl / (sum(ms) / len(ms) * 1e-3) / 1e12, 1))
+        ach = tot_flop / (tot_ms * 1e-3) / 1e12
+        traffic = None            # HBM bytes per 1/4-scale launch from the committed PMC passes (same kernel, same shape), if present
         tfile = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
         if os.path.exists(tfile) and (T, H, W) == (5, 320, 512):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        roof = dict(bound="mfma", kernel="mem_attn_kernel + attn_combine_kernel (1/4 scale, all T clips and picked frames per launch)",
+        roof = dict(bound="mfma", kernel="mem_attn_kernel (+ attn_combine_kernel of split mode), every launch of the timed region "
+                                         "(3 scales: 1/16, 1/8, 1/4); algorithmic FLOPs = sum over launches of 4*n*(k*n)*128*T",
                     achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                    traffic=traffic, traffic_source="profiles/r01_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-                    launches=len(ms), avg_ms=round(avg, 4), flop_per_launch=attn_flop)
+                    traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/r01_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                    launches=n_launch, avg_ms=round(tot_ms / n_launch, 4), flop_per_launch=tot_flop / n_launch, per_scale=per_scale)
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
