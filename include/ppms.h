@@ -75,6 +75,10 @@ typedef struct ppms_epilogue {
     ppms_sp aux_sp;               /* residual / h                                                  */
     const float* aux_f32;         /* z                                                             */
     int32_t aux_f32_ld;
+    int32_t pre_f32_ld;
+    const float* pre_f32;         /* optional [pixel][pre_f32_ld]: added to acc + bias before the activation -- the
+                                   * contribution of input channels that do not change between iterations (computed
+                                   * once per scale by another launch of the same conv on those channels)         */
 } ppms_epilogue;
 
 typedef struct ppms_conv {

@@ -24,7 +24,8 @@ class SP(C.Structure):
 class Epilogue(C.Structure):
     _fields_ = [("kind", C.c_int32), ("act", C.c_int32), ("scale", c_float), ("n_valid", C.c_int32),
                 ("out_sp", SP), ("out_f32", c_void_p), ("out_f32_ld", C.c_int32), ("out_vt", c_void_p),
-                ("aux_sp", SP), ("aux_f32", c_void_p), ("aux_f32_ld", C.c_int32)]
+                ("aux_sp", SP), ("aux_f32", c_void_p), ("aux_f32_ld", C.c_int32), ("pre_f32_ld", C.c_int32),
+                ("pre_f32", c_void_p)]
 
 
 class Conv(C.Structure):

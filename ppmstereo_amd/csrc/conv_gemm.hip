@@ -206,6 +206,7 @@ extern "C" int ppms_conv_gemm(const ppms_conv* d, const ppms_conv* dev_desc, voi
         const ppms_epilogue& e = d->epi[hlf];
         if (hlf == 1 && d->m_split >= d->M) break;
         PPMS_REQUIRE(e.n_valid > 0, "conv_gemm: epilogue %d has n_valid=%d", hlf, e.n_valid);
+        PPMS_REQUIRE(e.pre_f32 == nullptr || (e.n_valid % 4 == 0 && e.pre_f32_ld % 4 == 0), "conv_gemm: pre_f32 needs n_valid and pre_f32_ld to be multiples of 4");
         if (e.out_sp.hi) PPMS_REQUIRE(e.out_sp.lo && e.out_sp.ld % 4 == 0 && ((uintptr_t)e.out_sp.hi & 7) == 0 && ((uintptr_t)e.out_sp.lo & 7) == 0,
                                       "conv_gemm: epilogue %d SP output misaligned", hlf);
         if (e.out_f32) PPMS_REQUIRE(e.out_f32_ld % 4 == 0 || e.kind == PPMS_EPI_ADDF32, "conv_gemm: epilogue %d f32 ld", hlf);

@@ -242,51 +242,85 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
                     }
         }
         __syncthreads();
+        if (kg == 0)
+            for (int k = 1; k < KG; ++k) {
+                const int src = ((k - 1) * 2 * WM + wave) * 64 * 64;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v4 = *(const f32x4*)(red + src + (((mb * 2 + nb) * 4 + q) * 64 + lane) * 4);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] += v4[e];
+                        }
+            }
+        __syncthreads();                     // the exchange area is reused as the epilogue's staging patches
         if (kg > 0) return;
-        for (int k = 1; k < KG; ++k) {
-            const int src = ((k - 1) * 2 * WM + wave) * 64 * 64;
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v4 = *(const f32x4*)(red + src + (((mb * 2 + nb) * 4 + q) * 64 + lane) * 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[mb][nb][4 * q + e] += v4[e];
-                    }
-        }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // ---- epilogue: accumulators -> wave-private LDS patch [32 px][64 couts] -> 8 couts of one pixel per lane -------
+    // (the loop's / the reduction's last barrier guarantees nobody still reads the operand stages reused here; from
+    // here on every wave touches only its own patch, and LDS operations of one wave execute in order)
     const int cblock = (mgrp * WM + wm) * 64;
     const int half = (cblock >= p.m_split) ? 1 : 0;
     const ppms_epilogue& e = p.epi[half];
     const int cbase = cblock - (half ? p.m_split : 0);
-    for (int it = 0; it < 16; ++it) {
-        const int nb = it >> 3, mb = (it >> 2) & 1, gq = it & 3;
-        float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float* stg = (float*)(smem + wave * STG_WAVE);
+    const int q = lane & 7;
+    float b8[8];
+    {
+        const f32x4 b0 = *(const f32x4*)(p.bias + cblock + q * 8), b1 = *(const f32x4*)(p.bias + cblock + q * 8 + 4);
 #pragma unroll
-        for (int s_nb = 0; s_nb < 2; ++s_nb)
-#pragma unroll
-            for (int s_mb = 0; s_mb < 2; ++s_mb)
-#pragma unroll
-                for (int s_g = 0; s_g < 4; ++s_g)
-                    if (it == s_nb * 8 + s_mb * 4 + s_g) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) a4[j] = acc[s_mb][s_nb][4 * s_g + j];
-                    }
-        const int pid = wn * 64 + nb * 32 + r;
-        const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
-        if (px < W && py < H) {
-            const int64_t pix = (int64_t)(tf * H + py) * W + px;
-            const int c4 = mb * 32 + 8 * gq + 4 * h;
-            const f32x4 b4 = *(const f32x4*)(p.bias + cblock + c4);
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = a4[j] + b4[j];
-            epilogue_group(e, v, pix, cbase + c4, HW);
+        for (int j = 0; j < 4; ++j) {
+            b8[j] = b0[j];
+            b8[4 + j] = b1[j];
         }
+    }
+#pragma unroll 1
+    for (int nb = 0; nb < 2; ++nb) {
+        if (e.out_vt != nullptr) {                                   // pixel-major V^T straight from the accumulator layout
+            const int pid = wn * 64 + nb * 32 + r;
+            const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+            const int64_t pix = (int64_t)(tf * H + py) * W + px;
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int c4 = mb * 32 + 8 * gq + 4 * h;
+                    const f32x4 bb = *(const f32x4*)(p.bias + cblock + c4);
+                    float v4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = (nb ? acc[mb][1][4 * gq + j] : acc[mb][0][4 * gq + j]) + bb[j];
+                    if (px < W && py < H) epilogue_vt4(e, v4, pix, cbase + c4, HW);
+                }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 a4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a4[j] = nb ? acc[mb][1][4 * gq + j] : acc[mb][0][4 * gq + j];
+                stage_write32(stg, r, h, mb, gq, a4);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int prow = it * 8 + (lane >> 3);
+            float v[8];
+            stage_read8(stg, prow, q, v);
+            const int pid = wn * 64 + nb * 32 + prow;
+            const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+            if (px < W && py < H) {
+                const int64_t pix = (int64_t)(tf * H + py) * W + px;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                epilogue_row8(e, v, pix, cbase + q * 8, HW);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -295,6 +329,8 @@ int launch2(const ppms_conv* d, const ppms_conv* dev_desc, const Geo2& g, int nt
     size_t lds = (size_t)KG * ((size_t)2 * WM * A_BLK + (size_t)g.bstages * 2 * g.Wr * 64);
     const size_t red = (size_t)(KG - 1) * 2 * WM * 64 * 64 * 4;          // partial-accumulator exchange reuses the staging area
     if (red > lds) lds = red;
+    const size_t stg = (size_t)2 * WM * STG_WAVE;                        // so do the epilogue's transposition patches
+    if (stg > lds) lds = stg;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv2_kernel<WM, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -330,6 +366,11 @@ extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, in
         const ppms_epilogue& e = d->epi[hlf];
         if (hlf == 1 && d->m_split >= d->M) break;
         PPMS_REQUIRE(e.n_valid > 0, "conv_gemm2: epilogue %d has n_valid=%d", hlf, e.n_valid);
+        PPMS_REQUIRE(e.pre_f32 == nullptr || (e.n_valid % 4 == 0 && e.pre_f32_ld % 4 == 0), "conv_gemm2: pre_f32 needs n_valid and pre_f32_ld to be multiples of 4");
+        {
+            const char* why = epilogue_row8_check(e);
+            PPMS_REQUIRE(why == nullptr, "conv_gemm2: epilogue %d: %s", hlf, why ? why : "");
+        }
         if (e.out_sp.hi) PPMS_REQUIRE(e.out_sp.lo && e.out_sp.ld % 4 == 0 && ((uintptr_t)e.out_sp.hi & 7) == 0 && ((uintptr_t)e.out_sp.lo & 7) == 0,
                                       "conv_gemm2: epilogue %d SP output misaligned", hlf);
         if (e.out_f32) PPMS_REQUIRE(e.out_f32_ld % 4 == 0 || e.kind == PPMS_EPI_ADDF32, "conv_gemm2: epilogue %d f32 ld", hlf);

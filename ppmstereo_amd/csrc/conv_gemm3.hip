@@ -203,37 +203,66 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv* __restri
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------
+    // ---- epilogue: accumulators -> wave-private LDS patch [32 px][64 couts] -> 8 couts of one pixel per lane -------
+    // (see conv_epilogue.h; the loop's last barrier freed the operand stages, each wave only touches its own patch)
     const int cblock = (mgrp * WM + wm) * 64;
     const int half = (cblock >= p.m_split) ? 1 : 0;
     const ppms_epilogue& e = p.epi[half];
     const int cbase = cblock - (half ? p.m_split : 0);
+    float* stg = (float*)(smem + wave * STG_WAVE);
+    const int q = lane & 7;
+    float b8[8];
+    {
+        const f32x4 b0 = *(const f32x4*)(p.bias + cblock + q * 8), b1 = *(const f32x4*)(p.bias + cblock + q * 8 + 4);
 #pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b8[j] = b0[j];
+            b8[4 + j] = b1[j];
+        }
+    }
+#pragma unroll 1
     for (int nb = 0; nb < 4; ++nb) {
-        const int pid = wn * 128 + nb * 32 + r;
-        const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
-        const bool inside = px < W && py < H;
-        const int64_t pix = (int64_t)(tf * H + py) * W + px;
-        for (int it = 0; it < 8; ++it) {                           // one copy of the epilogue code per nb, 8 trips
-            const int mb = it >> 2, gq = it & 3;
-            float a4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int s_mb = 0; s_mb < 2; ++s_mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int s_g = 0; s_g < 4; ++s_g)
-                    if (it == s_mb * 4 + s_g) {
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 a4;
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) a4[jj] = acc[s_mb][nb][4 * s_g + jj];
-                    }
-            if (inside) {
-                const int c4 = mb * 32 + 8 * gq + 4 * h;
-                const f32x4 b4 = *(const f32x4*)(p.bias + cblock + c4);
-                float v[4];
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[mb][0][4 * gq + j];
+                    x = (nb == 1) ? acc[mb][1][4 * gq + j] : x;
+                    x = (nb == 2) ? acc[mb][2][4 * gq + j] : x;
+                    x = (nb == 3) ? acc[mb][3][4 * gq + j] : x;
+                    a4[j] = x;
+                }
+                if (e.out_vt != nullptr) {                           // pixel-major V^T straight from the accumulator layout
+                    const int pid = wn * 128 + nb * 32 + r;
+                    const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+                    const int c4 = mb * 32 + 8 * gq + 4 * h;
+                    const f32x4 bb = *(const f32x4*)(p.bias + cblock + c4);
+                    float v4[4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) v[jj] = a4[jj] + b4[jj];
-                epilogue_group(e, v, pix, cbase + c4, HW);
+                    for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
+                    if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+                }
+                stage_write32(stg, r, h, mb, gq, a4);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int prow = it * 8 + (lane >> 3);
+            float v[8];
+            stage_read8(stg, prow, q, v);
+            const int pid = wn * 128 + nb * 32 + prow;
+            const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+            if (px < W && py < H) {
+                const int64_t pix = (int64_t)(tf * H + py) * W + px;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                epilogue_row8(e, v, pix, cbase + q * 8, HW);
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -268,6 +297,11 @@ extern "C" int ppms_conv_gemm3(const ppms_conv* d, const ppms_conv* dev_desc, vo
         const ppms_epilogue& e = d->epi[hlf];
         if (hlf == 1 && d->m_split >= d->M) break;
         PPMS_REQUIRE(e.n_valid > 0, "conv_gemm3: epilogue %d has n_valid=%d", hlf, e.n_valid);
+        PPMS_REQUIRE(e.pre_f32 == nullptr || (e.n_valid % 4 == 0 && e.pre_f32_ld % 4 == 0), "conv_gemm3: pre_f32 needs n_valid and pre_f32_ld to be multiples of 4");
+        {
+            const char* why = epilogue_row8_check(e);
+            PPMS_REQUIRE(why == nullptr, "conv_gemm3: epilogue %d: %s", hlf, why ? why : "");
+        }
         if (e.out_sp.hi) PPMS_REQUIRE(e.out_sp.lo && e.out_sp.ld % 4 == 0, "conv_gemm3: epilogue %d SP output misaligned", hlf);
         if (e.kind == PPMS_EPI_RESID || e.kind == PPMS_EPI_RH || e.kind == PPMS_EPI_GRU)
             PPMS_REQUIRE(e.aux_sp.hi && e.aux_sp.lo && e.aux_sp.ld % 4 == 0, "conv_gemm3: epilogue %d needs aux_sp", hlf);
@@ -322,7 +356,8 @@ extern "C" int ppms_conv_gemm3(const ppms_conv* d, const ppms_conv* dev_desc, vo
     g.n0 = d->seg[0].c / BK;
     g.mgroups = d->M / 128;
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
-    const size_t lds = (size_t)2 * A_STAGE + (size_t)2 * g.Wr * 64;
+    size_t lds = (size_t)2 * A_STAGE + (size_t)2 * g.Wr * 64;
+    if (lds < (size_t)4 * STG_WAVE) lds = (size_t)4 * STG_WAVE;          // the epilogue's transposition patches reuse the stages
     PPMS_REQUIRE(g.Wr <= 64 * MAXS && lds <= 80 * 1024, "conv_gemm3: window of %d rows does not fit", g.Wr);
     static bool attr_set = false;
     if (!attr_set) {

@@ -33,6 +33,7 @@ TOP_K = 5
 CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
+HOIST_INP = os.environ.get("PPMS_HOIST", "1") != "0"      # iteration-invariant inp share of the GRU gates computed once per scale
 ATTN16_TORCH = os.environ.get("PPMS_ATTN16", "hip") == "torch"   # update_block16 time/space attention: HIP (default) or torch ops
 
 
@@ -78,7 +79,7 @@ class ConvOp:
 
 
 def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Optional[L.SP] = None, out_f32=None, out_f32_ld=0,
-             out_vt=None, aux_sp: Optional[L.SP] = None, aux_f32=None, aux_f32_ld=0) -> L.Epilogue:
+             out_vt=None, aux_sp: Optional[L.SP] = None, aux_f32=None, aux_f32_ld=0, pre_f32=None, pre_off=0) -> L.Epilogue:
     e = L.Epilogue()
     e.kind, e.act, e.scale, e.n_valid = kind, act, scale, n_valid
     if out_sp is not None:
@@ -90,6 +91,8 @@ def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Opt
         e.aux_sp = aux_sp
     e.aux_f32 = None if aux_f32 is None else aux_f32.data_ptr()
     e.aux_f32_ld = aux_f32_ld
+    if pre_f32 is not None:                  # (P, ld) fp32, this half's columns start at pre_off
+        e.pre_f32, e.pre_f32_ld = pre_f32.data_ptr() + 4 * pre_off, pre_f32.shape[1]
     return e
 
 
@@ -163,6 +166,23 @@ class PackedBlock:
         # the (1,5,1) pass again with kh / kw swapped: k-step order of the y-swept large-map kernel (conv_gemm3.hip)
         put("zr2_y", cat(gr + "convz2.weight", gr + "convr2.weight").transpose(3, 4).contiguous(), cat(gr + "convz2.bias", gr + "convr2.bias"), [128, 384])
         put("q2_y", g(gr + "convq2.weight").transpose(3, 4).contiguous(), g(gr + "convq2.bias"), [128, 384])
+        # The GRU input is [h | inp, mf, mfg] (ppmtereo_update.py:292-310, 985-988) and inp does not change between the
+        # iterations of one scale: its share of every gate pre-activation is computed once per scale ("*_i" packs, with
+        # the bias) and added in the epilogue of the per-iteration convs over [h | mf, mfg] ("*_h" packs).  Not for
+        # update_block16, whose time / space attention rewrites all of x every iteration.
+        self.hoist = "time_attn.temporal_fc.weight" not in sd and CONV_VERSION == 2 and HOIST_INP
+        if self.hoist:
+            for name in ("zr1_0", "q1", "zr2", "q2", "zr3", "q3"):
+                if name.startswith("zr"):
+                    n_ = name[2:].replace("1_0", "1.0")
+                    wt, bs = cat(gr + f"convz{n_}.weight", gr + f"convr{n_}.weight"), cat(gr + f"convz{n_}.bias", gr + f"convr{n_}.bias")
+                else:
+                    wt, bs = g(gr + f"convq{name[1:]}.weight"), g(gr + f"convq{name[1:]}.bias")
+                w_h = torch.cat([wt[:, :128], wt[:, 256:]], 1).contiguous()
+                put(name + "_i", wt[:, 128:256].contiguous(), bs, [128])
+                put(name + "_h", w_h, None, [128, 256])
+                if name in ("zr2", "q2"):
+                    put(name + "_h_y", w_h.transpose(3, 4).contiguous(), None, [128, 256])
         put("fh1", g("flow_head.conv1.weight"), g("flow_head.conv1.bias"), [128])
         # flow_head.conv2 (256 -> 2, 3x3x3) as a 1x1 GEMM to 27*2 = 54 channels + shifted sum (ppms_tap_gather_sum)
         w2 = g("flow_head.conv2.weight")                                     # (2, 256, 3, 3, 3)
@@ -214,6 +234,10 @@ class ScaleEngine:
         self.ZT, self.RT, self.RH, self.FH1, self.M1 = sp(128), sp(128), sp(128), sp(256), sp(256)
         self.Z, self.MASK, self.FLOW, self.QK = f32(P, 128), f32(P, 144), f32(P, 2), f32(P, 256)
         self.DFLOW = f32(P, 4)
+        if pk.hoist:
+            self.PRE = {k: torch.empty(P, m, dtype=torch.float32, device=device) for k, m in
+                        (("zr1_0", 256), ("q1", 128), ("zr2", 256), ("q2", 128), ("zr3", 256), ("q3", 128))}
+            self._pre_stream, self._ev_pre, self._pre_pending = torch.cuda.Stream(device=device), torch.cuda.Event(), False
         self.FH2Y = f32(P, 64)
         self.VT = torch.zeros(T, 128, self.n, dtype=torch.bfloat16, device=device)
         self.QB = torch.zeros(T, self.n, 128, dtype=torch.bfloat16, device=device)
@@ -307,18 +331,28 @@ class ScaleEngine:
             o["sa_mlp0"] = self._conv("sa_mlp0", [self.XT.view(), self.MSGN.view()], k1, E(act=L.ACT_RELU, n_valid=768, out_sp=self.H1.view()))
             o["sa_mlp2"] = self._conv("sa_mlp2", [self.H1.view()], k1, E(n_valid=384, out_f32=self.M3, out_f32_ld=384))
         x_all = self.XA.view()
+        hoist = self.pk.hoist
+        if hoist:                                   # per-iteration convs see [h | mf, mfg]; the inp share comes from PRE
+            x_all = X.view(128, 256)
+            for k, kk in (("zr1_0", (1, 1, 15)), ("q1", (1, 1, 5)), ("zr2", (1, 5, 1)), ("q2", (1, 5, 1)), ("zr3", (5, 1, 1)), ("q3", (5, 1, 1))):
+                m = self.PRE[k].shape[1]
+                o["pre_" + k] = self._conv(k + "_i", [inp], kk, E(n_valid=m, out_f32=self.PRE[k], out_f32_ld=m))
+        sfx = "_h" if hoist else ""
+        pre = lambda k, off=0: dict(pre_f32=self.PRE[k], pre_off=off) if hoist else {}
         # GRU pass along W (two-layer z / r), then H, then T: h cycles through Hb[0] -> Hb[1] -> Hb[2] -> Hb[0]
-        o["zr1_0"] = self._conv("zr1_0", [H[0].view(), x_all], (1, 1, 15), E(act=L.ACT_GELU, n_valid=128, out_sp=self.ZT.view()),
-                                E(act=L.ACT_GELU, n_valid=128, out_sp=self.RT.view()), m_split=128)
+        o["zr1_0"] = self._conv("zr1_0" + sfx, [H[0].view(), x_all], (1, 1, 15), E(act=L.ACT_GELU, n_valid=128, out_sp=self.ZT.view(), **pre("zr1_0")),
+                                E(act=L.ACT_GELU, n_valid=128, out_sp=self.RT.view(), **pre("zr1_0", 128)), m_split=128)
         o["z1_2"] = self._conv("z1_2", [self.ZT.view()], (1, 1, 5), E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128))
         o["r1_2"] = self._conv("r1_2", [self.RT.view()], (1, 1, 5), E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[0].view()))
-        o["q1"] = self._conv("q1", [self.RH.view(), x_all], (1, 1, 5),
-                             E(L.EPI_GRU, n_valid=128, out_sp=H[1].view(), aux_sp=H[0].view(), aux_f32=self.Z, aux_f32_ld=128))
+        o["q1"] = self._conv("q1" + sfx, [self.RH.view(), x_all], (1, 1, 5),
+                             E(L.EPI_GRU, n_valid=128, out_sp=H[1].view(), aux_sp=H[0].view(), aux_f32=self.Z, aux_f32_ld=128, **pre("q1")))
         for n, kk, src, dst in (("2", (1, 5, 1), 1, 2), ("3", (5, 1, 1), 2, 0)):
-            o["zr" + n] = self._conv("zr" + n, [H[src].view(), x_all], kk, E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128),
-                                     E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[src].view()), m_split=128)
-            o["q" + n] = self._conv("q" + n, [self.RH.view(), x_all], kk,
-                                    E(L.EPI_GRU, n_valid=128, out_sp=H[dst].view(), aux_sp=H[src].view(), aux_f32=self.Z, aux_f32_ld=128))
+            o["zr" + n] = self._conv("zr" + n + sfx, [H[src].view(), x_all], kk,
+                                     E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128, **pre("zr" + n)),
+                                     E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[src].view(), **pre("zr" + n, 128)), m_split=128)
+            o["q" + n] = self._conv("q" + n + sfx, [self.RH.view(), x_all], kk,
+                                    E(L.EPI_GRU, n_valid=128, out_sp=H[dst].view(), aux_sp=H[src].view(), aux_f32=self.Z, aux_f32_ld=128,
+                                      **pre("q" + n)))
         o["fh1"] = self._conv("fh1", [H[0].view()], (3, 3, 3), E(act=L.ACT_RELU, n_valid=256, out_sp=self.FH1.view()))
         o["fh2"] = self._conv("fh2", [self.FH1.view()], k1, E(n_valid=54, out_f32=self.FH2Y, out_f32_ld=64))
         o["m1"] = self._conv("m1", [H[0].view()], k3, E(act=L.ACT_RELU, n_valid=256, out_sp=self.M1.view()))
@@ -340,6 +374,14 @@ class ScaleEngine:
 
     def set_inp(self, inp: torch.Tensor):
         self.load_nchw(inp, self.X.view(0, 128))
+        if self.pk.hoist:                          # inp share of the GRU gate pre-activations, once per scale, on its own stream
+            self._ev_fork.record()
+            self._pre_stream.wait_event(self._ev_fork)
+            with torch.cuda.stream(self._pre_stream):
+                for k in ("zr1_0", "q1", "zr2", "q2", "zr3", "q3"):
+                    self.op["pre_" + k]()
+                self._ev_pre.record()
+            self._pre_pending = True
 
     def set_net(self, net: torch.Tensor):
         self.load_nchw(net, self.Hb[0].view())
@@ -518,6 +560,9 @@ class ScaleEngine:
         o = self.op
         if self.pk.attn is not None:
             self.block16_attention()
+        if self.pk.hoist and self._pre_pending:
+            torch.cuda.current_stream().wait_event(self._ev_pre)
+            self._pre_pending = False
         o["zr1_0"]()
         with self._fork():
             o["r1_2"]()

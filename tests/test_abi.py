@@ -31,7 +31,7 @@ def test_struct_layout_matches_header():
     lib = L.load()
     a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.ppms_struct_sizes(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
-    assert (a.value, b.value, c.value) == (ctypes.sizeof(L.SP), ctypes.sizeof(L.Epilogue), ctypes.sizeof(L.Conv)) == (24, 104, 312)
+    assert (a.value, b.value, c.value) == (ctypes.sizeof(L.SP), ctypes.sizeof(L.Epilogue), ctypes.sizeof(L.Conv)) == (24, 112, 328)
 
 
 def test_argument_errors_are_reported_not_raised_in_c():

@@ -71,7 +71,7 @@ def test_ops_refuse_cpu_tensors(lib):
 
 
 # ------------------------------------------------------------------------------------------------ conv GEMM
-def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0):
+def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None):
     """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
     from ppmstereo_amd.engine import ConvOp, epilogue
     from ppmstereo_amd.packing import pack_conv as pack1, pack_conv2
@@ -102,6 +102,11 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
         zt[:, :cout] = z.to(DEV)
         e.aux_f32, e.aux_f32_ld = zt.data_ptr(), meta["M"]
         keep.append(zt)
+    if pre is not None:                                      # iteration-invariant share of the pre-activation
+        pt = torch.zeros(P, meta["M"], device=DEV)
+        pt[:, :cout] = pre.to(DEV)
+        e.pre_f32, e.pre_f32_ld = pt.data_ptr(), meta["M"]
+        keep.append(pt)
     d = L.Conv()
     for i, s in enumerate(segs):
         d.seg[i] = s
@@ -207,6 +212,29 @@ def test_conv_gemm3_vs_torch(lib, name, T, H, W, segs, cout, k3):
     z = torch.sigmoid(hash_normal((P, cout), 304))
     got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=3, kind=lib.EPI_GRU, aux=aux, z=z)
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
+@pytest.mark.parametrize("version", [3, 2, 1])
+def test_conv_gemm_hoisted_input_share(lib, version):
+    """conv([h | inp | rest]) == conv_h_rest([h | rest]) + pre, pre = conv_inp(inp) + bias computed by another launch
+    (the engine hoists the inp share of the GRU gates out of the iteration loop): every epilogue adds pre_f32 to
+    acc + bias before its activation."""
+    L = lib
+    T, H, W, k3 = 2, 6, 128, (1, 1, 5)
+    P = T * H * W
+    h, inp, rest = hash_normal((P, 128), 400), hash_normal((P, 128), 401), hash_normal((P, 64), 402)
+    wt = hash_normal((128, 320, *k3), 403) / math.sqrt(320 * 5)
+    bs = hash_normal((128,), 404) * 0.1
+    full = _ref_conv([h, inp, rest], wt, bs, k3, T, H, W)
+    pre = _run_conv(L, [inp], wt[:, 128:256].contiguous(), bs, k3, T, H, W, version=version)
+    w_h = torch.cat([wt[:, :128], wt[:, 256:]], 1).contiguous()
+    aux = hash_normal((P, 128), 405)
+    z = torch.sigmoid(hash_normal((P, 128), 406))
+    run = lambda **k: _run_conv(L, [h, rest], w_h, None, k3, T, H, W, version=version, pre=pre, **k)
+    assert maxdiff(run(), full) < 5e-5
+    assert maxdiff(run(act=L.ACT_GELU), F.gelu(full)) < 5e-5
+    assert maxdiff(run(kind=L.EPI_RH, aux=aux), torch.sigmoid(full) * aux) < 5e-5
+    assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(full)) < 5e-5
 
 
 def test_conv_gemm_rejects_bad_descriptors(lib):
