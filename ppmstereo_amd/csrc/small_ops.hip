@@ -45,66 +45,102 @@ extern "C" int ppms_device_info(char* name, int name_cap, int* cu_count, int* cl
 
 // ------------------------------------------------------------------------------------------------ depthwise conv
 // y = gelu(x + dw_k(x) + b), PCBlock4_Deep_nopool_res.forward (ppmtereo_update.py:1026-1027)
-// one thread = one pixel x 8 channels: 16-byte loads of the hi and lo planes per tap (channel-last rows are contiguous)
+// one thread = a run of DW_PX pixels along x times 8 channels: per kernel row it loads the DW_PX + K - 1 window
+// positions once (16-byte loads of the hi and lo planes, channel-last rows are contiguous) and sweeps the K taps over
+// them from registers; the weights sit in LDS transposed to [tap][channel] (two b128 reads per tap).
+constexpr int DW_PX = 4;
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_gelu_kernel(ppms_sp x, ppms_sp y, const float* __restrict__ w, const float* __restrict__ b,
-                                                          int H, int W, int64_t P, int groups) {
+                                                          int H, int W, int64_t rows, int groups) {
+    __shared__ __attribute__((aligned(16))) float wl[K * K * 64];
+    const int C = groups * 8;
+    for (int i = threadIdx.x; i < K * K * C; i += 256) {
+        const int c = i % C, tap = i / C;
+        wl[tap * C + c] = w[c * K * K + tap];
+    }
+    __syncthreads();
+    const int rpr = (W + DW_PX - 1) / DW_PX;                       // runs per image row
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P * groups) return;
+    if (idx >= rows * rpr * groups) return;
     const int c0 = (int)(idx % groups) * 8;
-    const int64_t pix = idx / groups;
-    const int px = (int)(pix % W);
-    const int py = (int)((pix / W) % H);
+    const int64_t run = idx / groups;
+    const int px0 = (int)(run % rpr) * DW_PX;
+    const int64_t row = run / rpr;                                 // frame * H + y
+    const int py = (int)(row % H);
+    const int64_t pix0 = row * W + px0;
     const bf16_t* xh = (const bf16_t*)x.hi + c0;
     const bf16_t* xl = (const bf16_t*)x.lo + c0;
-    float acc[8], x0[8];
+    float acc[DW_PX][8], x0[DW_PX][8];
     {
-        const bf16x8 h8 = *(const bf16x8*)(xh + pix * x.ld), l8 = *(const bf16x8*)(xl + pix * x.ld);
+        const f32x4 b0 = *(const f32x4*)(b + c0), b1 = *(const f32x4*)(b + c0 + 4);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            x0[j] = join_bf16(h8[j], l8[j]);
-            acc[j] = b[c0 + j];
-        }
+        for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                acc[p][j] = j < 4 ? b0[j & 3] : b1[j & 3];
+                x0[p][j] = 0.0f;
+            }
     }
-    constexpr int R = K / 2;
+    constexpr int R = K / 2, NW = DW_PX + K - 1;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
         const int yy = py + ky - R;
         if ((unsigned)yy >= (unsigned)H) continue;
+        float win[NW][8];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) {
+            const int xx = px0 - R + i;
+            bf16x8 h8 = {0, 0, 0, 0, 0, 0, 0, 0}, l8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((unsigned)xx < (unsigned)W) {
+                const int64_t q = pix0 + (int64_t)(ky - R) * W + (i - R);
+                h8 = *(const bf16x8*)(xh + q * x.ld);
+                l8 = *(const bf16x8*)(xl + q * x.ld);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) win[i][j] = join_bf16(h8[j], l8[j]);
+        }
+        if (ky == R) {
+#pragma unroll
+            for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x0[p][j] = win[p + R][j];
+        }
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-            const int xx = px + kx - R;
-            if ((unsigned)xx >= (unsigned)W) continue;
-            const int64_t q = pix + (int64_t)(ky - R) * W + (kx - R);
-            const bf16x8 h8 = *(const bf16x8*)(xh + q * x.ld), l8 = *(const bf16x8*)(xl + q * x.ld);
+            const f32x4 w0 = *(const f32x4*)(wl + (ky * K + kx) * C + c0), w1 = *(const f32x4*)(wl + (ky * K + kx) * C + c0 + 4);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += w[(c0 + j) * K * K + ky * K + kx] * join_bf16(h8[j], l8[j]);
+            for (int p = 0; p < DW_PX; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[p][j] += (j < 4 ? w0[j & 3] : w1[j & 3]) * win[p + kx][j];   // out-of-image taps add 0 * w
         }
     }
-    bf16x8 oh, ol;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        bf16_t hi, lo;
-        split_bf16(gelu_erf(x0[j] + acc[j]), hi, lo);
-        oh[j] = hi;
-        ol[j] = lo;
+    for (int p = 0; p < DW_PX; ++p) {
+        if (px0 + p >= W) break;
+        bf16x8 oh, ol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            bf16_t hi, lo;
+            split_bf16(gelu_erf(x0[p][j] + acc[p][j]), hi, lo);
+            oh[j] = hi;
+            ol[j] = lo;
+        }
+        *(bf16x8*)((bf16_t*)y.hi + (pix0 + p) * y.ld + c0) = oh;
+        *(bf16x8*)((bf16_t*)y.lo + (pix0 + p) * y.ld + c0) = ol;
     }
-    *(bf16x8*)((bf16_t*)y.hi + pix * y.ld + c0) = oh;
-    *(bf16x8*)((bf16_t*)y.lo + pix * y.ld + c0) = ol;
 }
 
 extern "C" int ppms_dwconv_gelu(ppms_sp x, ppms_sp y, const float* w, const float* b, int k, int BT, int H, int W, void* stream) {
     PPMS_REQUIRE(k == 1 || k == 7, "dwconv_gelu: k=%d (only 1 and 7)", k);
-    PPMS_REQUIRE(x.hi && x.lo && y.hi && y.lo && x.c == y.c && x.c > 0 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0,
-                 "dwconv_gelu: views must have c, ld multiples of 8");
-    const int64_t P = (int64_t)BT * H * W;
+    PPMS_REQUIRE(x.hi && x.lo && y.hi && y.lo && x.c == y.c && x.c > 0 && x.c <= 64 && x.c % 8 == 0 && x.ld % 8 == 0 && y.ld % 8 == 0,
+                 "dwconv_gelu: views must have c <= 64 and c, ld multiples of 8");
+    const int64_t rows = (int64_t)BT * H;
     const int groups = x.c / 8;
-    const dim3 grid(ceil_div(P * groups, 256));
-    // (an LDS-tiled 7x7 variant was measured 2.3x SLOWER than these L1/L2-served 16-byte loads: scalar LDS reads dominate)
+    const dim3 grid(ceil_div(rows * ((W + DW_PX - 1) / DW_PX) * groups, 256));
     if (k == 1)
-        hipLaunchKernelGGL(dwconv_gelu_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P, groups);
+        hipLaunchKernelGGL(dwconv_gelu_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, rows, groups);
     else
-        hipLaunchKernelGGL(dwconv_gelu_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, P, groups);
+        hipLaunchKernelGGL(dwconv_gelu_kernel<7>, grid, dim3(256), 0, (hipStream_t)stream, x, y, w, b, H, W, rows, groups);
     return ppms_check_launch("dwconv_gelu");
 }
 

@@ -405,3 +405,130 @@ def test_mem_attn_sharp_softmax(lib):
         V = torch.cat([vt[0].float().cpu().t(), vt[1].float().cpu().t()], 0)
         ref = O.flash_attn_math(qb[i].float().cpu(), K, V, scale)
         assert maxdiff(raw[i].float(), ref) < 0.02 * ref.abs().max().item() + 1e-3
+
+
+# ------------------------------------------------------------------------------------------------ small fused ops
+@pytest.mark.parametrize("k", [7, 1])
+@pytest.mark.parametrize("BT,H,W,cv", [(2, 9, 18, 40), (1, 5, 7, 40), (3, 20, 32, 40), (1, 8, 64, 64)])
+def test_dwconv_gelu(lib, k, BT, H, W, cv):
+    """depthwise k x k conv + residual GELU (ppmtereo_update.py:1026-1027) on a channel view of an SP tensor."""
+    L = lib
+    P = BT * H * W
+    x = hash_normal((P, 64), 500)
+    w = torch.zeros(64, k * k)
+    b = torch.zeros(64)
+    w[:36] = hash_normal((36, k * k), 501) / k
+    b[:36] = hash_normal((36,), 502) * 0.1
+    xs, ys = L.SPTensor(P, 64, DEV), L.SPTensor(P, 64, DEV)
+    xs.set_f32(x.to(DEV))
+    wd, bd = w.to(DEV), b.to(DEV)
+    L.check(L.load().ppms_dwconv_gelu(xs.view(0, cv), ys.view(0, cv), wd.data_ptr(), bd.data_ptr(), k, BT, H, W, L.stream_ptr()))
+    torch.cuda.synchronize()
+    xq = xs.to_f32().cpu()                                                    # the split-bf16 planes hold ~16 mantissa bits
+    xi = xq[:, :cv].reshape(BT, H, W, cv).permute(0, 3, 1, 2)
+    ref = F.gelu(xi + F.conv2d(xi, w[:cv].reshape(cv, 1, k, k), b[:cv], padding=k // 2, groups=cv)).permute(0, 2, 3, 1).reshape(P, cv)
+    got = ys.to_f32().cpu()
+    assert maxdiff(got[:, :cv], ref) < 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got[:, cv:] == 0).all(), "channels outside the view must not be written"
+
+
+@pytest.mark.parametrize("T,H,W", [(3, 5, 9), (1, 4, 6), (5, 10, 16)])
+def test_tap_gather_sum(lib, T, H, W):
+    """FlowHead3D.conv2 (256 -> 2, 3x3x3) = 1x1 GEMM to 54 channels + shifted sum; checked against conv3d."""
+    L = lib
+    P = T * H * W
+    x = hash_normal((P, 256), 510)
+    wt = hash_normal((2, 256, 3, 3, 3), 511) / math.sqrt(256 * 27)
+    bs = hash_normal((2,), 512)
+    w1 = wt.permute(2, 3, 4, 0, 1).reshape(54, 256, 1, 1, 1).contiguous()       # row = tap * 2 + cout
+    y = _run_conv(L, [x], w1, None, (1, 1, 1), T, H, W)                          # (P, 54)
+    yd = torch.zeros(P, 64, device=DEV)
+    yd[:, :54] = y.to(DEV)
+    out = torch.zeros(P, 4, device=DEV)
+    bd = bs.to(DEV)
+    L.check(L.load().ppms_tap_gather_sum(yd.data_ptr(), 64, bd.data_ptr(), out.data_ptr(), 4, 2, 3, 3, 3, T, H, W, L.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = _ref_conv([x], wt, bs, (3, 3, 3), T, H, W)
+    assert maxdiff(out[:, :2], ref) < 3e-5
+
+
+def test_pwchain_vs_unfused_layers(lib):
+    """Fused per-pixel chains of the correlation encoder (pwchain.hip) against fp32 torch math of
+    PCBlock4_Deep_nopool_res.forward (ppmtereo_update.py:1024-1030), ragged pixel count."""
+    from ppmstereo_amd.engine import PwChain
+    from ppmstereo_amd.packing import pack_conv2
+    L = lib
+    P = 5 * 7 * 9 + 3
+    x = hash_normal((P, 36), 520)
+    mk = lambda co, ci, s: (hash_normal((co, ci, 1, 1), s) / math.sqrt(ci), hash_normal((co,), s + 1) * 0.1)
+    (w0, b0), (w2, b2), (wp, bp), (w3, b3), (w4, b4) = mk(54, 36, 521), mk(36, 54, 523), mk(36, 36, 525), mk(54, 36, 527), mk(256, 54, 529)
+    dws, dwt = hash_normal((36,), 531) * 0.5, hash_normal((36,), 532) * 0.1
+    pk = lambda w, b, ci: pack_conv2(w.to(DEV), b.to(DEV), [ci], [64])
+    xs, mid, out = L.SPTensor(P, 64, DEV), L.SPTensor(P, 64, DEV), L.SPTensor(P, 256, DEV)
+    xp = torch.zeros(P, 64)
+    xp[:, :36] = x
+    xs.set_f32(xp.to(DEV))
+    s64, t64 = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    s64[:36], t64[:36] = dws.to(DEV), dwt.to(DEV)
+    PwChain(xs.view(), mid.view(), [(pk(w0, b0, 36), 54, False, None), (pk(w2, b2, 54), 36, True, (s64, t64))], P, [])()
+    torch.cuda.synchronize()
+    lin = lambda v, w, b: v @ w.reshape(w.shape[0], -1).t() + b
+    x = xs.to_f32().cpu()[:, :36]
+    x1 = F.gelu(x + lin(F.gelu(lin(x, w0, b0)), w2, b2))
+    x2 = F.gelu(x1 + (x1 * dws + dwt))
+    got = mid.to_f32().cpu()
+    assert maxdiff(got[:, :36], x2) < 3e-5 * max(1.0, x2.abs().max().item())     # split-bf16 storage: ~2^-17 relative
+    assert (got[:, 36:] == 0).all()
+    # chain B on x2 (the engine runs the depthwise 7x7 in between): gelu(x + pw x) -> ffn2 -> outer gelu
+    PwChain(mid.view(), out.view(), [(pk(wp, bp, 36), 36, True, None), (pk(w3, b3, 36), 54, False, None), (pk(w4, b4, 54), 256, False, None)], P, [])()
+    torch.cuda.synchronize()
+    x2g = got[:, :36]
+    x4 = F.gelu(x2g + lin(x2g, wp, bp))
+    ref = F.gelu(lin(F.gelu(lin(x4, w3, b3)), w4, b4))
+    assert maxdiff(out.to_f32(), ref) < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("T,n", [(5, 640), (3, 77), (2, 1000)])
+def test_attn16_kernels(lib, T, n):
+    """TimeAttnBlock core, LayerNorm(+residual) and LinearAttention kernels (attn16.hip) vs fp32 torch math
+    (ppmtereo_update.py:593-631, attention.py:73-100)."""
+    L = lib
+    lb = L.load()
+    P, Cc, heads, d = T * n, 384, 8, 48
+    x = hash_normal((P, Cc), 540)
+    lw, lbias = 1 + 0.1 * hash_normal((Cc,), 541), 0.1 * hash_normal((Cc,), 542)
+    xs, o = L.SPTensor(P, Cc, DEV), L.SPTensor(P, Cc, DEV)
+    xs.set_f32(x.to(DEV))
+    lwd, lbd = lw.to(DEV), lbias.to(DEV)
+    L.check(lb.ppms_time_attn(xs.view(), lwd.data_ptr(), lbd.data_ptr(), o.view(), T, n, heads, L.stream_ptr()))
+    torch.cuda.synchronize()
+    tok = x.view(T, n, Cc).transpose(0, 1)
+    y = F.layer_norm(tok, (Cc,), lw, lbias, 1e-5).reshape(n, T, heads, d).permute(0, 2, 1, 3)
+    att = torch.softmax((y @ y.transpose(-2, -1)) * d ** -0.5, dim=-1)
+    ref = (att @ y).transpose(1, 2).reshape(n, T, Cc).transpose(0, 1).reshape(P, Cc)
+    assert maxdiff(o.to_f32(), ref) < 5e-5 * max(1.0, ref.abs().max().item())
+    # LayerNorm with and without residual
+    xd = x.to(DEV).contiguous()
+    none_sp = L.SP(None, None, 0, 0)
+    L.check(lb.ppms_layernorm(xd.data_ptr(), Cc, lwd.data_ptr(), lbd.data_ptr(), none_sp, o.view(), P, Cc, L.stream_ptr()))
+    torch.cuda.synchronize()
+    ln = F.layer_norm(x, (Cc,), lw, lbias, 1e-5)
+    rel = max(1.0, (x + ln).abs().max().item())                              # split-bf16 storage: ~2^-17 relative
+    assert maxdiff(o.to_f32(), ln) < 2e-5 * rel
+    o2 = L.SPTensor(P, Cc, DEV)
+    L.check(lb.ppms_layernorm(xd.data_ptr(), Cc, lwd.data_ptr(), lbd.data_ptr(), xs.view(), o2.view(), P, Cc, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert maxdiff(o2.to_f32(), xs.to_f32().cpu() + ln) < 2e-5 * rel
+    # linear attention: Q, K already elu()+1, V already / n
+    Q = (F.elu(hash_normal((P, Cc), 543)) + 1).contiguous()
+    K = (F.elu(hash_normal((P, Cc), 544)) + 1).contiguous()
+    V = (hash_normal((P, Cc), 545) / n).contiguous()
+    Qd, Kd, Vd = Q.to(DEV), K.to(DEV), V.to(DEV)
+    ws = torch.zeros(4 * T * heads * d * (d + 1), device=DEV)
+    L.check(lb.ppms_linear_attention(Qd.data_ptr(), Cc, Kd.data_ptr(), Cc, Vd.data_ptr(), Cc, ws.data_ptr(), o.view(), T, n, heads, d, L.stream_ptr()))
+    torch.cuda.synchronize()
+    q4, k4, v4 = (t.view(T, n, heads, d) for t in (Q, K, V))
+    KV = torch.einsum("nshd,nshv->nhdv", k4, v4)
+    Z = 1 / (torch.einsum("nlhd,nhd->nlh", q4, k4.sum(1)) + 1e-6)
+    ref = (torch.einsum("nlhd,nhdv,nlh->nlhv", q4, KV, Z) * n).reshape(P, Cc)
+    assert maxdiff(o.to_f32(), ref) < 5e-5 * max(1.0, ref.abs().max().item())
