@@ -9,6 +9,7 @@
 // to_v conv epilogue) so both MFMA operands are plain 8/16-byte LDS reads.  K rows are XOR-swizzled on 16-B chunks,
 // V^T rows on 8-B granules: all fragment reads are bank-conflict free.  Two LDS stages, register-staged prefetch.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -37,11 +38,18 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
                                                           float scale_log2, const float* __restrict__ beta_p, ppms_sp mf, ppms_sp mfg,
                                                           bf16_t* __restrict__ out_bf16, int n, float* __restrict__ part_o,
-                                                          float* __restrict__ part_ml) {
+                                                          float* __restrict__ part_ml, int32_t* __restrict__ redo, int redo_stride) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int clip = blockIdx.y;
+    if (redo != nullptr) {                       // fix-up pass behind mem_attn64_kernel: only flagged tiles are recomputed
+        int32_t* f = redo + (int64_t)(clip * gridDim.z + blockIdx.z) * redo_stride + blockIdx.x;
+        const int flagged = *f;
+        if (flagged == 0) return;                // (uniform)
+        __syncthreads();
+        if (tid == 0) *f = 0;                    // leave the flag array clean for the next launch
+    }
     const int q0 = blockIdx.x * (QW * NW) + wave * QW;
     const int qi = q0 + r;                       // this lane's query
     const int qc = qi < n ? qi : n - 1;          // clamped for loads
@@ -70,33 +78,49 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
     const int ntile = (nsplit > 1) ? it0 + tpf : ksel * tpf;
 
     u32x4 rk[4], rv[4];
-    auto load_tile = [&](int it) {
+    auto load_k = [&](int it) {
+        const int slot = it / tpf;
+        const int key0 = (it - slot * tpf) * KT;
+        // K': [clip][slot][key][128], 256-B rows; thread -> rows (tid>>4) + 16 i, chunk tid&15
+        const bf16_t* kbase = kb + ((int64_t)(clip * ksel + slot) * n) * D;
+        if (!TAIL || key0 + KT <= n) {           // whole tile inside the frame (always, when n % 64 == 0): no per-row guards
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rk[i] = gload16(kbase + (int64_t)(key0 + (tid >> 4) + 16 * i) * D + (tid & 15) * 8);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = key0 + (tid >> 4) + 16 * i;
+                rk[i] = key < n ? gload16(kbase + (int64_t)key * D + (tid & 15) * 8) : (u32x4){0, 0, 0, 0};
+            }
+        }
+    };
+    auto load_v = [&](int it) {
         const int slot = it / tpf;
         const int key0 = (it - slot * tpf) * KT;
         const int frame = sel[clip * 5 + slot];
-        // K': [clip][slot][key][128], 256-B rows; thread -> rows (tid>>4) + 16 i, chunk tid&15
-        const bf16_t* kbase = kb + ((int64_t)(clip * ksel + slot) * n) * D;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int key = key0 + (tid >> 4) + 16 * i;
-            rk[i] = key < n ? gload16(kbase + (int64_t)key * D + (tid & 15) * 8) : (u32x4){0, 0, 0, 0};
-        }
         // V^T: [frame][d][n], this tile = 64 keys (128 B) of every d row; thread -> d = (tid>>3) + 32 i, chunk tid&7
         const bf16_t* vbase = vt + (int64_t)frame * D * n;
+        if (!TAIL || (n_vec && key0 + KT <= n)) {   // 16-byte aligned rows and a whole tile: plain vector loads
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int d = (tid >> 3) + 32 * i;
-            rv[i] = load16_guard(vbase + (int64_t)d * n, key0 + (tid & 7) * 8, n, n_vec);
+            for (int i = 0; i < 4; ++i) rv[i] = gload16(vbase + (int64_t)((tid >> 3) + 32 * i) * n + key0 + (tid & 7) * 8);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int d = (tid >> 3) + 32 * i;
+                rv[i] = load16_guard(vbase + (int64_t)d * n, key0 + (tid & 7) * 8, n, n_vec);
+            }
         }
     };
-    auto store_tile = [&](int stage) {
+    auto store_k = [&](int stage) {
         char* ks = smem + stage * ATT_STAGE;
-        char* vs = ks + K_TILE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = (tid >> 4) + 16 * i;
             *(u32x4*)(ks + row * 256 + (((tid & 15) ^ (row & 15)) << 4)) = rk[i];
         }
+    };
+    auto store_v = [&](int stage) {
+        char* vs = smem + stage * ATT_STAGE + K_TILE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             // V^T row d holds 64 keys as 4 groups of 16; inside a group the keys are stored [0-3, 8-11 | 4-7, 12-15] so
@@ -112,17 +136,10 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
             *(u32x2*)(vs + d * 128 + (((2 * G + 1) ^ f) << 4) + 8 * e) = (u32x2){v[2], v[3]};
         }
     };
-
-    // one KV tile; MASKED is only instantiated for the last tile of a frame when n % 64 != 0, so the steady-state
-    // loop carries no per-key compare/select work (the softmax VALU stream, not the MFMA pipe, is the critical path:
-    // every v_cndmask / range fix-up removed here is ~1 % of the kernel)
-    auto process_tile = [&](const char* ks, const char* vs, int key0) {
-        // ---- S^T[key][query] = K Q^T ---------------------------------------------------------------
-        f32x16 st[2];
-        st[0] = (f32x16){0};
-        st[1] = (f32x16){0};
+    // k-steps [s0, s1) of S^T[key][query] = K Q^T for one staged K tile
+    auto s_steps = [&](const char* ks, f32x16 (&st)[2], int s0, int s1) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
+        for (int s = s0; s < s1; ++s) {
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk) {
                 const int row = kblk * 32 + r;
@@ -130,6 +147,8 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
                 st[kblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kblk], 0, 0, 0);
             }
         }
+    };
+    auto mask_tail = [&](f32x16 (&st)[2], int key0) {       // keys beyond the frame's last pixel (only when n % 64 != 0)
         if (TAIL && key0 + KT > n) {
 #pragma unroll
             for (int kblk = 0; kblk < 2; ++kblk)
@@ -139,12 +158,33 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
                     if (key >= n) st[kblk][g] = -INFINITY;
                 }
         }
+    };
+
+    // Software pipeline over the KV tiles.  The softmax VALU stream of a tile (~1400 issue cycles with its 32
+    // quarter-rate v_exp) is longer than the tile's 32 MFMAs (1024 cycles), and two resident workgroups tend to fall into
+    // lock step, so MFMA and VALU phases did not overlap (MFMA pipe 41 % busy).  Here one wave carries TWO score tiles:
+    // while the VALU works through softmax(S_j), the matrix pipe already computes S_{j+1} = K_{j+1} Q^T; K therefore
+    // runs one tile ahead of V in the two LDS stages.  Iteration j:
+    //     global loads K_{j+2}, V_{j+1} -> registers
+    //     S_{j+1} MFMAs  ||  max / exp / sum of S_j           (independent instruction streams, one basic block each side
+    //     O += V_j P_j                                          of the rare rescale branch)
+    //     registers -> LDS: K_{j+2} over K_j, V_{j+1} over V_{j-1};  one barrier
+    auto body = [&](int j, int nt, f32x16 (&cur)[2], f32x16 (&nxt)[2]) {
+        const int it = it0 + j;
+        const bool more1 = j + 1 < nt, more2 = j + 2 < nt;
+        if (more2) load_k(it + 2);
+        if (more1) load_v(it + 1);
+        const char* kn = smem + ((j + 1) & 1) * ATT_STAGE;              // K_{j+1} (stale data on the last tile: result unused)
+        const char* vs = smem + (j & 1) * ATT_STAGE + K_TILE;           // V_j
+        nxt[0] = (f32x16){0};
+        nxt[1] = (f32x16){0};
+        s_steps(kn, nxt, 0, 2);
         // ---- online softmax (fp32), one query per lane pair (r, r+32) --------------------------------
-        float mx = st[0][0];
+        float mx = cur[0][0];
 #pragma unroll
         for (int kblk = 0; kblk < 2; ++kblk)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, st[kblk][g]);
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, cur[kblk][g]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx * scale_log2);
         // rescale O and l only when some query of the wave raised its running max (wave-uniform branch); NaN scores
@@ -156,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
             for (int i = 0; i < 4; ++i) o[i] *= alpha;
             m_run = m_new;
         }
+        s_steps(kn, nxt, 2, 8);
         const float neg_m = -m_run;
         float psum = 0.0f;
 #pragma unroll
@@ -163,12 +204,12 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 // raw v_exp_f32: arguments are <= 0, results in [0,1]; values below 2^-126 flush to 0 (irrelevant for P)
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kblk][g], scale_log2, neg_m));
-                st[kblk][g] = p;
-                psum += p;
+                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[kblk][g], scale_log2, neg_m));
+                cur[kblk][g] = pe;
+                psum += pe;
             }
         l_run += psum;
-
+        mask_tail(nxt, ((it + 1) % tpf) * KT);
         // ---- O^T[d][query] += V^T P^T ; P^T fragments come straight from the S^T accumulators -------------
 #pragma unroll
         for (int kblk = 0; kblk < 2; ++kblk) {
@@ -176,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
             for (int s2 = 0; s2 < 2; ++s2) {
                 bf16x8 pf;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)st[kblk][8 * s2 + j];
+                for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)cur[kblk][8 * s2 + jj];
                 const int chunk = (kblk * 2 + s2) * 2 + h;
 #pragma unroll
                 for (int dblk = 0; dblk < 4; ++dblk) {
@@ -186,20 +227,28 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
                 }
             }
         }
+        if (more2) store_k(j & 1);
+        if (more1) store_v((j + 1) & 1);
+        __syncthreads();
     };
 
-    load_tile(it0);
-    store_tile(it0 & 1);
+    const int nt = ntile - it0;
+    f32x16 sa[2], sb[2];
+    load_k(it0);
+    load_v(it0);
+    store_k(0);
+    store_v(0);
+    if (nt > 1) load_k(it0 + 1);
     __syncthreads();
-    for (int it = it0; it < ntile; ++it) {
-        const bool more = it + 1 < ntile;
-        if (more) load_tile(it + 1);
-        const char* ks = smem + (it & 1) * ATT_STAGE;
-        const char* vs = ks + K_TILE;
-        const int key0 = (it % tpf) * KT;
-        process_tile(ks, vs, key0);
-        if (more) store_tile((it + 1) & 1);
-        __syncthreads();
+    sa[0] = (f32x16){0};
+    sa[1] = (f32x16){0};
+    s_steps(smem, sa, 0, 8);
+    mask_tail(sa, (it0 % tpf) * KT);
+    if (nt > 1) store_k(1);
+    __syncthreads();
+    for (int j = 0; j < nt; j += 2) {
+        body(j, nt, sa, sb);
+        if (j + 1 < nt) body(j + 1, nt, sb, sa);
     }
 
     // ---- epilogue: hid = bf16(O / l); mfg = mf + beta * hid ---------------------------------------------
@@ -250,6 +299,205 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
             *(bf16x4*)(gh + d) = oh;
             *(bf16x4*)(gl + d) = ol;
         }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 64 queries per wave, LDS-DMA ring (n % 64 == 0, split workspace given).
+//
+// What bounds the 32-query kernel above is not the matrix pipe: (1) it issues one ds_read_b128 per MFMA (each K / V^T
+// fragment feeds a single 32-query block); (2) its KV tile for iteration j+1 is requested at the start of iteration j and
+// must have arrived by its end -- a ~2 us round trip through L2 / Infinity Cache under load, against ~1 us of MFMA work;
+// (3) softmax VALU work and MFMAs of two co-resident waves do not overlap on this part (a wave streaming MFMAs starves
+// the other wave's VALU; independent VALU work of the SAME wave does issue under its MFMAs, ~6 ops per 32-cycle MFMA:
+// tools/probe/coissue_probe.hip).  This kernel addresses all three:
+//  * a wave owns TWO 32-query blocks: every fragment read feeds two MFMAs.  State = O^T (128 accumulator registers) +
+//    two S^T sub-tiles (2 x 32) + Q (64): the unified 512-register file, one wave per SIMD;
+//  * KV tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers) into a ring of FOUR 32 KiB
+//    stages, requested three tiles ahead and waited for with counted s_waitcnt vmcnt: >= 2 iterations of latency hiding.
+//    The DMA destination is lane-linear, so the bank-conflict swizzles are applied on the SOURCE chunk index; V^T needs
+//    no key permutation any more because the K rows are fed to the MFMA in an order (bits 2 and 3 of the row swapped)
+//    that makes every lane's 8 P values belong to 8 CONSECUTIVE keys;
+//  * the 64-key tile is consumed as two 32-key sub-tiles, software pipelined inside the wave: the matrix pipe computes S
+//    of the next sub-tile while the VALU runs exp / sum / bf16 of the current one, then O += V P.  One basic block;
+//  * above 256 registers the MFMA accumulators live in the accumulator half of the register file, which the VALU only
+//    reaches through copies, and the compiler puts such copies on the hot path as soon as ANY code multiplies O^T (the
+//    usual online-softmax rescale).  So O^T is never rescaled here: the softmax reference of a query is fixed to the
+//    maximum over the first 32 keys of the frame (an actual score: the largest P is >= 1, nothing underflows), later
+//    scores may exceed it by up to 2^60 (P, l and O carry that factor in fp32 / bf16, exponent range 2^127), and
+//    (O, m, l) go to the split workspace for attn_combine_kernel, which normalises.  A larger jump (or a NaN, T == 1)
+//    makes the workgroup raise a flag instead: the 32-query kernel, launched right after as a fix-up pass, recomputes
+//    exactly the flagged tiles with the classic online softmax and returns immediately everywhere else.
+constexpr int ATT_NS = 4;                   // LDS ring stages (K 16 KiB + V^T 16 KiB each)
+
+__device__ __forceinline__ void att_dma16(const void* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const PPMS_GLOBAL void*)(uintptr_t)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
+                                                            const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
+                                                            float scale_log2, int n, float* __restrict__ part_o, float* __restrict__ part_ml,
+                                                            int32_t* __restrict__ redo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QB = 2;                         // 32-query blocks per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int clip = blockIdx.y;
+    const int nsplit = gridDim.z;                 // one picked frame per workgroup (gridDim.z == ksel)
+    const int slot0 = (int)blockIdx.z;
+    const int q0 = blockIdx.x * (64 * NW) + wave * 64;
+    const int nt = n / KT;
+
+    bf16x8 qf[QB][8];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qi = q0 + b * 32 + r;
+        const int qc = qi < n ? qi : n - 1;
+        const bf16_t* qp = qb + ((int64_t)clip * n + qc) * D + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) qf[b][s] = *(const bf16x8*)(qp + 16 * s);
+    }
+    // ---- DMA sources of this thread (tile 0); LDS chunk q = i*256 + tid, i = 0..3 -----------------------------------
+    //  K tile: row = q >> 4 (key), LDS position q & 15 holds source chunk (q & 15) ^ (row & 15)
+    //  V^T tile: row d = q >> 3, LDS position q & 7 holds source chunk (q & 7) ^ ((d >> 1) & 7)     (chunk = 8 keys)
+    const char* ksrc = (const char*)(kb + ((int64_t)(clip * ksel + slot0) * n + (tid >> 4)) * D) + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);
+    const char* vsrc;
+    {
+        const int frame = sel[clip * 5 + slot0];
+        const int d = tid >> 3;
+        vsrc = (const char*)(vt + ((int64_t)frame * D + d) * n) + (((tid & 7) ^ ((d >> 1) & 7)) << 4);
+    }
+    const int64_t vrow32 = (int64_t)32 * n * 2;   // bytes between V^T rows d and d + 32
+    auto issue_tile = [&](int j) __attribute__((always_inline)) {
+        char* st = smem + (j & (ATT_NS - 1)) * ATT_STAGE + wave * 1024;
+        const char* kp = ksrc + (int64_t)j * KT * D * 2;
+        const char* vp = vsrc + (int64_t)j * KT * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) att_dma16(kp + i * 16 * D * 2, st + i * 4096);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) att_dma16(vp + i * vrow32, st + K_TILE + i * 4096);
+    };
+
+    f32x16 o[4][QB];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int b = 0; b < QB; ++b) o[i][b] = (f32x16){0};
+    float neg_m[QB], l_run[QB];
+    bool bail = false;
+
+    // K rows enter the MFMA with bits 2 and 3 of the row index swapped: S^T register g of lane half h then belongs to key
+    // 16 (g >> 3) + 8 h + (g & 7) of the sub-tile, i.e. a lane's 8 P values per PV step are 8 consecutive keys
+    const int rk_row = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
+    auto s_steps = [&](const char* ks, int kblk, f32x16 (&st)[QB], int s0, int s1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+            const int row = kblk * 32 + rk_row;
+            const bf16x8 kf = *(const bf16x8*)(ks + row * 256 + (((2 * s + h) ^ (row & 15)) << 4));
+#pragma unroll
+            for (int b = 0; b < QB; ++b) {
+                const f32x16 c = (s == 0) ? (f32x16){0} : st[b];
+                st[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][s], c, 0, 0, 0);
+            }
+        }
+    };
+    // one sub-step, ONE basic block: S of the next sub-tile (matrix pipe) || exp / sum / bf16 of the current one (VALU),
+    // then O += V P
+    auto substep = [&](const char* ks_next, int kblk_next, const char* vs, int kblk, f32x16 (&cur)[QB],
+                       f32x16 (&nxt)[QB]) __attribute__((always_inline)) {
+        s_steps(ks_next, kblk_next, nxt, 0, 8);
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            float psum = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                // raw v_exp_f32; values below 2^-126 flush to 0 (irrelevant for P)
+                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[b][g], scale_log2, neg_m[b]));
+                cur[b][g] = pe;
+                psum += pe;
+            }
+            l_run[b] += psum;
+            bail = bail || !(psum <= 0x1p60f);          // some score > reference + 60, or NaN: the fix-up pass redoes this tile
+        }
+        // O^T[d][query] += V^T P^T: one V^T fragment read feeds both query blocks
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pf[QB];
+#pragma unroll
+            for (int b = 0; b < QB; ++b)
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) pf[b][jj] = (bf16_t)cur[b][8 * s2 + jj];
+            const int chunk = (kblk * 2 + s2) * 2 + h;            // keys kblk*32 + 16 s2 + 8 h .. + 7
+#pragma unroll
+            for (int dblk = 0; dblk < 4; ++dblk) {
+                const int d = dblk * 32 + r;
+                const bf16x8 vf = *(const bf16x8*)(vs + d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4));
+#pragma unroll
+                for (int b = 0; b < QB; ++b) o[dblk][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b], o[dblk][b], 0, 0, 0);
+            }
+        }
+    };
+
+    // ring: iteration j requests tile j+3 (into the stage tile j-1 just left), computes with K_j, K_{j+1}, V_j, and ends
+    // with "tiles <= j+2 have landed" (counted vmcnt: only tile j+3's 8 DMAs of this thread may still be in flight) + barrier
+    issue_tile(0);
+    if (nt > 1) issue_tile(1);
+    if (nt > 2) issue_tile(2);
+    if (nt > 2)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 sa[QB], sb[QB];
+    s_steps(smem, 0, sa, 0, 8);
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {                // softmax reference: maximum over the first 32 keys of the frame
+        float mx = sa[b][0];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) mx = fmaxf(mx, sa[b][g]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        neg_m[b] = -(mx * scale_log2);
+        l_run[b] = 0.0f;
+    }
+    for (int j = 0; j < nt; ++j) {
+        const bool more3 = j + 3 < nt;
+        if (more3) issue_tile(j + 3);
+        const char* kc = smem + (j & (ATT_NS - 1)) * ATT_STAGE;             // K_j, V_j
+        const char* kn = smem + ((j + 1) & (ATT_NS - 1)) * ATT_STAGE;       // K_{j+1} (stale on the last tile: result unused)
+        const char* vs = kc + K_TILE;
+        substep(kc, 1, vs, 0, sa, sb);
+        substep(kn, 0, vs, 1, sb, sa);
+        if (more3)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- (O, m, l) -> this workgroup's partial slot; attn_combine_kernel finishes the softmax and the aggregation ------
+    if (__any(bail) && lane == 0) {               // both 128-query halves of this workgroup are redone by the fix-up pass
+        int32_t* f = redo + ((int64_t)(clip * nsplit + slot0) * gridDim.x + blockIdx.x) * 2;
+        f[0] = 1;
+        f[1] = 1;
+    }
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qi = q0 + b * 32 + r;
+        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32);
+        if (qi >= n) continue;
+        const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
+        float* po = part_o + row * D;
+#pragma unroll
+        for (int dblk = 0; dblk < 4; ++dblk)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v4 = {o[dblk][b][4 * g], o[dblk][b][4 * g + 1], o[dblk][b][4 * g + 2], o[dblk][b][4 * g + 3]};
+                *(f32x4*)(po + dblk * 32 + 8 * g + 4 * h) = v4;
+            }
+        if (h == 0) {
+            part_ml[row * 2] = -neg_m[b];
+            part_ml[row * 2 + 1] = l_tot;
+        }
+    }
 }
 
 // merges the per-frame partials of split mode: O = sum_s O_s 2^(m_s - m), l = sum_s l_s 2^(m_s - m); then the same
@@ -311,17 +559,38 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
     }
     const float scale_log2 = scale * 1.4426950408889634f;
     // split over the picked frames when a workspace is given (ppms_mem_attn_workspace_bytes) and there is more than one
-    const bool split = split_ws != nullptr && ksel > 1;
+    static const int qw_env = []() {
+        const char* e = getenv("PPMS_ATTN_QW");          // A/B switch: 32 = first-generation kernel (two waves per SIMD)
+        return e ? atoi(e) : 64;
+    }();
+    const bool use64 = qw_env != 32 && split_ws != nullptr && n % KT == 0;      // (its state lives in the workspace partials)
+    const bool split = use64 || (split_ws != nullptr && ksel > 1);
     float* part_o = split ? (float*)split_ws : nullptr;
     float* part_ml = split ? part_o + (size_t)T * ksel * n * D : nullptr;
-    dim3 grid(ceil_div(n, QW * NW), T, split ? ksel : 1);
     hipStream_t st = (hipStream_t)stream;
-    if (n % KT)
-        hipLaunchKernelGGL(mem_attn_kernel<true>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt, sel,
-                           ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml);
-    else
-        hipLaunchKernelGGL(mem_attn_kernel<false>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt, sel,
-                           ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml);
+    if (use64) {
+        static bool attr64 = false;
+        if (!attr64) {
+            (void)hipFuncSetAttribute((const void*)mem_attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
+            attr64 = true;
+        }
+        const int g64 = (int)ceil_div(n, 64 * NW);
+        int32_t* redo = (int32_t*)(part_ml + (size_t)T * ksel * n * 2);
+        (void)hipMemsetAsync(redo, 0, (size_t)T * ksel * g64 * 2 * sizeof(int32_t), st);
+        dim3 grid64(g64, T, ksel), grid32(ceil_div(n, QW * NW), T, ksel);
+        hipLaunchKernelGGL(mem_attn64_kernel, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+                           sel, ksel, scale_log2, n, part_o, part_ml, redo);
+        hipLaunchKernelGGL(mem_attn_kernel<false>, grid32, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+                           sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, redo, 2 * g64);
+    } else {
+        dim3 grid(ceil_div(n, QW * NW), T, split ? ksel : 1);
+        if (n % KT)
+            hipLaunchKernelGGL(mem_attn_kernel<true>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+                               sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, (int32_t*)nullptr, 0);
+        else
+            hipLaunchKernelGGL(mem_attn_kernel<false>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+                               sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, (int32_t*)nullptr, 0);
+    }
     if (split) {
         const int64_t total = (int64_t)T * n * 16;
         hipLaunchKernelGGL(attn_combine_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, part_o, part_ml, ksel, beta, mf, mfg,
@@ -330,4 +599,7 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
     return ppms_check_launch("mem_attn");
 }
 
-extern "C" int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n) { return (int64_t)T * ksel * n * (D + 2) * 4; }
+// partial O (T*ksel*n*128 fp32) + partial (m, l) (T*ksel*n*2 fp32) + redo flags of the 64-query kernel (2 per 256-query block)
+extern "C" int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n) {
+    return (int64_t)T * ksel * n * (D + 2) * 4 + (int64_t)T * ksel * ceil_div(n, 64 * NW) * 2 * 4;
+}
