@@ -144,12 +144,15 @@ class PackedBlock:
             b[:36] = g(c1 + f"conv_list.{i}.bias")
             self.dw.append((w.contiguous(), b.contiguous(), k))
         put("convc2", g(e + "convc2.weight"), g(e + "convc2.bias"), [256])
+        # 192-cout convs padded to 256 rows: lets the large-map kernel (128-cout groups) take them where it applies
+        put("convc2_p", g(e + "convc2.weight"), g(e + "convc2.bias"), [256], None, None, 256)
         # convf1 (7x7 on the 2-channel flow) runs as a 1x1 GEMM over the im2col patch [tap*2 + c], 98 -> 128
         wf1 = g(e + "convf1.weight").permute(0, 2, 3, 1).reshape(128, 98, 1, 1)
         put("convf1", wf1, g(e + "convf1.bias"), [98], [128])
         put("convf2", g(e + "convf2.weight"), g(e + "convf2.bias"), [128])
         # final_conv: couts 0..125 -> motion features (rows 0..125), couts 126..189 -> motion hidden state (rows 128..191)
         put("final", g(e + "final_conv.weight"), g(e + "final_conv.bias"), [320], None, list(range(126)) + list(range(128, 192)), 192)
+        put("final_p", g(e + "final_conv.weight"), g(e + "final_conv.bias"), [320], None, list(range(126)) + list(range(128, 192)), 256)
         put("to_v", g("aggregator.to_v.weight"), None, [128])
         put("unc0", g("uncertainty.0.weight"), g("uncertainty.0.bias"), [128, 128])
         self.unc2_w = g("uncertainty.2.weight").reshape(128).contiguous()
@@ -290,6 +293,14 @@ class ScaleEngine:
                 return ConvOp(d, [packed, bias, *keep], 3)
         return ConvOp(d, [packed, bias, *keep], version)
 
+    def _conv_padded(self, wname, *a, **k) -> ConvOp:
+        """wname + "_p" (couts padded to a multiple of 128) when the large-map kernel takes it, else the tight pack."""
+        if USE_CONV3 and CONV_VERSION == 2 and wname + "_p" in self.pk.w:
+            op = self._conv(wname + "_p", *a, **k)
+            if op.version == 3:
+                return op
+        return self._conv(wname, *a, **k)
+
     def _build_descriptors(self):
         E, X, H = epilogue, self.X, self.Hb
         k1, k3 = (1, 1, 1), (1, 3, 3)
@@ -316,9 +327,9 @@ class ScaleEngine:
         for par in (0, 1):
             cf, cf_next = self.CF[par], self.CF[1 - par]
             o[f"init2_{par}"] = self._conv("init2", [self.ZT.view(0, 64)], k3, E(n_valid=64, out_sp=cf.view(256, 64)))
-            o[f"convc2_{par}"] = self._conv("convc2", [self.COR256.view()], k3, E(act=L.ACT_RELU, n_valid=192, out_sp=cf.view(0, 192)))
+            o[f"convc2_{par}"] = self._conv_padded("convc2", [self.COR256.view()], k3, E(act=L.ACT_RELU, n_valid=192, out_sp=cf.view(0, 192)))
             o[f"convf2_{par}"] = self._conv("convf2", [self.FLO1.view()], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=cf.view(192, 64)))
-            o[f"final_{par}"] = self._conv("final", [cf.view()], k3, E(act=L.ACT_RELU, n_valid=126, out_sp=mf),
+            o[f"final_{par}"] = self._conv_padded("final", [cf.view()], k3, E(act=L.ACT_RELU, n_valid=126, out_sp=mf),
                                            E(act=L.ACT_RELU, n_valid=64, out_sp=cf_next.view(256, 64)), m_split=128)
         o["to_v"] = self._conv("to_v", [mf], k1, E(n_valid=128, out_sp=self.VAL.view(), out_vt=self.VT))
         o["unc0"] = self._conv("unc0", [H[0].view(), self.VAL.view()], k3, E(act=L.ACT_RELU, n_valid=128, out_sp=self.U1.view()))
