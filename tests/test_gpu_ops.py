@@ -381,8 +381,11 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split):
     assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 1e-4
 
 
-def test_mem_attn_sharp_softmax(lib):
-    """Forces the online-softmax rescale path: one key per query dominates and sits in a late tile."""
+@pytest.mark.parametrize("boost", [40.0, 3.0])
+def test_mem_attn_sharp_softmax(lib, boost):
+    """One key per query dominates and sits in a late tile.  boost = 40: the score jumps ~650 log2 units above the
+    first keys, far beyond what the rescale-free 64-query kernel carries (2^60): its workgroups raise their redo flags
+    and the 32-query online-softmax kernel recomputes them.  boost = 3: ~50 log2 units, carried in-kernel (P up to 2^50)."""
     L = lib
     from ppmstereo_amd.engine import softmax_scale
     T, n = 2, 512
@@ -390,7 +393,7 @@ def test_mem_attn_sharp_softmax(lib):
     k = hash_normal((T, 2, n, 128), 901) * 0.1
     v = hash_normal((T, 128, n), 902)
     for i in range(n):
-        k[0, 1, (i * 7 + 300) % n] += 40.0 * q[0, i] / q[0, i].norm()
+        k[0, 1, (i * 7 + 300) % n] += boost * q[0, i] / q[0, i].norm()
     qb, kb, vt = q.to(torch.bfloat16).to(DEV), k.to(torch.bfloat16).to(DEV), v.to(torch.bfloat16).to(DEV)
     sel = torch.tensor([[0, 1, 0, 0, 0], [0, 1, 0, 0, 0]], dtype=torch.int32, device=DEV)
     X = L.SPTensor(T * n, 256, DEV)

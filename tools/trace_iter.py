@@ -13,7 +13,17 @@ s16, s8, s4 = cb[-3], cb[-2], cb[-1]
 def seg(a, b, label):
     rs = rows[a:b]
     t0, t1 = int(rs[0]["Start_Timestamp"]), int(rs[-1]["End_Timestamp"])
-    print(f"{label}: kernels={len(rs)} wall_ms={(t1 - t0) / 1e6:.2f}")
+    iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rs)
+    busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+    for a, b in iv[1:]:
+        if a > cur_e:
+            busy += cur_e - cur_s
+            cur_s, cur_e = a, b
+        else:
+            cur_e = max(cur_e, b)
+    busy += cur_e - cur_s
+    print(f"{label}: kernels={len(rs)} wall_ms={(t1 - t0) / 1e6:.2f} busy_ms={busy / 1e6:.2f} (union of kernel intervals) "
+          f"sum_ms={sum(b - a for a, b in iv) / 1e6:.2f}")
     return rs
 
 
