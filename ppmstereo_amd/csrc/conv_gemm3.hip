@@ -8,11 +8,13 @@
 //     a linear 16 KiB copy of the pre-swizzled packed image; the activation window is gathered with per-lane source
 //     addresses (the XOR swizzle is applied on the SOURCE chunk index, the LDS destination stays lane-linear) and
 //     out-of-image rows read a zero page;
-//   * the activation window is swept along x (kw > 1) or along y (kw == 1, kh > 1): window = halo'd patch, tap s reads
-//     LDS row brow + s * tstride.
+//   * the activation window is a halo'd patch swept by the taps from LDS: along x (kh == 1), along y (kw == 1) or over
+//     all kh x kw taps (2-D halo): a window switch stalls the workgroup for a global -> LDS round trip, so the more
+//     taps share a window the better (3x3: one switch per 9 k-steps instead of per 3).
 // Workgroup = 4 waves (wm, wn); LDS = 2 x 16 KiB weight stages + one window (<= 40 KiB): two workgroups per CU.
-// Packed weights: pack_conv2 order, k-step = (rowstep * nchunk + chunk) * nsweep + s (y-sweep convs are packed with
-// their kh / kw axes swapped, see ppmstereo_amd/engine.py).
+// Packed weights: pack_conv2 order, k-step = (rowstep * nchunk + chunk) * nsweep + s: y-sweep convs are packed with
+// their kh / kw axes swapped, 2-D sweep convs with (ky, kx) flattened into the x axis (weight viewed as
+// (cout, cin, kt, 1, kh*kw)), see ppmstereo_amd/engine.py.
 #include "common.h"
 #include "conv_epilogue.h"
 
@@ -22,7 +24,7 @@ constexpr int BK = 32;
 constexpr int A_BLK = 64 * BK * 2 * 2;        // 8 KiB: one 64-cout block, hi + lo
 constexpr int WM = 2, NT = 256;
 constexpr int A_STAGE = WM * A_BLK;           // 16 KiB
-constexpr int MAXS = 5;                       // window 16-B chunks per thread and plane (window <= 320 rows)
+constexpr int MAXS = 6;                       // window 16-B chunks per thread and plane (window <= 384 rows)
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];      // zero-initialised: source of padded rows
 
@@ -32,10 +34,11 @@ struct Geo3 {
     int WRL;                 // window row length (pixels)
     int Wr;                  // window rows
     int hxw, hyw;            // halo of the window in x / y
-    int tstride;             // LDS row step per sweep tap (1: x sweep, WRL: y sweep)
-    int nsweep;              // taps swept inside one window (kw or kh)
-    int nrow;                // row-steps per chunk set: taps NOT swept (kt*kh for x sweep, kt for y sweep)
-    int rdy;                 // 1: row-step index carries a dy (x sweep), 0: only dt (y sweep)
+    int swx_n, row_jump;     // sweep: the LDS row advances by 1 per tap and by row_jump more after every swx_n taps
+                             //   x sweep: (nsweep, 0);  y sweep: (1, WRL - 1);  2-D sweep (kh x kw taps): (kw, WRL - kw)
+    int nsweep;              // taps swept inside one window (kw, kh or kh*kw)
+    int nrow;                // row-steps per chunk set: taps NOT swept (kt*kh for x sweep, kt otherwise)
+    int rdy;                 // 1: row-step index carries a dy (x sweep), 0: only dt
     int nchunk, n0;
     int mgroups;
 };
@@ -154,13 +157,12 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv* __restri
     dma_b(rs / g.nchunk, rs % g.nchunk);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int sw = 0;
+    int sw = 0, swx = 0, trow = 0;
     for (int j = 0; j < nsteps; ++j) {
         const bool more = j + 1 < nsteps;
         const bool need_b = more && (sw + 1 == g.nsweep);
         if (more) dma_a(need_b ? (rs + 1) * g.nsweep : rs * g.nsweep + sw + 1, (j + 1) & 1);
         const char* a_s = sA + (j & 1) * A_STAGE + wm * A_BLK;
-        const int trow = sw * g.tstride;
 #pragma unroll
         for (int k16 = 0; k16 < 2; ++k16) {
             bf16x8 ah[2], al[2], bh[4], bl[4];
@@ -196,10 +198,15 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv* __restri
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (need_b) {
-            sw = 0;
+            sw = swx = trow = 0;
             ++rs;
         } else {
             ++sw;
+            ++trow;
+            if (++swx == g.swx_n) {
+                swx = 0;
+                trow += g.row_jump;
+            }
         }
     }
 
@@ -271,8 +278,12 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv* __restri
 // returns 1 when the large-map kernel applies to this convolution (the caller then packs y-sweep convs with swapped axes)
 extern "C" int ppms_conv_gemm3_applicable(const ppms_conv* d) {
     if (d == nullptr || d->M % 128 != 0 || d->m_split % 64 != 0) return 0;
-    const bool xs = d->kw > 1, ys = d->kw == 1 && d->kh > 1;
-    if (!xs && !ys) return 0;
+    if (d->kw == 1 && d->kh == 1) return 0;
+    if (d->kw > 1 && d->kh > 1) {                            // 2-D window: some 256-pixel patch with its halo must fit
+        bool fits = false;
+        for (int C = 8; C <= 256; C *= 2) fits = fits || (256 / C + d->kh - 1) * (C + d->kw - 1) <= 64 * MAXS;
+        if (!fits) return 0;
+    }
     const int64_t P = (int64_t)d->T * d->H * d->W;
     if (P / 256 * (d->M / 128) < 384) return 0;              // fewer than ~1.5 workgroups per CU: conv_gemm2's smaller tiles fill the chip better
     return 1;
@@ -307,7 +318,8 @@ extern "C" int ppms_conv_gemm3(const ppms_conv* d, const ppms_conv* dev_desc, vo
             PPMS_REQUIRE(e.aux_sp.hi && e.aux_sp.lo && e.aux_sp.ld % 4 == 0, "conv_gemm3: epilogue %d needs aux_sp", hlf);
         if (e.kind == PPMS_EPI_GRU) PPMS_REQUIRE(e.aux_f32 != nullptr, "conv_gemm3: GRU epilogue needs z");
     }
-    const bool xs = d->kw > 1;
+    const int mode = (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);      // 0: x sweep, 1: y sweep, 2: 2-D sweep
+    const int hx = mode != 1 ? d->kw - 1 : 0, hy = mode != 0 ? d->kh - 1 : 0;   // window halo (total) in x / y
     Geo3 g;
     // patch shape: x sweep wants wide patches (halo = kw-1 columns per row), y sweep tall ones (halo = kh-1 rows);
     // among the shapes whose window fits, take the one wasting the fewest pixels, then the smallest window
@@ -316,7 +328,7 @@ extern "C" int ppms_conv_gemm3(const ppms_conv* d, const ppms_conv* dev_desc, vo
     int bestWr = 1 << 30;
     for (int C = 8; C <= 256; C *= 2) {
         const int R = 256 / C;
-        const int Wr = xs ? R * (C + d->kw - 1) : (R + d->kh - 1) * C;
+        const int Wr = (R + hy) * (C + hx);
         if (Wr > 64 * MAXS || C < 8) continue;
         const double waste = (double)((d->W + C - 1) / C * C) * ((d->H + R - 1) / R * R) / ((double)d->W * d->H);
         if (waste < bestw - 1e-9 || (waste < bestw + 1e-9 && Wr < bestWr)) {
@@ -332,22 +344,26 @@ extern "C" int ppms_conv_gemm3(const ppms_conv* d, const ppms_conv* dev_desc, vo
     while ((1 << g.logC) < g.C) ++g.logC;
     g.tiles_x = (d->W + g.C - 1) / g.C;
     g.tiles_y = (d->H + g.R - 1) / g.R;
-    if (xs) {
-        g.WRL = g.C + d->kw - 1;
-        g.Wr = g.R * g.WRL;
-        g.hxw = d->kw >> 1;
-        g.hyw = 0;
-        g.tstride = 1;
+    g.WRL = g.C + hx;
+    g.Wr = (g.R + hy) * g.WRL;
+    g.hxw = hx >> 1;
+    g.hyw = hy >> 1;
+    if (mode == 0) {
+        g.swx_n = d->kw;
+        g.row_jump = 0;
         g.nsweep = d->kw;
         g.nrow = d->kt * d->kh;
         g.rdy = 1;
-    } else {
-        g.WRL = g.C;
-        g.Wr = (g.R + d->kh - 1) * g.C;
-        g.hxw = 0;
-        g.hyw = d->kh >> 1;
-        g.tstride = g.C;
+    } else if (mode == 1) {
+        g.swx_n = 1;
+        g.row_jump = g.WRL - 1;
         g.nsweep = d->kh;
+        g.nrow = d->kt;
+        g.rdy = 0;
+    } else {
+        g.swx_n = d->kw;
+        g.row_jump = g.WRL - d->kw;
+        g.nsweep = d->kh * d->kw;
         g.nrow = d->kt;
         g.rdy = 0;
     }

@@ -126,6 +126,11 @@ class PackedBlock:
 
         def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
             self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
+            w5 = weight if weight.dim() == 5 else weight[:, :, None]
+            if CONV_VERSION == 2 and w5.shape[3] > 1 and w5.shape[4] > 1 and (m_pad or w5.shape[0]) % 128 == 0:
+                # k-step order of the large-map kernel's 2-D window sweep: (ky, kx) flattened into the x axis
+                flat = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, w5.shape[3] * w5.shape[4]).contiguous()
+                self.w[name + "_2d"] = pack_conv(flat, bias, segs, seg_pad, cout_map, m_pad)
 
         e = "encoder."
         put("init0", g(e + "init_conv.0.weight"), g(e + "init_conv.0.bias"), [128])
@@ -284,13 +289,13 @@ class ScaleEngine:
             d.epi[1] = epi1
         version = meta.get("version", 1)
         if version == 2 and USE_CONV3 and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
-            if k3[2] == 1 and k3[1] > 1:                                   # y sweep: needs the axis-swapped pack
-                if wname + "_y" in self.pk.w:
-                    packed_y, bias_y, _ = self.pk.w[wname + "_y"]
-                    d.w, d.bias = packed_y.data_ptr(), bias_y.data_ptr()
-                    return ConvOp(d, [packed_y, bias_y, *keep], 3)
-            else:
-                return ConvOp(d, [packed, bias, *keep], 3)
+            # the large-map kernel wants its k-steps in sweep order: y-swept convs packed with kh / kw swapped ("_y"),
+            # 2-D swept ones (kh, kw > 1) with (ky, kx) flattened into x ("_2d"); without such a pack: conv_gemm2
+            key = wname + "_2d" if (k3[1] > 1 and k3[2] > 1) else wname + "_y" if (k3[2] == 1 and k3[1] > 1) else wname
+            if key in self.pk.w:
+                packed3, bias3, _ = self.pk.w[key]
+                d.w, d.bias = packed3.data_ptr(), bias3.data_ptr()
+                return ConvOp(d, [packed3, bias3, *keep], 3)
         return ConvOp(d, [packed, bias, *keep], version)
 
     def _conv_padded(self, wname, *a, **k) -> ConvOp:

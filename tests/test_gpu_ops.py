@@ -87,6 +87,9 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     wpack = weight
     if version == 3 and k3[2] == 1 and k3[1] > 1:            # y-swept large-map kernel: pack with kh / kw swapped
         wpack = (weight if weight.dim() == 5 else weight[:, :, None]).transpose(3, 4).contiguous()
+    if version == 3 and k3[2] > 1 and k3[1] > 1:             # 2-D swept: (ky, kx) flattened into the x axis
+        w5 = weight if weight.dim() == 5 else weight[:, :, None]
+        wpack = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, k3[1] * k3[2]).contiguous()
     packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad)
     cout = weight.shape[0]
     out = L.SPTensor(P, meta["M"], DEV)
@@ -194,6 +197,8 @@ CONV3_CASES = [
     ("y_1x5x1", 2, 40, 32, [128, 32], 256, (1, 5, 1)),
     ("y_w80", 1, 23, 80, [64], 128, (1, 5, 1)),
     ("x_w80_1x5", 2, 7, 80, [64], 128, (1, 1, 5)),
+    ("3x3_w80_ragged", 2, 23, 80, [32, 32], 128, (1, 3, 3)),
+    ("3x3x3_odd", 3, 11, 50, [64], 128, (3, 3, 3)),
 ]
 
 
