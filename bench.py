@@ -125,7 +125,7 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
         if os.path.exists(tfile) and (T, H, W) == (5, 320, 512):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        roof = dict(bound="mfma", kernel="mem_attn_kernel (+ attn_combine_kernel of split mode), every launch of the timed region "
+        roof = dict(bound="mfma", kernel="memory attention (mem_attn64_kernel + its fix-up pass + attn_combine_kernel = one ppms_mem_attn call), every call of the timed region "
                                          "(3 scales: 1/16, 1/8, 1/4); algorithmic FLOPs = sum over launches of 4*n*(k*n)*128*T",
                     achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
                     traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/r01_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
