@@ -100,9 +100,12 @@ int ppms_conv_gemm(const ppms_conv* desc, const ppms_conv* dev_desc, void* strea
  * by the kw taps).  Same descriptor; desc->w must be in the pack_conv2 layout (ppmstereo_amd/packing.py).
  * wm_hint: 64-cout blocks per workgroup (1..4), 0 = let the library choose from the grid size. */
 int ppms_conv_gemm2(const ppms_conv* desc, const ppms_conv* dev_desc, int wm_hint, void* stream);
-/* Large-map variant (128 couts x 256 pixels per workgroup, LDS-DMA operands, x- or y-swept activation window).
- * ppms_conv_gemm3_applicable() tells whether it serves a descriptor (M % 128 == 0, kw > 1 or kh > 1, enough tiles);
- * weights in pack_conv2 order -- for kw == 1 convs (swept along y) packed with the kh / kw axes swapped. */
+/* Large-map variant (128 couts x 256 pixels per workgroup, LDS-DMA operands, activation window swept by the taps along
+ * x, along y, or over all kh x kw taps).  ppms_conv_gemm3_applicable() tells whether it serves a descriptor
+ * (M % 128 == 0, kw > 1 or kh > 1, the halo'd window fits, enough tiles).  Weights in pack_conv2 order with the k-steps
+ * in sweep order: kw == 1 convs (swept along y) packed with the kh / kw axes swapped; kh > 1 and kw > 1 convs packed
+ * with (ky, kx) flattened into the x axis, i.e. from the weight viewed as (cout, cin, kt, 1, kh*kw).  desc->kh / kw
+ * stay the true extents. */
 int ppms_conv_gemm3_applicable(const ppms_conv* desc);
 int ppms_conv_gemm3(const ppms_conv* desc, const ppms_conv* dev_desc, void* stream);
 /* sizeof(ppms_sp), sizeof(ppms_epilogue), sizeof(ppms_conv) as compiled: lets a foreign-language binding check its
@@ -160,8 +163,11 @@ int ppms_attn_prep_k(const float* key, int ld, const float* pe, const int32_t* s
  * sel); mf / mfg: SP views (128 channels).  out_bf16 (optional): bf16 [T][n][128] raw attention output. */
 int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
                   ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, void* stream);
-/* split_ws (optional, caller-owned, ppms_mem_attn_workspace_bytes(T, ksel, n) bytes): when given, the picked frames are
- * processed by separate workgroups (ksel x more, smaller work units) and merged by a combine kernel; NULL = fused. */
+/* split_ws (optional, caller-owned, ppms_mem_attn_workspace_bytes(T, ksel, n) bytes, contents need not be
+ * initialised): when given, every picked frame is processed by its own workgroups, which leave fp32 partials
+ * (O, m, l) in the workspace, and a combine kernel merges them; with n % 64 == 0 this is the 64-queries-per-wave
+ * LDS-DMA kernel (rescale-free accumulation + a fix-up pass for tiles it flags, see mem_attn.hip).  NULL = one fused
+ * launch of the 32-query online-softmax kernel. */
 int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
 
 /* Fused chain of up to three per-pixel (1x1, <= 64 input channels) layers with GELU, optional residual from the chain
