@@ -100,6 +100,14 @@ int ppms_conv_gemm(const ppms_conv* desc, const ppms_conv* dev_desc, void* strea
  * by the kw taps).  Same descriptor; desc->w must be in the pack_conv2 layout (ppmstereo_amd/packing.py).
  * wm_hint: 64-cout blocks per workgroup (1..4), 0 = let the library choose from the grid size. */
 int ppms_conv_gemm2(const ppms_conv* desc, const ppms_conv* dev_desc, int wm_hint, void* stream);
+/* K-sliced form of the same kernel for small maps (1/16 and 1/8 scales: fewer workgroups than CUs, long K loops):
+ * nslice workgroups share each output tile and leave fp32 partial sums in `workspace` (caller-owned,
+ * ppms_conv_gemm2_slice_workspace_bytes() bytes), a second launch sums them in slice order (deterministic) and runs the
+ * fused epilogue.  ppms_conv_gemm2_slices() returns the slice count that pays off for a descriptor (1: use
+ * ppms_conv_gemm2).  Not for epilogues with out_vt. */
+int ppms_conv_gemm2_slices(const ppms_conv* desc);
+int64_t ppms_conv_gemm2_slice_workspace_bytes(const ppms_conv* desc, int nslice);
+int ppms_conv_gemm2_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream);
 /* Large-map variant (128 couts x 256 pixels per workgroup, LDS-DMA operands, activation window swept by the taps along
  * x, along y, or over all kh x kw taps).  ppms_conv_gemm3_applicable() tells whether it serves a descriptor
  * (M % 128 == 0, kw > 1 or kh > 1, the halo'd window fits, enough tiles).  Weights in pack_conv2 order with the k-steps

@@ -32,6 +32,9 @@ struct Geo2 {
     int nk;                  // k-steps = kt*kh*nchunk*kw
     int mgroups;             // M / (64*WM)
     int bstages;             // 2: window double-buffered; 1: single window + one extra barrier per window switch
+    int nslice;              // grid-level K slices (gridDim.y): slice s takes the row-steps s*KG + kg, + KG*nslice, ...
+    float* part;             // nslice > 1: fp32 partial sums [slice][pixel][M] (no bias), finished by conv_slice_reduce_kernel
+    int64_t P;               // pixels = T*H*W
 };
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
@@ -156,8 +159,9 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     const int kz1 = (ht + T - 1 - tf) < (p.kt - 1) ? (ht + T - 1 - tf) : (p.kt - 1);
     const int rs_per_kz = p.kh * g.nchunk;
     const int rs_end = (kz1 + 1) * rs_per_kz;
-    int rs = kz0 * rs_per_kz + kg;            // row-step = trow * nchunk + chunk; this K-group takes every KG-th one
-    const int nsteps = ((rs_end - kz0 * rs_per_kz) / KG) * p.kw;     // identical for every K-group (nchunk % KG == 0)
+    const int kstride = KG * g.nslice;        // row-step = trow * nchunk + chunk; K-group kg of slice s takes every kstride-th one
+    int rs = kz0 * rs_per_kz + (int)blockIdx.y * KG + kg;
+    const int nsteps = ((rs_end - kz0 * rs_per_kz) / kstride) * p.kw;     // identical for every group (kh*nchunk % kstride == 0)
     {
         const int trow = rs / g.nchunk;
         load_a(rs * p.kw);
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         const bool more = j + 1 < nsteps;
         const bool need_b = more && (kx + 1 == p.kw);
         if (more) {
-            const int nrs = need_b ? rs + KG : rs;
+            const int nrs = need_b ? rs + kstride : rs;
             load_a(nrs * p.kw + (need_b ? 0 : kx + 1));
             if (need_b) {
                 const int trow = nrs / g.nchunk;
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         if (need_b) {
             bsel = (g.bstages == 1) ? 0 : (bsel ^ 1);
             kx = 0;
-            rs += KG;
+            rs += kstride;
         } else {
             ++kx;
         }
@@ -315,13 +319,49 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
             const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
             if (px < W && py < H) {
                 const int64_t pix = (int64_t)(tf * H + py) * W + px;
+                if (g.nslice > 1) {                                  // K-sliced launch: raw partial sums, finished by the reduce kernel
+                    float* pp = g.part + ((int64_t)blockIdx.y * g.P + pix) * p.M + cblock + q * 8;
+                    const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                    *(f32x4*)pp = o0;
+                    *(f32x4*)(pp + 4) = o1;
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += b8[j];
-                epilogue_row8(e, v, pix, cbase + q * 8, HW);
+                    for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                    epilogue_row8(e, v, pix, cbase + q * 8, HW);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// Second half of a K-sliced convolution: sums the slices' partial tiles in slice order (deterministic), adds the bias and
+// runs the conv's own fused epilogue.  One thread = one pixel x 8 couts (coalesced 32-byte reads per slice).
+__global__ __launch_bounds__(256) void conv_slice_reduce_kernel(const ppms_conv* __restrict__ pd, const float* __restrict__ part, int nslice,
+                                                                int64_t P) {
+    const ppms_conv& p = *pd;
+    const int groups = p.M >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * groups) return;
+    const int c8 = (int)(idx % groups) * 8;
+    const int64_t pix = idx / groups;
+    float v[8];
+    {
+        const f32x4 b0 = *(const f32x4*)(p.bias + c8), b1 = *(const f32x4*)(p.bias + c8 + 4);
+        f32x4 s0 = {0.0f, 0.0f, 0.0f, 0.0f}, s1 = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int s = 0; s < nslice; ++s) {
+            const float* pp = part + ((int64_t)s * P + pix) * p.M + c8;
+            s0 += *(const f32x4*)pp;
+            s1 += *(const f32x4*)(pp + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = s0[j] + b0[j];
+            v[4 + j] = s1[j] + b1[j];
+        }
+    }
+    const int half = (c8 >= p.m_split) ? 1 : 0;
+    epilogue_row8(p.epi[half], v, pix, c8 - (half ? p.m_split : 0), p.H * p.W);
 }
 
 template <int WM, int KG>
@@ -340,14 +380,56 @@ int launch2(const ppms_conv* d, const ppms_conv* dev_desc, const Geo2& g, int nt
         ppms_set_error("conv_gemm2: LDS budget exceeded (%zu B)", lds);
         return PPMS_EINVAL;
     }
-    hipLaunchKernelGGL((conv2_kernel<WM, KG>), dim3(ntiles * g.mgroups), dim3(128 * WM * KG), lds, stream, dev_desc, g);
+    hipLaunchKernelGGL((conv2_kernel<WM, KG>), dim3(ntiles * g.mgroups, g.nslice), dim3(128 * WM * KG), lds, stream, dev_desc, g);
     return ppms_check_launch("conv_gemm2");
 }
 
 }  // namespace
 
+static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, int nslice, float* part, void* stream);
+
 // wm_hint: 0 = choose (all couts per workgroup when the grid still fills the chip, otherwise 64-cout blocks)
 extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, void* stream) {
+    return conv2_launch(d, dev_desc, wm_hint, 1, nullptr, stream);
+}
+
+// Small maps (fewer workgroups than the chip has CUs, long K loops): how many grid-level K slices pay off.  1 = none.
+extern "C" int ppms_conv_gemm2_slices(const ppms_conv* d) {
+    if (d == nullptr || d->nseg < 1 || d->nseg > 2 || d->M <= 0 || d->M % 64 != 0) return 1;
+    if (d->epi[0].out_vt != nullptr || (d->m_split < d->M && d->epi[1].out_vt != nullptr)) return 1;   // V^T is written from the accumulators
+    int nchunk = 0;
+    for (int s = 0; s < d->nseg; ++s) nchunk += d->seg[s].c / BK;
+    const int64_t P = (int64_t)d->T * d->H * d->W;
+    const int64_t nwg = (P + 127) / 128 * (d->M / 64);              // 64-cout x 128-pixel workgroups without slicing
+    if (nwg >= 512) return 1;
+    const int rs_per_kz = d->kh * nchunk;
+    const int64_t steps = (int64_t)d->kt * rs_per_kz * d->kw;        // k-steps of the whole K loop
+    int best = 1;
+    for (int s = 2; s <= 8; ++s)
+        if (rs_per_kz % s == 0 && nwg * s <= 1024 && steps / s >= 6) best = s;
+    return best;
+}
+
+extern "C" int64_t ppms_conv_gemm2_slice_workspace_bytes(const ppms_conv* d, int nslice) {
+    if (d == nullptr || nslice <= 1) return 0;
+    return (int64_t)nslice * d->T * d->H * d->W * d->M * 4;
+}
+
+// K-sliced form for small maps: nslice workgroups share each output tile (each takes every nslice-th row-step of the K loop
+// and writes fp32 partial sums to `workspace`), then a reduce kernel sums them in slice order and runs the fused epilogue.
+extern "C" int ppms_conv_gemm2_sliced(const ppms_conv* d, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream) {
+    PPMS_REQUIRE(nslice >= 1 && nslice <= 16, "conv_gemm2_sliced: nslice=%d", nslice);
+    if (nslice == 1) return conv2_launch(d, dev_desc, 0, 1, nullptr, stream);
+    PPMS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "conv_gemm2_sliced: workspace missing or not 16-B aligned");
+    const int rc = conv2_launch(d, dev_desc, 1, nslice, (float*)workspace, stream);
+    if (rc != 0) return rc;
+    const int64_t P = (int64_t)d->T * d->H * d->W;
+    const int64_t total = P * (d->M / 8);
+    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dev_desc, (const float*)workspace, nslice, P);
+    return ppms_check_launch("conv_gemm2_sliced");
+}
+
+static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, int nslice, float* part, void* stream) {
     PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm2: null descriptor (host copy and device copy are both required)");
     PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm2: nseg=%d", d->nseg);
     PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm2: bad volume %dx%dx%d", d->T, d->H, d->W);
@@ -402,6 +484,13 @@ extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, in
     g.nchunk = nchunk;
     g.n0 = d->seg[0].c / BK;
     g.nk = d->kt * d->kh * nchunk * d->kw;
+    g.nslice = nslice;
+    g.part = part;
+    g.P = (int64_t)d->T * d->H * d->W;
+    if (nslice > 1) {
+        PPMS_REQUIRE((d->kh * nchunk) % nslice == 0, "conv_gemm2: %d row-steps per temporal tap do not split into %d slices", d->kh * nchunk, nslice);
+        PPMS_REQUIRE(d->epi[0].out_vt == nullptr && (d->m_split >= d->M || d->epi[1].out_vt == nullptr), "conv_gemm2: sliced launch cannot write out_vt");
+    }
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
     const int mblocks = d->M / 64;
     int wm = wm_hint;
@@ -423,7 +512,7 @@ extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, in
     // small maps: split K inside the workgroup so that more waves work on the few tiles there are
     const int nwg = ntiles * g.mgroups;
     int kgs = 1;
-    if (wm == 1 && wm_hint <= 0) {
+    if (wm == 1 && wm_hint <= 0 && nslice == 1) {
         if (nwg <= 128 && nchunk % 4 == 0) kgs = 4;
         else if (nwg <= 512 && nchunk % 2 == 0) kgs = 2;   // ~68 KiB of LDS each: two such workgroups share a CU
     }

@@ -33,6 +33,7 @@ TOP_K = 5
 CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
+USE_SLICES = os.environ.get("PPMS_SLICE", "1") != "0"     # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
 HOIST_INP = os.environ.get("PPMS_HOIST", "1") != "0"      # iteration-invariant inp share of the GRU gates computed once per scale
 ATTN16_TORCH = os.environ.get("PPMS_ATTN16", "hip") == "torch"   # update_block16 time/space attention: HIP (default) or torch ops
 
@@ -63,14 +64,23 @@ def softmax_scale(c: int = 128) -> float:
 class ConvOp:
     """One implicit-GEMM launch: host descriptor (validated by the library) + its device copy."""
 
-    def __init__(self, desc: L.Conv, keep: list, version: int = 1, wm_hint: int = 0):
+    def __init__(self, desc: L.Conv, keep: list, version: int = 1, wm_hint: int = 0, nslice: Optional[int] = None):
         self.desc, self.version, self.wm_hint = desc, version, wm_hint
         raw = bytes(desc)
         self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone().cuda()
         self.keep = keep            # tensors whose storage the descriptor points at
+        # small maps: K-sliced launch + reduce kernel (nslice None: ask the library; own workspace per op because ops
+        # of the two streams run concurrently)
+        self.nslice, self.ws = 1, None
+        if version == 2 and wm_hint == 0 and (nslice is not None or USE_SLICES):
+            self.nslice = int(L.load().ppms_conv_gemm2_slices(C.byref(desc))) if nslice is None else nslice
+            if self.nslice > 1:
+                self.ws = torch.empty(int(L.load().ppms_conv_gemm2_slice_workspace_bytes(C.byref(desc), self.nslice)), dtype=torch.uint8, device="cuda")
 
     def __call__(self):
-        if self.version == 3:
+        if self.nslice > 1:
+            L.check(L.load().ppms_conv_gemm2_sliced(C.byref(self.desc), self.dev.data_ptr(), self.nslice, self.ws.data_ptr(), L.stream_ptr()))
+        elif self.version == 3:
             L.check(L.load().ppms_conv_gemm3(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
         elif self.version == 2:
             L.check(L.load().ppms_conv_gemm2(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))

@@ -71,7 +71,7 @@ def test_ops_refuse_cpu_tensors(lib):
 
 
 # ------------------------------------------------------------------------------------------------ conv GEMM
-def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None):
+def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None, nslice=None):
     """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
     from ppmstereo_amd.engine import ConvOp, epilogue
     from ppmstereo_amd.packing import pack_conv as pack1, pack_conv2
@@ -118,7 +118,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     d.kt, d.kh, d.kw = k3
     d.M = d.m_split = meta["M"]
     d.epi[0] = e
-    ConvOp(d, keep, version, wm)()
+    ConvOp(d, keep, version, wm, nslice=nslice if nslice is not None else 1)()
     torch.cuda.synchronize()
     sp = out.to_f32()[:, :cout].cpu()
     assert (sp - outf[:, :cout].cpu()).abs().max() < 2e-5 * (1 + sp.abs().max()), "SP and fp32 outputs of one launch disagree"
@@ -240,6 +240,28 @@ def test_conv_gemm_hoisted_input_share(lib, version):
     assert maxdiff(run(act=L.ACT_GELU), F.gelu(full)) < 5e-5
     assert maxdiff(run(kind=L.EPI_RH, aux=aux), torch.sigmoid(full) * aux) < 5e-5
     assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(full)) < 5e-5
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3,nslice", [
+    ("gru_1x15", 5, 20, 32, [128, 384], 256, (1, 1, 15), 8), ("q_1x5", 2, 10, 18, [128, 256], 128, (1, 1, 5), 4),
+    ("t_5x1x1", 5, 6, 10, [128, 64], 128, (5, 1, 1), 3), ("3x3x3", 4, 7, 9, [128], 190, (3, 3, 3), 2), ("3x3_320", 2, 9, 13, [320], 190, (1, 3, 3), 5)])
+def test_conv_gemm_k_sliced(lib, name, T, H, W, segs, cout, k3, nslice):
+    """Grid-level K slicing for small maps: partial tiles + deterministic reduce kernel with the fused epilogue."""
+    L = lib
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    got = _run_conv(L, xs, wt, bs, k3, T, H, W, nslice=nslice)
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    again = _run_conv(L, xs, wt, bs, k3, T, H, W, nslice=nslice)
+    assert torch.equal(got, again), "slice reduction must be order-deterministic"
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    got = _run_conv(L, xs, wt, bs, k3, T, H, W, nslice=nslice, kind=L.EPI_GRU, aux=aux, z=z)
+    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
 def test_conv_gemm_rejects_bad_descriptors(lib):
