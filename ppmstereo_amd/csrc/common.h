@@ -43,15 +43,36 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
 }
 __device__ __forceinline__ float join_bf16(bf16_t hi, bf16_t lo) { return (float)hi + (float)lo; }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }      // library-accurate (QAM confidence path)
+
+// Branch-free transcendentals of the fused epilogues (GRU gates, GELU): the ocml erff / tanhf / expf + IEEE division cost
+// 25-60 instructions per element with divergent range branches, which made the activation the longest part of the
+// per-pixel layer chains and ~3 % of an iteration.  These use the raw v_exp_f32 / v_rcp_f32 (1 ulp each); absolute
+// errors: sigmoid, tanh <= ~1e-7, erf <= 1.5e-7 (Abramowitz & Stegun 7.1.26), i.e. the rounding level of fp32 values
+// of magnitude 1, far inside the 3e-5 tolerance the bf16x3 convolutions are tested to.  NaN propagates.
+__device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + exp_fast(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + exp_fast(2.0f * x));       // +-1 at the infinities
+    const float x2 = x * x;
+    const float small = x * (1.0f + x2 * (-0.33333333333f + x2 * (0.13333333333f - 0.05396825397f * x2)));   // |x| < 1/8: rel. 2e-10
+    return __builtin_fabsf(x) < 0.125f ? small : big;
+}
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float y = 1.0f - poly * exp_fast(-ax * ax);
+    return __builtin_copysignf(y, x);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 __device__ __forceinline__ float apply_act(float x, int act) {
     switch (act) {
         case PPMS_ACT_RELU: return x < 0.0f ? 0.0f : x;   // not fmaxf: NaN must propagate like torch.relu (T == 1 case)
         case PPMS_ACT_GELU: return gelu_erf(x);
-        case PPMS_ACT_SIGMOID: return sigmoid_f(x);
-        case PPMS_ACT_TANH: return tanhf(x);
+        case PPMS_ACT_SIGMOID: return sigmoid_fast(x);
+        case PPMS_ACT_TANH: return tanh_fast(x);
         case PPMS_ACT_ELU1: return x > 0.0f ? x + 1.0f : expf(x);      // elu(x) + 1 (attention.py:14-15)
         default: return x;
     }

@@ -34,13 +34,13 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
         for (int j = 0; j < 4; ++j) y[j] = apply_act(ax[j] + v[j], e.act) * e.scale;
     } else if (kind == PPMS_EPI_RH) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = sigmoid_f(v[j]) * ax[j];
+        for (int j = 0; j < 4; ++j) y[j] = sigmoid_fast(v[j]) * ax[j];
     } else if (kind == PPMS_EPI_GRU) {
         const float* zp = e.aux_f32 + pix * e.aux_f32_ld + cl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float z = (j < nv) ? zp[j] : 0.0f;
-            y[j] = (1.0f - z) * ax[j] + z * tanhf(v[j]);
+            y[j] = (1.0f - z) * ax[j] + z * tanh_fast(v[j]);
         }
     } else if (kind == PPMS_EPI_ADDF32) {
         float* op = e.out_f32 + pix * e.out_f32_ld + cl;
@@ -163,14 +163,14 @@ __device__ __forceinline__ void epilogue_row8(const ppms_epilogue& e, const floa
         for (int j = 0; j < 8; ++j) y[j] = apply_act(ax[j] + v[j], e.act) * e.scale;
     } else if (kind == PPMS_EPI_RH) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = sigmoid_f(v[j]) * ax[j];
+        for (int j = 0; j < 8; ++j) y[j] = sigmoid_fast(v[j]) * ax[j];
     } else if (kind == PPMS_EPI_GRU) {
         const float* zp = e.aux_f32 + pix * e.aux_f32_ld + cl;
         const f32x4 z0 = *(const f32x4*)zp, z1 = *(const f32x4*)(zp + 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float z = j < 4 ? z0[j & 3] : z1[j & 3];
-            y[j] = (1.0f - z) * ax[j] + z * tanhf(v[j]);
+            y[j] = (1.0f - z) * ax[j] + z * tanh_fast(v[j]);
         }
     } else if (kind == PPMS_EPI_ADDF32) {
         float* op = e.out_f32 + pix * e.out_f32_ld + cl;

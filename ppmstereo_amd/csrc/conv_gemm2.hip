@@ -497,6 +497,7 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
     if (wm <= 0) {
         // <= 3 cout blocks: one group; 4 blocks (M = 256): two 128-cout groups (measured 8 % faster than one 8-wave group)
         wm = mblocks <= 3 ? mblocks : 2;
+        if (mblocks == 4 && d->kw == 1 && d->kh == 1) wm = 4;   // no window reuse across taps (1x1, temporal): share each window among all couts
         if (mblocks % wm) wm = 1;
         if (ntiles < 160 && mblocks > 1) wm = 1;          // small maps: spread cout blocks over more workgroups
     }
