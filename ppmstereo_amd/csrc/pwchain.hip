@@ -127,17 +127,33 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
                         oh[j] = hh;
                         ol[j] = ll;
                     }
-                    if (last) {
-                        if (pix < c.P && cg < L.n_valid) {
-                            *(bf16x4*)((bf16_t*)c.out.hi + pix * c.out.ld + cg) = oh;
-                            *(bf16x4*)((bf16_t*)c.out.lo + pix * c.out.ld + cg) = ol;
-                        }
-                    } else {
+                    {
                         const int xo = (cl >> 5) * 2 * ACT_PLANE + swzp(px, (cl & 31) >> 3) + (cl & 7) * 2;
                         *(bf16x4*)(dst + xo) = oh;
                         *(bf16x4*)(dst + ACT_PLANE + xo) = ol;
                     }
                 }
+            if (last) {
+                // the 64-cout block sits in LDS like an intermediate layer; copy it out with whole 128-byte runs per pixel
+                // and plane (in the accumulator layout a wave's store touched 32 cache lines with 16 useful bytes each)
+                __syncthreads();
+                for (int qd = tid; qd < TP * 16; qd += 256) {               // 8 chunks x 2 planes per pixel
+                    const int opx = qd >> 4, plane = (qd >> 3) & 1, ch = qd & 7;
+                    const int64_t opix = p0 + opx;
+                    const int ocg = mblk * 64 + ch * 8;
+                    if (opix < c.P && ocg < L.n_valid) {
+                        const u32x4 v = *(const u32x4*)(dst + (ch >> 2) * 2 * ACT_PLANE + plane * ACT_PLANE + swzp(opx, ch & 3));
+                        bf16_t* op = (bf16_t*)(plane ? c.out.lo : c.out.hi) + opix * c.out.ld + ocg;
+                        if (ocg + 8 <= L.n_valid) {
+                            gstore16(op, v);
+                        } else {                                                // ragged tail of the valid couts
+                            const bf16_t* e = (const bf16_t*)&v;
+                            for (int j = 0; j < 8; ++j)
+                                if (ocg + j < L.n_valid) op[j] = e[j];
+                        }
+                    }
+                }
+            }
         }
         src = dst;
     }
