@@ -57,6 +57,19 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
         *(u32x4*)(bufX + off) = vh;
         *(u32x4*)(bufX + ACT_PLANE + off) = vl;
     }
+    // weight blocks are requested one phase ahead (registers): phase = (layer, 64-cout block)
+    u32x4 wreg[4];
+    auto load_w = [&](int l, int mblk) __attribute__((always_inline)) {
+        const Layer& Lw = c.layer[l];
+        const int mbs = Lw.M / 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + i * 256;
+            const int ks = q >> 9, rem = q & 511;                 // 512 chunks (8 KiB) per k-step
+            wreg[i] = gload16((const char*)Lw.w + ((int64_t)(ks * mbs + mblk) * 512 + rem) * 16);
+        }
+    };
+    load_w(0, 0);
     const char* src = bufX;
     for (int l = 0; l < c.nlayers; ++l) {
         const Layer& L = c.layer[l];
@@ -66,10 +79,12 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
         for (int mblk = 0; mblk < mblocks; ++mblk) {
             __syncthreads();                                      // previous users of wsm / producers of src are done
             // weight block: k-step ks of block mblk lives at ((ks * mblocks + mblk) * 8 KiB) in the packed tensor
-            for (int q = tid; q < W_BLK / 16; q += 256) {
-                const int ks = q >> 9, rem = q & 511;             // 512 chunks (8 KiB) per k-step
-                *(u32x4*)(wsm + q * 16) = gload16((const char*)L.w + ((int64_t)(ks * mblocks + mblk) * 512 + rem) * 16);
-            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(wsm + (tid + i * 256) * 16) = wreg[i];
+            if (mblk + 1 < mblocks)
+                load_w(l, mblk + 1);
+            else if (l + 1 < c.nlayers)
+                load_w(l + 1, 0);
             __syncthreads();
             // wave w: 64 couts x pixels [32 w, 32 w + 32)
             f32x16 acc[2];
