@@ -115,3 +115,56 @@ def test_temporal_encoding_and_scale_match_the_oracle():
         assert torch.equal(get_temporal_positional_encoding(T, 128, "cpu", is_normalize=True, scale=1.0).reshape(T, 128), O.temporal_pe(T, 128))
     assert torch.isnan(temporal_pe(1, 128)).all()
     assert softmax_scale(128) == O.softmax_scale(128)
+
+
+# ------------------------------------------------------------------------------------------------ launch heuristics (host code of libppms)
+def _desc(T, H, W, M, k3, seg_c, out_vt=False):
+    """A conv descriptor good enough for the host-side planners (they never dereference the pointers)."""
+    from ppmstereo_amd import _lib as L
+    d = L.Conv()
+    for i, c in enumerate(seg_c):
+        d.seg[i] = L.SP(0x1000, 0x2000, c, c)
+    d.nseg, d.w, d.bias = len(seg_c), 0x3000, 0x4000
+    d.T, d.H, d.W = T, H, W
+    d.kt, d.kh, d.kw = k3
+    d.M = d.m_split = M
+    d.epi[0].n_valid = M
+    if out_vt:
+        d.epi[0].out_vt = 0x5000
+    return d
+
+
+def test_k_slicing_plan_for_small_maps():
+    """ppms_conv_gemm2_slices: small maps (fewer than ~512 workgroups of 64 couts x 128 px) get their K loop cut into
+    2..8 slices that divide kh * chunks; the 1/4 scale, V^T-writing convs and short K loops are left alone."""
+    import ctypes as C
+    from ppmstereo_amd import _lib as L
+    lib = L.load()
+    s = lambda *a, **k: lib.ppms_conv_gemm2_slices(C.byref(_desc(*a, **k)))
+    assert s(5, 20, 32, 256, (1, 1, 15), [128, 384]) == 8          # GRU z/r pass W at 1/16: 100 workgroups, 16 chunks
+    assert s(5, 40, 64, 256, (1, 1, 15), [128, 256]) == 2          # 1/8 with the hoisted inp share: 400 workgroups, 12 chunks
+    assert s(5, 80, 128, 256, (1, 1, 15), [128, 256]) == 1         # 1/4 scale: enough workgroups
+    assert s(5, 20, 32, 128, (1, 1, 1), [128], out_vt=True) == 1   # to_v writes V^T from the accumulators
+    assert s(5, 20, 32, 64, (1, 1, 1), [128]) == 1                 # 4 k-steps in all: nothing to slice
+    n = s(5, 20, 32, 192, (1, 3, 3), [320])                        # final_conv at 1/16: 30 row-steps per temporal tap
+    assert n in (2, 3, 5, 6) and 30 % n == 0
+    d = _desc(5, 20, 32, 256, (1, 1, 15), [128, 384])
+    assert lib.ppms_conv_gemm2_slice_workspace_bytes(C.byref(d), 8) == 8 * 5 * 20 * 32 * 256 * 4
+    assert lib.ppms_conv_gemm2_slice_workspace_bytes(C.byref(d), 1) == 0
+
+
+def test_large_map_kernel_applicability():
+    """ppms_conv_gemm3_applicable: M % 128 == 0, a spatial sweep axis, >= 384 workgroups, and (2-D sweeps) a halo'd window
+    that fits the LDS budget."""
+    import ctypes as C
+    from ppmstereo_amd import _lib as L
+    lib = L.load()
+    a = lambda *args: lib.ppms_conv_gemm3_applicable(C.byref(_desc(*args)))
+    assert a(5, 80, 128, 256, (1, 1, 15), [128, 256]) == 1         # x sweep
+    assert a(5, 80, 128, 256, (1, 5, 1), [128, 256]) == 1          # y sweep
+    assert a(5, 80, 128, 256, (3, 3, 3), [128]) == 1               # 2-D sweep, 3x3 window fits
+    assert a(5, 80, 128, 256, (1, 9, 9), [128]) == 0               # 9x9 halo does not fit
+    assert a(5, 80, 128, 256, (5, 1, 1), [128, 256]) == 0          # temporal only: no sweep axis
+    assert a(5, 80, 128, 128, (1, 1, 5), [128, 256]) == 0          # 200 workgroups: conv_gemm2 fills the chip better
+    assert a(5, 80, 128, 192, (1, 3, 3), [256]) == 0               # M not a multiple of 128 (the engine pads such convs)
+    assert a(5, 40, 64, 256, (1, 1, 15), [128, 256]) == 0          # 1/8 scale: too few tiles
