@@ -108,6 +108,12 @@ int ppms_conv_gemm2(const ppms_conv* desc, const ppms_conv* dev_desc, int wm_hin
 int ppms_conv_gemm2_slices(const ppms_conv* desc);
 int64_t ppms_conv_gemm2_slice_workspace_bytes(const ppms_conv* desc, int nslice);
 int ppms_conv_gemm2_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream);
+/* (kt, kh, 1) convs swept along y by the same kernel: one halo'd window serves all kh taps (ppms_conv_gemm2 loads a
+ * window per tap for kw == 1).  Weights: pack_conv2 order of the kernel with its kh / kw axes swapped (as for
+ * ppms_conv_gemm3).  nslice / workspace as for ppms_conv_gemm2_sliced (nslice == 1: none);
+ * ppms_conv_gemm2_ysweep_slices() = the slice count that pays off (0: descriptor is not a y-sweep candidate). */
+int ppms_conv_gemm2_ysweep_slices(const ppms_conv* desc);
+int ppms_conv_gemm2_ysweep(const ppms_conv* desc, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream);
 /* Large-map variant (128 couts x 256 pixels per workgroup, LDS-DMA operands, activation window swept by the taps along
  * x, along y, or over all kh x kw taps).  ppms_conv_gemm3_applicable() tells whether it serves a descriptor
  * (M % 128 == 0, kw > 1 or kh > 1, the halo'd window fits, enough tiles).  Weights in pack_conv2 order with the k-steps

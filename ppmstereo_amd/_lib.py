@@ -56,6 +56,8 @@ _SIGS = {
     "ppms_conv_gemm2_slices": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm2_slice_workspace_bytes": (C.c_int64, [C.POINTER(Conv), c_int]),
     "ppms_conv_gemm2_sliced": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p, c_void_p]),
+    "ppms_conv_gemm2_ysweep_slices": (c_int, [C.POINTER(Conv)]),
+    "ppms_conv_gemm2_ysweep": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p, c_void_p]),
     "ppms_conv_gemm3_applicable": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm3": (c_int, [C.POINTER(Conv), c_void_p, c_void_p]),
     "ppms_struct_sizes": (c_int, [C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),

@@ -32,6 +32,9 @@ struct Geo2 {
     int nk;                  // k-steps = kt*kh*nchunk*kw
     int mgroups;             // M / (64*WM)
     int bstages;             // 2: window double-buffered; 1: single window + one extra barrier per window switch
+    int ysweep;              // 1: (1, kh, 1) conv swept along y: column-major patch / window (fast axis y, logF = log2 R), taps step
+                             //    the window row; weights packed with kh / kw swapped.  0: taps along x (fast axis x, logF = log2 C)
+    int ksw, logF;           // taps swept inside one window (kw, or kh when ysweep); log2 of the patch's fast-axis length
     int nslice;              // grid-level K slices (gridDim.y): slice s takes the row-steps s*KG + kg, + KG*nslice, ...
     float* part;             // nslice > 1: fp32 partial sums [slice][pixel][M] (no bias), finished by conv_slice_reduce_kernel
     int64_t P;               // pixels = T*H*W
@@ -63,7 +66,9 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     const int x0 = tx * g.C, y0 = ty * g.R;
     const int H = p.H, W = p.W, T = p.T;
     const int HW = H * W;
-    const int hx = p.kw >> 1, hy = p.kh >> 1, ht = p.kt >> 1;
+    const int hy = p.kh >> 1, ht = p.kt >> 1;
+    const int hsw = g.ksw >> 1;               // halo of the window along the swept axis
+    const int F = 1 << g.logF;                // patch extent along the fast (swept) axis
 
     const int bplane = g.Wr * 64;
     char* sA = smem + kg * (2 * WM * A_BLK + g.bstages * 2 * bplane);      // this K-group's stages: 2 x WM x 8 KiB weights,
@@ -82,8 +87,8 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         sl_y[i] = 0;
         if (j < nslot_total) {
             const int wrow = j >> 2, c = j & 3;
-            const int wy = wrow / g.WR, wx = wrow - wy * g.WR;
-            const int x = x0 + wx - hx, y = y0 + wy;
+            const int ws = wrow / g.WR, wf = wrow - ws * g.WR;       // slow / fast (swept, halo'd) window coordinate
+            const int x = g.ysweep ? x0 + ws : x0 + wf - hsw, y = g.ysweep ? y0 + wf - hsw : y0 + ws;
             sl_lds[i] = swz2(wrow, c);
             sl_y[i] = y;
             if ((unsigned)x < (unsigned)W) sl_off[i] = (tf * H + y) * W + x;
@@ -106,8 +111,9 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         for (int i = 0; i < 4; ++i) *(u32x4*)(s + i * NT * 16) = ra[i];
     };
     auto load_b = [&](int trow, int chunk) {
-        const int ky = trow % p.kh, kz = trow / p.kh;
-        const int dy = ky - hy, dt = kz - ht;
+        const int kho = g.ysweep ? 1 : p.kh;                       // kernel rows NOT swept inside a window
+        const int ky = trow % kho, kz = trow / kho;
+        const int dy = g.ysweep ? 0 : ky - hy, dt = kz - ht;
         const int s = (chunk >= g.n0) ? 1 : 0;
         const int c0 = (chunk - (s ? g.n0 : 0)) * BK + cB * 8;
         const bf16_t* sh = (const bf16_t*)p.seg[s].hi;
@@ -143,7 +149,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int pid = wn * 64 + nb * 32 + r;
-        brow[nb] = (pid >> g.logC) * g.WR + (pid & (g.C - 1));
+        brow[nb] = (pid >> g.logF) * g.WR + (pid & (F - 1));
     }
 
     f32x16 acc[2][2];
@@ -157,14 +163,14 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     // (T = 5: 24 % of the (5,1,1) GRU pass, 13 % of the 3x3x3 flow head).  Valid kz form one contiguous range.
     const int kz0 = (ht - tf) > 0 ? (ht - tf) : 0;
     const int kz1 = (ht + T - 1 - tf) < (p.kt - 1) ? (ht + T - 1 - tf) : (p.kt - 1);
-    const int rs_per_kz = p.kh * g.nchunk;
+    const int rs_per_kz = (g.ysweep ? 1 : p.kh) * g.nchunk;
     const int rs_end = (kz1 + 1) * rs_per_kz;
     const int kstride = KG * g.nslice;        // row-step = trow * nchunk + chunk; K-group kg of slice s takes every kstride-th one
     int rs = kz0 * rs_per_kz + (int)blockIdx.y * KG + kg;
-    const int nsteps = ((rs_end - kz0 * rs_per_kz) / kstride) * p.kw;     // identical for every group (kh*nchunk % kstride == 0)
+    const int nsteps = ((rs_end - kz0 * rs_per_kz) / kstride) * g.ksw;     // identical for every group (rs_per_kz % kstride == 0)
     {
         const int trow = rs / g.nchunk;
-        load_a(rs * p.kw);
+        load_a(rs * g.ksw);
         load_b(trow, rs - trow * g.nchunk);
     }
     store_a(0);
@@ -173,10 +179,10 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     int bsel = 0, kx = 0;
     for (int j = 0; j < nsteps; ++j) {
         const bool more = j + 1 < nsteps;
-        const bool need_b = more && (kx + 1 == p.kw);
+        const bool need_b = more && (kx + 1 == g.ksw);
         if (more) {
             const int nrs = need_b ? rs + kstride : rs;
-            load_a(nrs * p.kw + (need_b ? 0 : kx + 1));
+            load_a(nrs * g.ksw + (need_b ? 0 : kx + 1));
             if (need_b) {
                 const int trow = nrs / g.nchunk;
                 load_b(trow, nrs - trow * g.nchunk);
@@ -286,7 +292,8 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     for (int nb = 0; nb < 2; ++nb) {
         if (e.out_vt != nullptr) {                                   // pixel-major V^T straight from the accumulator layout
             const int pid = wn * 64 + nb * 32 + r;
-            const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+            const int pf_ = pid & (F - 1), ps_ = pid >> g.logF;
+            const int px = x0 + (g.ysweep ? ps_ : pf_), py = y0 + (g.ysweep ? pf_ : ps_);
             const int64_t pix = (int64_t)(tf * H + py) * W + px;
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
@@ -316,7 +323,8 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
             float v[8];
             stage_read8(stg, prow, q, v);
             const int pid = wn * 64 + nb * 32 + prow;
-            const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+            const int pf_ = pid & (F - 1), ps_ = pid >> g.logF;
+            const int px = x0 + (g.ysweep ? ps_ : pf_), py = y0 + (g.ysweep ? pf_ : ps_);
             if (px < W && py < H) {
                 const int64_t pix = (int64_t)(tf * H + py) * W + px;
                 if (g.nslice > 1) {                                  // K-sliced launch: raw partial sums, finished by the reduce kernel
@@ -386,7 +394,7 @@ int launch2(const ppms_conv* d, const ppms_conv* dev_desc, const Geo2& g, int nt
 
 }  // namespace
 
-static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, int nslice, float* part, void* stream);
+static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, int nslice, float* part, void* stream, int ysweep = 0);
 
 // wm_hint: 0 = choose (all couts per workgroup when the grid still fills the chip, otherwise 64-cout blocks)
 extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, void* stream) {
@@ -410,6 +418,15 @@ extern "C" int ppms_conv_gemm2_slices(const ppms_conv* d) {
     return best;
 }
 
+// Same planner for the y-swept form (row-steps per temporal tap = chunks only)
+extern "C" int ppms_conv_gemm2_ysweep_slices(const ppms_conv* d) {
+    if (d == nullptr || d->kw != 1 || d->kh <= 1) return 0;
+    ppms_conv t = *d;
+    t.kw = d->kh;                      // as an x-swept (1, 1, kh) conv: same number of workgroups, row-steps and k-steps
+    t.kh = 1;
+    return ppms_conv_gemm2_slices(&t);
+}
+
 extern "C" int64_t ppms_conv_gemm2_slice_workspace_bytes(const ppms_conv* d, int nslice) {
     if (d == nullptr || nslice <= 1) return 0;
     return (int64_t)nslice * d->T * d->H * d->W * d->M * 4;
@@ -429,7 +446,22 @@ extern "C" int ppms_conv_gemm2_sliced(const ppms_conv* d, const ppms_conv* dev_d
     return ppms_check_launch("conv_gemm2_sliced");
 }
 
-static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, int nslice, float* part, void* stream) {
+// (kt, kh, 1) convs swept along y: one halo'd window serves all kh taps (the plain entry loads a window per tap).  Weights in
+// pack_conv2 order of the kernel with kh / kw swapped.  nslice as in ppms_conv_gemm2_sliced (1: no slicing, workspace unused).
+extern "C" int ppms_conv_gemm2_ysweep(const ppms_conv* d, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream) {
+    PPMS_REQUIRE(d != nullptr && d->kw == 1 && d->kh > 1, "conv_gemm2_ysweep: needs a (kt, kh, 1) kernel with kh > 1");
+    PPMS_REQUIRE(nslice >= 1 && nslice <= 16, "conv_gemm2_ysweep: nslice=%d", nslice);
+    if (nslice == 1) return conv2_launch(d, dev_desc, 0, 1, nullptr, stream, 1);
+    PPMS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "conv_gemm2_ysweep: workspace missing or not 16-B aligned");
+    const int rc = conv2_launch(d, dev_desc, 1, nslice, (float*)workspace, stream, 1);
+    if (rc != 0) return rc;
+    const int64_t P = (int64_t)d->T * d->H * d->W;
+    const int64_t total = P * (d->M / 8);
+    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dev_desc, (const float*)workspace, nslice, P);
+    return ppms_check_launch("conv_gemm2_ysweep");
+}
+
+static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, int nslice, float* part, void* stream, int ysweep) {
     PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm2: null descriptor (host copy and device copy are both required)");
     PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm2: nseg=%d", d->nseg);
     PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm2: bad volume %dx%dx%d", d->T, d->H, d->W);
@@ -461,14 +493,17 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
         if (e.kind == PPMS_EPI_GRU) PPMS_REQUIRE(e.aux_f32 != nullptr, "conv_gemm2: GRU epilogue needs z");
         if (e.kind == PPMS_EPI_ADDF32) PPMS_REQUIRE(e.out_f32 != nullptr, "conv_gemm2: ADDF32 epilogue needs out_f32");
     }
-    // patch width: the power of two in [16,128] wasting the fewest pixels of the 128-pixel tile (ties: the widest)
+    // patch width: the power of two in [16,128] wasting the fewest pixels of the 128-pixel tile (ties: the widest for an x
+    // sweep, the narrowest -- tallest patch, smallest halo share -- for a y sweep)
+    PPMS_REQUIRE(!ysweep || (d->kw == 1 && d->kh > 1), "conv_gemm2: y sweep is for (kt, kh, 1) kernels");
     Geo2 g;
     int bestC = 16;
     double bestw = 1e30;
     for (int C = 16; C <= 128; C *= 2) {
         const int R = 128 / C;
+        if (ysweep && C * (R + d->kh - 1) > 256) continue;          // window rows must fit the staging slots of one cout block
         const double waste = (double)((d->W + C - 1) / C * C) * ((d->H + R - 1) / R * R) / ((double)d->W * d->H);
-        if (waste <= bestw + 1e-9) {
+        if (ysweep ? waste < bestw - 1e-9 : waste <= bestw + 1e-9) {
             bestw = waste;
             bestC = C;
         }
@@ -477,10 +512,13 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
     g.R = 128 / bestC;
     g.logC = 0;
     while ((1 << g.logC) < g.C) ++g.logC;
+    g.ysweep = ysweep;
+    g.ksw = ysweep ? d->kh : d->kw;
+    g.logF = ysweep ? 7 - g.logC : g.logC;
     g.tiles_x = (d->W + g.C - 1) / g.C;
     g.tiles_y = (d->H + g.R - 1) / g.R;
-    g.WR = g.C + d->kw - 1;
-    g.Wr = g.R * g.WR;
+    g.WR = (ysweep ? g.R : g.C) + g.ksw - 1;
+    g.Wr = (ysweep ? g.C : g.R) * g.WR;
     g.nchunk = nchunk;
     g.n0 = d->seg[0].c / BK;
     g.nk = d->kt * d->kh * nchunk * d->kw;
@@ -488,7 +526,8 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
     g.part = part;
     g.P = (int64_t)d->T * d->H * d->W;
     if (nslice > 1) {
-        PPMS_REQUIRE((d->kh * nchunk) % nslice == 0, "conv_gemm2: %d row-steps per temporal tap do not split into %d slices", d->kh * nchunk, nslice);
+        PPMS_REQUIRE(((ysweep ? 1 : d->kh) * nchunk) % nslice == 0, "conv_gemm2: %d row-steps per temporal tap do not split into %d slices",
+                     (ysweep ? 1 : d->kh) * nchunk, nslice);
         PPMS_REQUIRE(d->epi[0].out_vt == nullptr && (d->m_split >= d->M || d->epi[1].out_vt == nullptr), "conv_gemm2: sliced launch cannot write out_vt");
     }
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
@@ -505,7 +544,7 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
     g.mgroups = mblocks / wm;
     // kw > 1: the window changes every kw-th k-step -> keep ONE copy (extra barrier per switch) so that three 4-wave
     // workgroups fit a CU's LDS; kw == 1: it changes every k-step -> double-buffer it
-    g.bstages = (d->kw == 1) ? 2 : 1;
+    g.bstages = (g.ksw == 1) ? 2 : 1;
     const int maxslot = wm == 4 ? 2 : wm == 3 ? 3 : wm == 2 ? 4 : 8;
     PPMS_REQUIRE(g.Wr * 4 <= 128 * wm * maxslot, "conv_gemm2: window of %d rows does not fit the staging slots", g.Wr);
     PPMS_REQUIRE(2 * wm * A_BLK + g.bstages * 2 * g.Wr * 64 <= 160 * 1024, "conv_gemm2: LDS budget exceeded");

@@ -33,6 +33,7 @@ TOP_K = 5
 CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
+USE_YSWEEP = os.environ.get("PPMS_YSWEEP", "1") != "0"    # conv_gemm2's y-swept form for (1, kh, 1) convs (A/B switch)
 USE_SLICES = os.environ.get("PPMS_SLICE", "1") != "0"     # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
 HOIST_INP = os.environ.get("PPMS_HOIST", "1") != "0"      # iteration-invariant inp share of the GRU gates computed once per scale
 ATTN16_TORCH = os.environ.get("PPMS_ATTN16", "hip") == "torch"   # update_block16 time/space attention: HIP (default) or torch ops
@@ -64,8 +65,8 @@ def softmax_scale(c: int = 128) -> float:
 class ConvOp:
     """One implicit-GEMM launch: host descriptor (validated by the library) + its device copy."""
 
-    def __init__(self, desc: L.Conv, keep: list, version: int = 1, wm_hint: int = 0, nslice: Optional[int] = None):
-        self.desc, self.version, self.wm_hint = desc, version, wm_hint
+    def __init__(self, desc: L.Conv, keep: list, version: int = 1, wm_hint: int = 0, nslice: Optional[int] = None, ysweep: bool = False):
+        self.desc, self.version, self.wm_hint, self.ysweep = desc, version, wm_hint, ysweep
         raw = bytes(desc)
         self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone().cuda()
         self.keep = keep            # tensors whose storage the descriptor points at
@@ -73,12 +74,15 @@ class ConvOp:
         # of the two streams run concurrently)
         self.nslice, self.ws = 1, None
         if version == 2 and wm_hint == 0 and (nslice is not None or USE_SLICES):
-            self.nslice = int(L.load().ppms_conv_gemm2_slices(C.byref(desc))) if nslice is None else nslice
+            plan = L.load().ppms_conv_gemm2_ysweep_slices if ysweep else L.load().ppms_conv_gemm2_slices
+            self.nslice = max(1, int(plan(C.byref(desc)))) if nslice is None else nslice
             if self.nslice > 1:
                 self.ws = torch.empty(int(L.load().ppms_conv_gemm2_slice_workspace_bytes(C.byref(desc), self.nslice)), dtype=torch.uint8, device="cuda")
 
     def __call__(self):
-        if self.nslice > 1:
+        if self.ysweep:
+            L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
+        elif self.nslice > 1:
             L.check(L.load().ppms_conv_gemm2_sliced(C.byref(self.desc), self.dev.data_ptr(), self.nslice, self.ws.data_ptr(), L.stream_ptr()))
         elif self.version == 3:
             L.check(L.load().ppms_conv_gemm3(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
@@ -306,6 +310,11 @@ class ScaleEngine:
                 packed3, bias3, _ = self.pk.w[key]
                 d.w, d.bias = packed3.data_ptr(), bias3.data_ptr()
                 return ConvOp(d, [packed3, bias3, *keep], 3)
+        if version == 2 and USE_YSWEEP and isinstance(wname, str) and k3[2] == 1 and k3[1] > 1 and wname + "_y" in self.pk.w:
+            # (1, kh, 1) conv on a map too small for the large-map kernel: conv_gemm2's y-swept form, same "_y" pack
+            packed_y, bias_y, _ = self.pk.w[wname + "_y"]
+            d.w, d.bias = packed_y.data_ptr(), bias_y.data_ptr()
+            return ConvOp(d, [packed_y, bias_y, *keep], 2, ysweep=True)
         return ConvOp(d, [packed, bias, *keep], version)
 
     def _conv_padded(self, wname, *a, **k) -> ConvOp:

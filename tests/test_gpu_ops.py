@@ -71,7 +71,7 @@ def test_ops_refuse_cpu_tensors(lib):
 
 
 # ------------------------------------------------------------------------------------------------ conv GEMM
-def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None, nslice=None):
+def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None, nslice=None, ysweep=False):
     """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
     from ppmstereo_amd.engine import ConvOp, epilogue
     from ppmstereo_amd.packing import pack_conv as pack1, pack_conv2
@@ -85,7 +85,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
         segs.append(t.view())
         keep.append(t)
     wpack = weight
-    if version == 3 and k3[2] == 1 and k3[1] > 1:            # y-swept large-map kernel: pack with kh / kw swapped
+    if (version == 3 or ysweep) and k3[2] == 1 and k3[1] > 1:            # y-swept kernels: pack with kh / kw swapped
         wpack = (weight if weight.dim() == 5 else weight[:, :, None]).transpose(3, 4).contiguous()
     if version == 3 and k3[2] > 1 and k3[1] > 1:             # 2-D swept: (ky, kx) flattened into the x axis
         w5 = weight if weight.dim() == 5 else weight[:, :, None]
@@ -118,7 +118,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     d.kt, d.kh, d.kw = k3
     d.M = d.m_split = meta["M"]
     d.epi[0] = e
-    ConvOp(d, keep, version, wm, nslice=nslice if nslice is not None else 1)()
+    ConvOp(d, keep, version, wm, nslice=nslice if nslice is not None else 1, ysweep=ysweep)()
     torch.cuda.synchronize()
     sp = out.to_f32()[:, :cout].cpu()
     assert (sp - outf[:, :cout].cpu()).abs().max() < 2e-5 * (1 + sp.abs().max()), "SP and fp32 outputs of one launch disagree"
@@ -261,6 +261,27 @@ def test_conv_gemm_k_sliced(lib, name, T, H, W, segs, cout, k3, nslice):
     aux = hash_normal((P, cout), 303)
     z = torch.sigmoid(hash_normal((P, cout), 304))
     got = _run_conv(L, xs, wt, bs, k3, T, H, W, nslice=nslice, kind=L.EPI_GRU, aux=aux, z=z)
+    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3,nslice", [
+    ("gru_1x5x1", 5, 40, 64, [128, 256], 256, (1, 5, 1), 1), ("gru_sliced", 5, 20, 32, [128, 384], 128, (1, 5, 1), 4),
+    ("ragged", 2, 11, 9, [64], 64, (1, 5, 1), 1), ("w80", 1, 23, 80, [64, 32], 192, (1, 5, 1), 3), ("3x_t", 3, 10, 18, [32], 64, (3, 3, 1), 1)])
+def test_conv_gemm2_y_sweep(lib, name, T, H, W, segs, cout, k3, nslice):
+    """conv_gemm2's y-swept form for (kt, kh, 1) convs (column-major patch / window, one window for all kh taps), with and
+    without K slicing, vs torch conv3d."""
+    L = lib
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    got = _run_conv(L, xs, wt, bs, k3, T, H, W, nslice=nslice, ysweep=True)
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    got = _run_conv(L, xs, wt, bs, k3, T, H, W, nslice=nslice, ysweep=True, kind=L.EPI_GRU, aux=aux, z=z)
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
