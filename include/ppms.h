@@ -108,10 +108,11 @@ int ppms_conv_gemm2(const ppms_conv* desc, const ppms_conv* dev_desc, int wm_hin
 int ppms_conv_gemm2_slices(const ppms_conv* desc);
 int64_t ppms_conv_gemm2_slice_workspace_bytes(const ppms_conv* desc, int nslice);
 int ppms_conv_gemm2_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream);
-/* (kt, kh, 1) convs swept along y by the same kernel: one halo'd window serves all kh taps (ppms_conv_gemm2 loads a
- * window per tap for kw == 1).  Weights: pack_conv2 order of the kernel with its kh / kw axes swapped (as for
- * ppms_conv_gemm3).  nslice / workspace as for ppms_conv_gemm2_sliced (nslice == 1: none);
- * ppms_conv_gemm2_ysweep_slices() = the slice count that pays off (0: descriptor is not a y-sweep candidate). */
+/* Convs with kh > 1 by the same kernel with ONE halo'd window per (dt, chunk) for all their taps (ppms_conv_gemm2 loads a
+ * window per kernel row): (kt, kh, 1) kernels swept along y (weights: pack_conv2 order with the kh / kw axes swapped),
+ * kernels with kw > 1 as well through a 2-D window (weights: (ky, kx) flattened into x) -- the conventions of
+ * ppms_conv_gemm3.  nslice / workspace as for ppms_conv_gemm2_sliced (nslice == 1: none);
+ * ppms_conv_gemm2_ysweep_slices() = the slice count that pays off (0: not a candidate / window does not fit). */
 int ppms_conv_gemm2_ysweep_slices(const ppms_conv* desc);
 int ppms_conv_gemm2_ysweep(const ppms_conv* desc, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream);
 /* Large-map variant (128 couts x 256 pixels per workgroup, LDS-DMA operands, activation window swept by the taps along

@@ -34,7 +34,9 @@ struct Geo2 {
     int bstages;             // 2: window double-buffered; 1: single window + one extra barrier per window switch
     int ysweep;              // 1: (1, kh, 1) conv swept along y: column-major patch / window (fast axis y, logF = log2 R), taps step
                              //    the window row; weights packed with kh / kw swapped.  0: taps along x (fast axis x, logF = log2 C)
-    int ksw, logF;           // taps swept inside one window (kw, or kh when ysweep); log2 of the patch's fast-axis length
+    int ksw, logF;           // taps swept inside one window (kw; kh when ysweep; kh*kw for a 2-D window); log2 of the fast-axis length
+    int swn, jump;           // the LDS row advances by 1 per tap and by `jump` more after every `swn` taps (2-D window: kw, WR - kw)
+    int hs2;                 // 2-D window: halo rows above the patch (kh / 2); 0 otherwise
     int nslice;              // grid-level K slices (gridDim.y): slice s takes the row-steps s*KG + kg, + KG*nslice, ...
     float* part;             // nslice > 1: fp32 partial sums [slice][pixel][M] (no bias), finished by conv_slice_reduce_kernel
     int64_t P;               // pixels = T*H*W
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     const int H = p.H, W = p.W, T = p.T;
     const int HW = H * W;
     const int hy = p.kh >> 1, ht = p.kt >> 1;
-    const int hsw = g.ksw >> 1;               // halo of the window along the swept axis
+    const int hsw = g.swn >> 1;               // halo of the window along the fast (swept) axis
     const int F = 1 << g.logF;                // patch extent along the fast (swept) axis
 
     const int bplane = g.Wr * 64;
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         if (j < nslot_total) {
             const int wrow = j >> 2, c = j & 3;
             const int ws = wrow / g.WR, wf = wrow - ws * g.WR;       // slow / fast (swept, halo'd) window coordinate
-            const int x = g.ysweep ? x0 + ws : x0 + wf - hsw, y = g.ysweep ? y0 + wf - hsw : y0 + ws;
+            const int x = g.ysweep ? x0 + ws : x0 + wf - hsw, y = g.ysweep ? y0 + wf - hsw : y0 + ws - g.hs2;
             sl_lds[i] = swz2(wrow, c);
             sl_y[i] = y;
             if ((unsigned)x < (unsigned)W) sl_off[i] = (tf * H + y) * W + x;
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         for (int i = 0; i < 4; ++i) *(u32x4*)(s + i * NT * 16) = ra[i];
     };
     auto load_b = [&](int trow, int chunk) {
-        const int kho = g.ysweep ? 1 : p.kh;                       // kernel rows NOT swept inside a window
+        const int kho = (g.ysweep || g.hs2) ? 1 : p.kh;            // kernel rows NOT swept inside a window
         const int ky = trow % kho, kz = trow / kho;
-        const int dy = g.ysweep ? 0 : ky - hy, dt = kz - ht;
+        const int dy = kho == 1 ? 0 : ky - hy, dt = kz - ht;
         const int s = (chunk >= g.n0) ? 1 : 0;
         const int c0 = (chunk - (s ? g.n0 : 0)) * BK + cB * 8;
         const bf16_t* sh = (const bf16_t*)p.seg[s].hi;
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     // (T = 5: 24 % of the (5,1,1) GRU pass, 13 % of the 3x3x3 flow head).  Valid kz form one contiguous range.
     const int kz0 = (ht - tf) > 0 ? (ht - tf) : 0;
     const int kz1 = (ht + T - 1 - tf) < (p.kt - 1) ? (ht + T - 1 - tf) : (p.kt - 1);
-    const int rs_per_kz = (g.ysweep ? 1 : p.kh) * g.nchunk;
+    const int rs_per_kz = ((g.ysweep || g.hs2) ? 1 : p.kh) * g.nchunk;
     const int rs_end = (kz1 + 1) * rs_per_kz;
     const int kstride = KG * g.nslice;        // row-step = trow * nchunk + chunk; K-group kg of slice s takes every kstride-th one
     int rs = kz0 * rs_per_kz + (int)blockIdx.y * KG + kg;
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     store_a(0);
     store_b(0);
     __syncthreads();
-    int bsel = 0, kx = 0;
+    int bsel = 0, kx = 0, swx = 0, trow = 0;     // kx: tap index inside the window; trow: its LDS row offset
     for (int j = 0; j < nsteps; ++j) {
         const bool more = j + 1 < nsteps;
         const bool need_b = more && (kx + 1 == g.ksw);
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
             }
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                const int off = swz2(brow[nb] + kx, 2 * k16 + h);
+                const int off = swz2(brow[nb] + trow, 2 * k16 + h);
                 bh[nb] = *(const bf16x8*)(b_s + off);
                 bl[nb] = *(const bf16x8*)(b_s + bplane + off);
             }
@@ -228,10 +230,15 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         __syncthreads();
         if (need_b) {
             bsel = (g.bstages == 1) ? 0 : (bsel ^ 1);
-            kx = 0;
+            kx = swx = trow = 0;
             rs += kstride;
         } else {
             ++kx;
+            ++trow;
+            if (++swx == g.swn) {
+                swx = 0;
+                trow += g.jump;
+            }
         }
     }
 
@@ -418,11 +425,16 @@ extern "C" int ppms_conv_gemm2_slices(const ppms_conv* d) {
     return best;
 }
 
-// Same planner for the y-swept form (row-steps per temporal tap = chunks only)
+// Same planner for the y-swept and the 2-D window forms (row-steps per temporal tap = chunks only)
 extern "C" int ppms_conv_gemm2_ysweep_slices(const ppms_conv* d) {
-    if (d == nullptr || d->kw != 1 || d->kh <= 1) return 0;
+    if (d == nullptr || d->kh <= 1) return 0;
+    if (d->kw > 1) {                   // 2-D window: some 128-pixel patch with its halo must fit the staging slots
+        bool fits = false;
+        for (int C = 16; C <= 128; C *= 2) fits = fits || (C + d->kw - 1) * (128 / C + d->kh - 1) <= 256;
+        if (!fits) return 0;
+    }
     ppms_conv t = *d;
-    t.kw = d->kh;                      // as an x-swept (1, 1, kh) conv: same number of workgroups, row-steps and k-steps
+    t.kw = d->kh * d->kw;              // as an x-swept (1, 1, taps) conv: same number of workgroups, row-steps and k-steps
     t.kh = 1;
     return ppms_conv_gemm2_slices(&t);
 }
@@ -446,14 +458,16 @@ extern "C" int ppms_conv_gemm2_sliced(const ppms_conv* d, const ppms_conv* dev_d
     return ppms_check_launch("conv_gemm2_sliced");
 }
 
-// (kt, kh, 1) convs swept along y: one halo'd window serves all kh taps (the plain entry loads a window per tap).  Weights in
-// pack_conv2 order of the kernel with kh / kw swapped.  nslice as in ppms_conv_gemm2_sliced (1: no slicing, workspace unused).
+// Convs with kh > 1 whose taps all step ONE halo'd window per (dt, chunk) (the plain entry loads a window per kernel row):
+// (kt, kh, 1) kernels are swept along y, weights packed with kh / kw swapped; kernels with kw > 1 too use a 2-D window, weights
+// packed with (ky, kx) flattened into x -- the same conventions as ppms_conv_gemm3.  nslice as in ppms_conv_gemm2_sliced.
 extern "C" int ppms_conv_gemm2_ysweep(const ppms_conv* d, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream) {
-    PPMS_REQUIRE(d != nullptr && d->kw == 1 && d->kh > 1, "conv_gemm2_ysweep: needs a (kt, kh, 1) kernel with kh > 1");
+    PPMS_REQUIRE(d != nullptr && d->kh > 1, "conv_gemm2_ysweep: needs a kernel with kh > 1");
+    const int mode = d->kw > 1 ? 2 : 1;              // kw > 1: 2-D window over all kh x kw taps
     PPMS_REQUIRE(nslice >= 1 && nslice <= 16, "conv_gemm2_ysweep: nslice=%d", nslice);
-    if (nslice == 1) return conv2_launch(d, dev_desc, 0, 1, nullptr, stream, 1);
+    if (nslice == 1) return conv2_launch(d, dev_desc, 0, 1, nullptr, stream, mode);
     PPMS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "conv_gemm2_ysweep: workspace missing or not 16-B aligned");
-    const int rc = conv2_launch(d, dev_desc, 1, nslice, (float*)workspace, stream, 1);
+    const int rc = conv2_launch(d, dev_desc, 1, nslice, (float*)workspace, stream, mode);
     if (rc != 0) return rc;
     const int64_t P = (int64_t)d->T * d->H * d->W;
     const int64_t total = P * (d->M / 8);
@@ -495,30 +509,40 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
     }
     // patch width: the power of two in [16,128] wasting the fewest pixels of the 128-pixel tile (ties: the widest for an x
     // sweep, the narrowest -- tallest patch, smallest halo share -- for a y sweep)
+    // ysweep: 0 = taps along x (one window per (dt, dy)); 1 = (kt, kh, 1) kernel swept along y; 2 = 2-D window: all kh x kw taps of
+    // a (dt, chunk) step one window with a halo in x and y (weights packed with (ky, kx) flattened into x)
+    const bool win2d = ysweep == 2;
+    ysweep = ysweep == 1;
     PPMS_REQUIRE(!ysweep || (d->kw == 1 && d->kh > 1), "conv_gemm2: y sweep is for (kt, kh, 1) kernels");
+    PPMS_REQUIRE(!win2d || (d->kw > 1 && d->kh > 1), "conv_gemm2: the 2-D window is for kernels with kh > 1 and kw > 1");
     Geo2 g;
     int bestC = 16;
     double bestw = 1e30;
     for (int C = 16; C <= 128; C *= 2) {
         const int R = 128 / C;
         if (ysweep && C * (R + d->kh - 1) > 256) continue;          // window rows must fit the staging slots of one cout block
+        if (win2d && (C + d->kw - 1) * (R + d->kh - 1) > 256) continue;
         const double waste = (double)((d->W + C - 1) / C * C) * ((d->H + R - 1) / R * R) / ((double)d->W * d->H);
         if (ysweep ? waste < bestw - 1e-9 : waste <= bestw + 1e-9) {
             bestw = waste;
             bestC = C;
         }
     }
+    PPMS_REQUIRE(bestw < 1e29, "conv_gemm2: no patch shape fits the window");
     g.C = bestC;
     g.R = 128 / bestC;
     g.logC = 0;
     while ((1 << g.logC) < g.C) ++g.logC;
     g.ysweep = ysweep;
-    g.ksw = ysweep ? d->kh : d->kw;
+    g.ksw = ysweep ? d->kh : win2d ? d->kh * d->kw : d->kw;
     g.logF = ysweep ? 7 - g.logC : g.logC;
     g.tiles_x = (d->W + g.C - 1) / g.C;
     g.tiles_y = (d->H + g.R - 1) / g.R;
-    g.WR = (ysweep ? g.R : g.C) + g.ksw - 1;
-    g.Wr = (ysweep ? g.C : g.R) * g.WR;
+    g.swn = ysweep ? d->kh : d->kw;
+    g.WR = (ysweep ? g.R : g.C) + g.swn - 1;
+    g.hs2 = win2d ? d->kh >> 1 : 0;
+    g.jump = win2d ? g.WR - d->kw : 0;
+    g.Wr = (ysweep ? g.C : win2d ? g.R + d->kh - 1 : g.R) * g.WR;
     g.nchunk = nchunk;
     g.n0 = d->seg[0].c / BK;
     g.nk = d->kt * d->kh * nchunk * d->kw;
@@ -526,8 +550,8 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
     g.part = part;
     g.P = (int64_t)d->T * d->H * d->W;
     if (nslice > 1) {
-        PPMS_REQUIRE(((ysweep ? 1 : d->kh) * nchunk) % nslice == 0, "conv_gemm2: %d row-steps per temporal tap do not split into %d slices",
-                     (ysweep ? 1 : d->kh) * nchunk, nslice);
+        PPMS_REQUIRE((((ysweep || win2d) ? 1 : d->kh) * nchunk) % nslice == 0, "conv_gemm2: %d row-steps per temporal tap do not split into %d slices",
+                     ((ysweep || win2d) ? 1 : d->kh) * nchunk, nslice);
         PPMS_REQUIRE(d->epi[0].out_vt == nullptr && (d->m_split >= d->M || d->epi[1].out_vt == nullptr), "conv_gemm2: sliced launch cannot write out_vt");
     }
     const int ntiles = g.tiles_x * g.tiles_y * d->T;

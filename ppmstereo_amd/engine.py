@@ -33,7 +33,8 @@ TOP_K = 5
 CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
-USE_YSWEEP = os.environ.get("PPMS_YSWEEP", "1") != "0"    # conv_gemm2's y-swept form for (1, kh, 1) convs (A/B switch)
+_YS = os.environ.get("PPMS_YSWEEP", "1")                  # conv_gemm2 one-window forms: 0 = off, 1 = y-swept (1, kh, 1) convs (default),
+USE_YSWEEP, USE_WIN2D = _YS != "0", _YS == "2d"            # 2d = also the 2-D window for kh, kw > 1 (measured neutral to slower)
 USE_SLICES = os.environ.get("PPMS_SLICE", "1") != "0"     # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
 HOIST_INP = os.environ.get("PPMS_HOIST", "1") != "0"      # iteration-invariant inp share of the GRU gates computed once per scale
 ATTN16_TORCH = os.environ.get("PPMS_ATTN16", "hip") == "torch"   # update_block16 time/space attention: HIP (default) or torch ops
@@ -141,7 +142,7 @@ class PackedBlock:
         def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
             self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
             w5 = weight if weight.dim() == 5 else weight[:, :, None]
-            if CONV_VERSION == 2 and w5.shape[3] > 1 and w5.shape[4] > 1 and (m_pad or w5.shape[0]) % 128 == 0:
+            if CONV_VERSION == 2 and w5.shape[3] > 1 and w5.shape[4] > 1:
                 # k-step order of the large-map kernel's 2-D window sweep: (ky, kx) flattened into the x axis
                 flat = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, w5.shape[3] * w5.shape[4]).contiguous()
                 self.w[name + "_2d"] = pack_conv(flat, bias, segs, seg_pad, cout_map, m_pad)
@@ -310,11 +311,14 @@ class ScaleEngine:
                 packed3, bias3, _ = self.pk.w[key]
                 d.w, d.bias = packed3.data_ptr(), bias3.data_ptr()
                 return ConvOp(d, [packed3, bias3, *keep], 3)
-        if version == 2 and USE_YSWEEP and isinstance(wname, str) and k3[2] == 1 and k3[1] > 1 and wname + "_y" in self.pk.w:
-            # (1, kh, 1) conv on a map too small for the large-map kernel: conv_gemm2's y-swept form, same "_y" pack
-            packed_y, bias_y, _ = self.pk.w[wname + "_y"]
-            d.w, d.bias = packed_y.data_ptr(), bias_y.data_ptr()
-            return ConvOp(d, [packed_y, bias_y, *keep], 2, ysweep=True)
+        if version == 2 and USE_YSWEEP and isinstance(wname, str) and k3[1] > 1:
+            # kh > 1 on a map the large-map kernel does not take: conv_gemm2 with one window for all taps of a (dt, chunk)
+            # (y-swept "_y" pack for kw == 1, 2-D window "_2d" pack otherwise), when the halo'd window fits
+            key = wname + ("_y" if k3[2] == 1 else "_2d")
+            if (k3[2] == 1 or USE_WIN2D) and key in self.pk.w and self.lib.ppms_conv_gemm2_ysweep_slices(C.byref(d)) > 0:
+                packed_y, bias_y, _ = self.pk.w[key]
+                d.w, d.bias = packed_y.data_ptr(), bias_y.data_ptr()
+                return ConvOp(d, [packed_y, bias_y, *keep], 2, ysweep=True)
         return ConvOp(d, [packed, bias, *keep], version)
 
     def _conv_padded(self, wname, *a, **k) -> ConvOp:

@@ -87,7 +87,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     wpack = weight
     if (version == 3 or ysweep) and k3[2] == 1 and k3[1] > 1:            # y-swept kernels: pack with kh / kw swapped
         wpack = (weight if weight.dim() == 5 else weight[:, :, None]).transpose(3, 4).contiguous()
-    if version == 3 and k3[2] > 1 and k3[1] > 1:             # 2-D swept: (ky, kx) flattened into the x axis
+    if (version == 3 or ysweep) and k3[2] > 1 and k3[1] > 1:             # 2-D swept: (ky, kx) flattened into the x axis
         w5 = weight if weight.dim() == 5 else weight[:, :, None]
         wpack = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, k3[1] * k3[2]).contiguous()
     packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad)
@@ -266,10 +266,12 @@ def test_conv_gemm_k_sliced(lib, name, T, H, W, segs, cout, k3, nslice):
 
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3,nslice", [
     ("gru_1x5x1", 5, 40, 64, [128, 256], 256, (1, 5, 1), 1), ("gru_sliced", 5, 20, 32, [128, 384], 128, (1, 5, 1), 4),
-    ("ragged", 2, 11, 9, [64], 64, (1, 5, 1), 1), ("w80", 1, 23, 80, [64, 32], 192, (1, 5, 1), 3), ("3x_t", 3, 10, 18, [32], 64, (3, 3, 1), 1)])
+    ("ragged", 2, 11, 9, [64], 64, (1, 5, 1), 1), ("w80", 1, 23, 80, [64, 32], 192, (1, 5, 1), 3), ("3x_t", 3, 10, 18, [32], 64, (3, 3, 1), 1),
+    ("2d_3x3", 2, 9, 13, [128, 128], 128, (1, 3, 3), 1), ("2d_3x3x3_sliced", 4, 20, 32, [128], 190, (3, 3, 3), 4), ("2d_w80", 2, 23, 80, [320], 190, (1, 3, 3), 5),
+    ("2d_5x3", 1, 12, 40, [64], 64, (1, 5, 3), 2)])
 def test_conv_gemm2_y_sweep(lib, name, T, H, W, segs, cout, k3, nslice):
-    """conv_gemm2's y-swept form for (kt, kh, 1) convs (column-major patch / window, one window for all kh taps), with and
-    without K slicing, vs torch conv3d."""
+    """conv_gemm2's one-window forms: y-swept (kt, kh, 1) convs (column-major patch / window) and the 2-D window for
+    kh, kw > 1, with and without K slicing, vs torch conv3d."""
     L = lib
     P = T * H * W
     xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
