@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Benchmark of the PPMStereo hot path on MI355X (contract: see the round prompt / DESIGN.md section 5).
 
     python bench.py --gpus 1 --steps 5 --warmup 2

@@ -95,9 +95,8 @@ typedef struct ppms_conv {
 
 /* desc: host copy (validated, sizes the grid); dev_desc: the same bytes in device memory (caller-owned, must stay
  * valid until the kernel has run -- descriptors are built once per scale, every pointer in them is fixed). */
-int ppms_conv_gemm(const ppms_conv* desc, const ppms_conv* dev_desc, void* stream);
-/* Second-generation tiling of the same convolution (data-reuse: all couts per workgroup, LDS activation window swept
- * by the kw taps).  Same descriptor; desc->w must be in the pack_conv2 layout (ppmstereo_amd/packing.py).
+/* Data-reuse tiling: all couts of a pixel tile per workgroup, LDS activation window swept by the kw taps.
+ * desc->w must be in the pack_conv2 layout (ppmstereo_amd/packing.py).
  * wm_hint: 64-cout blocks per workgroup (1..4), 0 = let the library choose from the grid size. */
 int ppms_conv_gemm2(const ppms_conv* desc, const ppms_conv* dev_desc, int wm_hint, void* stream);
 /* K-sliced form of the same kernel for small maps (1/16 and 1/8 scales: fewer workgroups than CUs, long K loops):

@@ -51,7 +51,6 @@ _SIGS = {
     "ppms_corr_build": (c_int, [c_void_p, c_void_p, C.POINTER(c_void_p), c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_corr_lookup": (c_int, [C.POINTER(c_void_p), c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_int, c_int, c_int, c_int, c_void_p]),
-    "ppms_conv_gemm": (c_int, [C.POINTER(Conv), c_void_p, c_void_p]),
     "ppms_conv_gemm2": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
     "ppms_conv_gemm2_slices": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm2_slice_workspace_bytes": (C.c_int64, [C.POINTER(Conv), c_int]),

@@ -3,43 +3,58 @@
     python -m ppmstereo_amd.build          # or __graft_entry__.build()
 
 hipcc cross-compiles without a GPU; the .so is git-ignored but travels with the repo snapshot to the GPU box.
+
+Concurrency: several ranks of one torchrun job may import the package at once.  The whole build runs under an exclusive
+``flock`` on ``libppms.so.lock``; objects are compiled into a private temporary directory and the finished library and
+its stamp are moved into place with ``os.replace`` (atomic), so a process either maps the old complete library or the
+new complete one.  Ranks that lose the race wait on the lock, re-check the stamp and return without compiling.
 """
 from __future__ import annotations
 
+import fcntl
 import hashlib
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppms.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["corr.hip", "conv_gemm.hip", "conv_gemm2.hip", "conv_gemm3.hip", "small_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
-# v_pk_mul_f32 / v_pk_add_f32 (packed fp32) gave wrong results in lanes 48-63 of a wave of the bilinear resize kernel
-# whenever an MFMA-heavy kernel of another stream shared the SIMD (tools/race_probe.py, tests/test_gpu_concurrency.py: one of
-# the four taps was lost in 16-element runs; waits and nops around the loads did not help, disabling packed fp32 formation
-# did).  Every source except the memory attention is therefore compiled with -packed-fp32-ops; mem_attn.hip keeps the packed
-# forms (its exp / sum stream is 0.19 ms per 1/4-scale call faster with them; it is checked against the CPU restatement, by the
-# convex-combination property and under the same concurrency stress).
+LOCK = LIB + ".lock"
+SOURCES = ["corr.hip", "conv_gemm2.hip", "conv_gemm3.hip", "small_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
+HEADERS = ["common.h", "conv_epilogue.h", os.path.join("..", "..", "include", "ppms.h")]
+# Packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32) are disabled (NO_PK): a wave of the bilinear resize kernel returned
+# wrong values in lanes 48-63 when an MFMA-heavy kernel of another stream shared its SIMD (DESIGN.md section 5,
+# tools/race_probe.py, tests/test_gpu_concurrency.py).  Sources listed in PACKED_FP32_SOURCES keep the packed forms.
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-PACKED_FP32_SOURCES = ("mem_attn.hip",)
-FLAGS = COMMON + NO_PK                      # (kept for callers that print the flags)
+PACKED_FP32_SOURCES: tuple = tuple(x for x in os.environ.get("PPMS_BUILD_PACKED_FP32", "").split(",") if x)   # build-time A/B only
+FLAGS = COMMON + NO_PK
 
 
 def _digest() -> str:
-    h = hashlib.sha256(" ".join(COMMON + NO_PK + list(PACKED_FP32_SOURCES)).encode())
-    for f in sorted(os.listdir(CSRC)) + ["../../include/ppms.h"]:
+    """sha256 over the flags and exactly the files that go into the library (editor temp files do not count)."""
+    h = hashlib.sha256(" ".join(FLAGS + list(PACKED_FP32_SOURCES)).encode())
+    for f in SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(f.encode() + fh.read())
+            h.update(os.path.basename(f).encode() + fh.read())
     return h.hexdigest()
+
+
+def _fresh(dig: str) -> bool:
+    try:
+        return os.path.exists(LIB) and open(STAMP).read() == dig
+    except OSError:
+        return False
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+    if not force and _fresh(dig):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # the target feature is meant for the device pass only; the host pass of the same clang invocation reports it as unknown
@@ -55,16 +70,42 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if res.returncode != 0:
             raise subprocess.CalledProcessError(res.returncode, cmd)
 
-    objdir = os.path.join(HERE, "_obj")
-    os.makedirs(objdir, exist_ok=True)
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        run([hipcc] + COMMON + ([] if src in PACKED_FP32_SOURCES else NO_PK) + ["-c", os.path.join(CSRC, src), "-o", obj])
-        objs.append(obj)
-    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB])
-    with open(STAMP, "w") as fh:
-        fh.write(dig)
+    with open(LOCK, "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _fresh(dig):          # another process built it while this one waited
+                return LIB
+            tmp = tempfile.mkdtemp(prefix="_build_", dir=HERE)
+            try:
+                objs = []
+                procs = []
+                for src in SOURCES:                # compile the translation units in parallel (independent hipcc processes)
+                    obj = os.path.join(tmp, src.replace(".hip", ".o"))
+                    cmd = [hipcc] + (COMMON if src in PACKED_FP32_SOURCES else FLAGS) + ["-c", os.path.join(CSRC, src), "-o", obj]
+                    if verbose:
+                        print("[ppmstereo_amd.build]", " ".join(cmd), file=sys.stderr)
+                    procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+                    objs.append(obj)
+                for cmd, pr in procs:
+                    _, err = pr.communicate()
+                    err = "\n".join(ln for ln in err.splitlines() if noise not in ln)
+                    if err.strip():
+                        print(err, file=sys.stderr)
+                    if pr.returncode != 0:
+                        raise subprocess.CalledProcessError(pr.returncode, cmd)
+                out = os.path.join(tmp, "libppms.so")
+                run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out])
+                stamp = os.path.join(tmp, "stamp")
+                with open(stamp, "w") as fh:
+                    fh.write(dig)
+                if os.path.exists(STAMP):
+                    os.remove(STAMP)               # no window in which a new library sits beside an old stamp that matches
+                os.replace(out, LIB)
+                os.replace(stamp, STAMP)
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 

@@ -35,6 +35,24 @@ int ppms_check_launch(const char* what);
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Per-device one-time initialisation (dynamic-LDS limits of the kernels): the only mutable state of the library is this
+// lazily-initialised, immutable-afterwards table, guarded by std::call_once -- one flag per device, so a second GPU used
+// from the same process gets its own hipFuncSetAttribute calls.  Usage:
+//     static ppms_device_once once;  once.run([] { hipFuncSetAttribute(...); });
+#ifdef __cplusplus
+#include <mutex>
+struct ppms_device_once {
+    static constexpr int MAX_DEV = 64;
+    std::once_flag flag[MAX_DEV];
+    template <typename F>
+    void run(F&& f) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::call_once(flag[(unsigned)dev % MAX_DEV], f);
+    }
+};
+#endif
+
 // ---- device helpers ----------------------------------------------------------------------------
 // x ~= hi + lo with hi = bf16(x) (round to nearest even: identical to torch's .to(bfloat16)) and lo = bf16(x - hi)
 __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {

@@ -386,11 +386,8 @@ int launch2(const ppms_conv* d, const ppms_conv* dev_desc, const Geo2& g, int nt
     if (red > lds) lds = red;
     const size_t stg = (size_t)2 * WM * STG_WAVE;                        // so do the epilogue's transposition patches
     if (stg > lds) lds = stg;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv2_kernel<WM, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static ppms_device_once once;                                        // one per template instantiation
+    once.run([] { (void)hipFuncSetAttribute((const void*)conv2_kernel<WM, KG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     if (lds > 160 * 1024) {
         ppms_set_error("conv_gemm2: LDS budget exceeded (%zu B)", lds);
         return PPMS_EINVAL;

@@ -375,11 +375,8 @@ extern "C" int ppms_conv_gemm3(const ppms_conv* d, const ppms_conv* dev_desc, vo
     size_t lds = (size_t)2 * A_STAGE + (size_t)2 * g.Wr * 64;
     if (lds < (size_t)4 * STG_WAVE) lds = (size_t)4 * STG_WAVE;          // the epilogue's transposition patches reuse the stages
     PPMS_REQUIRE(g.Wr <= 64 * MAXS && lds <= 80 * 1024, "conv_gemm3: window of %d rows does not fit", g.Wr);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        attr_set = true;
-    }
+    static ppms_device_once once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)conv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
     hipLaunchKernelGGL(conv3_kernel, dim3(ntiles * g.mgroups), dim3(NT), lds, (hipStream_t)stream, dev_desc, g);
     return ppms_check_launch("conv_gemm3");
 }

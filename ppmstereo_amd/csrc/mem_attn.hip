@@ -9,7 +9,6 @@
 // to_v conv epilogue) so both MFMA operands are plain 8/16-byte LDS reads.  K rows are XOR-swizzled on 16-B chunks,
 // V^T rows on 8-B granules: all fragment reads are bank-conflict free.  Two LDS stages, register-staged prefetch.
 #include "common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -551,29 +550,20 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
     PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
     PPMS_REQUIRE(ksel >= 1 && ksel <= 5 && T >= 1 && n >= 1, "mem_attn: bad sizes ksel=%d T=%d n=%d", ksel, T, n);
     PPMS_REQUIRE(mf.hi && mf.lo && mfg.hi && mfg.lo && mf.ld % 8 == 0 && mfg.ld % 8 == 0, "mem_attn: mf / mfg must be 16-B aligned SP views");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static ppms_device_once once;
+    once.run([] {
         (void)hipFuncSetAttribute((const void*)mem_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         (void)hipFuncSetAttribute((const void*)mem_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        attr_set = true;
-    }
+        (void)hipFuncSetAttribute((const void*)mem_attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
+    });
     const float scale_log2 = scale * 1.4426950408889634f;
     // split over the picked frames when a workspace is given (ppms_mem_attn_workspace_bytes) and there is more than one
-    static const int qw_env = []() {
-        const char* e = getenv("PPMS_ATTN_QW");          // A/B switch: 32 = first-generation kernel (two waves per SIMD)
-        return e ? atoi(e) : 64;
-    }();
-    const bool use64 = qw_env != 32 && split_ws != nullptr && n % KT == 0;      // (its state lives in the workspace partials)
+    const bool use64 = split_ws != nullptr && n % KT == 0;      // (its state lives in the workspace partials)
     const bool split = use64 || (split_ws != nullptr && ksel > 1);
     float* part_o = split ? (float*)split_ws : nullptr;
     float* part_ml = split ? part_o + (size_t)T * ksel * n * D : nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (use64) {
-        static bool attr64 = false;
-        if (!attr64) {
-            (void)hipFuncSetAttribute((const void*)mem_attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
-            attr64 = true;
-        }
         const int g64 = (int)ceil_div(n, 64 * NW);
         int32_t* redo = (int32_t*)(part_ml + (size_t)T * ksel * n * 2);
         (void)hipMemsetAsync(redo, 0, (size_t)T * ksel * g64 * 2 * sizeof(int32_t), st);

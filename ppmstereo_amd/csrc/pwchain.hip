@@ -179,11 +179,8 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
 extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
     PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");
     constexpr size_t lds = 3 * ACT_BUF + W_BLK;                // 112 KiB
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)pwchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static ppms_device_once once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)pwchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * ACT_BUF + W_BLK)); });
     hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params);
     return ppms_check_launch("pwchain");
 }

@@ -27,34 +27,66 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     return rank, world, local
 
 
+def comm_device() -> torch.device:
+    """Where collective operands must live: the current GPU under RCCL ("nccl"), the host under gloo."""
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
-def max_over_ranks(value: float, device="cpu") -> float:
+def max_over_ranks(value: float, device=None) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=comm_device() if device is None else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def sum_over_ranks(value: float, device="cpu") -> float:
+def sum_over_ranks(value: float, device=None) -> float:
     if not dist.is_initialized():
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=comm_device() if device is None else device)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
 
-def gather_kept_frames(local: List[tuple], num_frames: int, H: int, W: int, device="cpu") -> Optional[torch.Tensor]:
-    """local: [(first_frame, disparity (k,1,H,W))] produced by this rank's windows.  Every rank contributes its frames
-    into a zero (num_frames,1,H,W) canvas; frames are disjoint across ranks, so one SUM all-reduce assembles the video
-    (a single end-of-job exchange, not a data-path collective)."""
-    canvas = torch.zeros(num_frames, 1, H, W, dtype=torch.float32, device=device)
-    for first, disp in local:
-        canvas[first:first + disp.shape[0]] = disp.to(device)
-    if dist.is_initialized():
-        dist.all_reduce(canvas, op=dist.ReduceOp.SUM)
-    return canvas
+def gather_kept_frames(local: List[tuple], num_frames: int, H: int, W: int, device=None) -> Optional[torch.Tensor]:
+    """local: [(first_frame, disparity (k,1,H,W))] produced by this rank's windows.  One end-of-job exchange (not a
+    data-path collective): every rank all-gathers only the frames it owns (padded to the largest per-rank count) plus
+    their frame indices, and places the received frames into the (num_frames,1,H,W) video."""
+    device = comm_device() if device is None else torch.device(device)
+    idx = [first + i for first, disp in local for i in range(disp.shape[0])]
+    frames = [disp.to(device=device, dtype=torch.float32) for _, disp in local]
+    mine = torch.cat(frames, 0) if frames else torch.zeros(0, 1, H, W, dtype=torch.float32, device=device)
+    out = torch.zeros(num_frames, 1, H, W, dtype=torch.float32, device=device)
+    if not dist.is_initialized():
+        if idx:
+            out[torch.tensor(idx, device=device)] = mine
+        return out
+    world = dist.get_world_size()
+    cnt = torch.tensor([len(idx)], dtype=torch.int64, device=device)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    cap = max(1, int(max(c.item() for c in cnts)))
+    pad_idx = torch.full((cap,), -1, dtype=torch.int64, device=device)
+    pad_frames = torch.zeros(cap, 1, H, W, dtype=torch.float32, device=device)
+    if idx:
+        pad_idx[:len(idx)] = torch.tensor(idx, device=device)
+        pad_frames[:len(idx)] = mine
+    all_idx = [torch.empty_like(pad_idx) for _ in range(world)]
+    all_frames = [torch.empty_like(pad_frames) for _ in range(world)]
+    dist.all_gather(all_idx, pad_idx)
+    dist.all_gather(all_frames, pad_frames)
+    for ii, ff in zip(all_idx, all_frames):
+        keep = ii >= 0
+        if keep.any():
+            out[ii[keep]] = ff[keep]
+    return out

@@ -29,19 +29,16 @@ from . import _lib as L
 from . import packing as _packing
 
 TOP_K = 5
-# 2 = data-reuse tiling (conv_gemm2.hip, default); 1 = first-generation kernel (conv_gemm.hip), kept for A/B checks
-CONV_VERSION = int(os.environ.get("PPMS_CONV", "2"))
+# tuning switches between HIP code paths of the library (A/B measurements on the GPU box; every setting runs HIP kernels only)
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
 _YS = os.environ.get("PPMS_YSWEEP", "1")                  # conv_gemm2 one-window forms: 0 = off, 1 = y-swept (1, kh, 1) convs (default),
 USE_YSWEEP, USE_WIN2D = _YS != "0", _YS == "2d"            # 2d = also the 2-D window for kh, kw > 1 (measured neutral to slower)
 USE_SLICES = os.environ.get("PPMS_SLICE", "1") != "0"     # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
 HOIST_INP = os.environ.get("PPMS_HOIST", "1") != "0"      # iteration-invariant inp share of the GRU gates computed once per scale
-ATTN16_TORCH = os.environ.get("PPMS_ATTN16", "hip") == "torch"   # update_block16 time/space attention: HIP (default) or torch ops
 
 
-def pack_conv(*a, **k):
-    return (_packing.pack_conv2 if CONV_VERSION == 2 else _packing.pack_conv)(*a, **k)
+pack_conv = _packing.pack_conv2
 
 
 def temporal_pe(T: int, channels: int) -> torch.Tensor:
@@ -66,10 +63,12 @@ def softmax_scale(c: int = 128) -> float:
 class ConvOp:
     """One implicit-GEMM launch: host descriptor (validated by the library) + its device copy."""
 
-    def __init__(self, desc: L.Conv, keep: list, version: int = 1, wm_hint: int = 0, nslice: Optional[int] = None, ysweep: bool = False):
+    def __init__(self, desc: L.Conv, keep: list, version: int = 2, wm_hint: int = 0, nslice: Optional[int] = None, ysweep: bool = False,
+                 device=None):
         self.desc, self.version, self.wm_hint, self.ysweep = desc, version, wm_hint, ysweep
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         raw = bytes(desc)
-        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone().cuda()
+        self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone().to(device)
         self.keep = keep            # tensors whose storage the descriptor points at
         # small maps: K-sliced launch + reduce kernel (nslice None: ask the library; own workspace per op because ops
         # of the two streams run concurrently)
@@ -78,7 +77,7 @@ class ConvOp:
             plan = L.load().ppms_conv_gemm2_ysweep_slices if ysweep else L.load().ppms_conv_gemm2_slices
             self.nslice = max(1, int(plan(C.byref(desc)))) if nslice is None else nslice
             if self.nslice > 1:
-                self.ws = torch.empty(int(L.load().ppms_conv_gemm2_slice_workspace_bytes(C.byref(desc), self.nslice)), dtype=torch.uint8, device="cuda")
+                self.ws = torch.empty(int(L.load().ppms_conv_gemm2_slice_workspace_bytes(C.byref(desc), self.nslice)), dtype=torch.uint8, device=device)
 
     def __call__(self):
         if self.ysweep:
@@ -87,10 +86,8 @@ class ConvOp:
             L.check(L.load().ppms_conv_gemm2_sliced(C.byref(self.desc), self.dev.data_ptr(), self.nslice, self.ws.data_ptr(), L.stream_ptr()))
         elif self.version == 3:
             L.check(L.load().ppms_conv_gemm3(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
-        elif self.version == 2:
-            L.check(L.load().ppms_conv_gemm2(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         else:
-            L.check(L.load().ppms_conv_gemm(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
+            L.check(L.load().ppms_conv_gemm2(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
 
 
 def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Optional[L.SP] = None, out_f32=None, out_f32_ld=0,
@@ -114,7 +111,8 @@ def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Opt
 class PwChain:
     """One fused per-pixel layer chain launch (pwchain.hip): host parameter block + device copy."""
 
-    def __init__(self, inp: L.SP, out: L.SP, layers, pixels: int, keep: list):
+    def __init__(self, inp: L.SP, out: L.SP, layers, pixels: int, keep: list, device=None):
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         cp = L.ChainParams()
         cp.inp, cp.out, cp.nlayers, cp.P = inp, out, len(layers), pixels
         for i, (pack, n_valid, resid, post) in enumerate(layers):
@@ -126,7 +124,7 @@ class PwChain:
             ly.post_t = None if post is None else post[1].data_ptr()
             keep += [packed, bias]
         self.pixels, self.keep = pixels, keep
-        self.dev = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).clone().cuda()
+        self.dev = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).clone().to(device)
 
     def __call__(self):
         L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
@@ -142,7 +140,7 @@ class PackedBlock:
         def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
             self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
             w5 = weight if weight.dim() == 5 else weight[:, :, None]
-            if CONV_VERSION == 2 and w5.shape[3] > 1 and w5.shape[4] > 1:
+            if w5.shape[3] > 1 and w5.shape[4] > 1:
                 # k-step order of the large-map kernel's 2-D window sweep: (ky, kx) flattened into the x axis
                 flat = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, w5.shape[3] * w5.shape[4]).contiguous()
                 self.w[name + "_2d"] = pack_conv(flat, bias, segs, seg_pad, cout_map, m_pad)
@@ -193,7 +191,7 @@ class PackedBlock:
         # iterations of one scale: its share of every gate pre-activation is computed once per scale ("*_i" packs, with
         # the bias) and added in the epilogue of the per-iteration convs over [h | mf, mfg] ("*_h" packs).  Not for
         # update_block16, whose time / space attention rewrites all of x every iteration.
-        self.hoist = "time_attn.temporal_fc.weight" not in sd and CONV_VERSION == 2 and HOIST_INP
+        self.hoist = "time_attn.temporal_fc.weight" not in sd and HOIST_INP
         if self.hoist:
             for name in ("zr1_0", "q1", "zr2", "q2", "zr3", "q3"):
                 if name.startswith("zr"):
@@ -302,28 +300,28 @@ class ScaleEngine:
         d.epi[0] = epi0
         if epi1 is not None:
             d.epi[1] = epi1
-        version = meta.get("version", 1)
-        if version == 2 and USE_CONV3 and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
+        version = 2
+        if USE_CONV3 and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
             # the large-map kernel wants its k-steps in sweep order: y-swept convs packed with kh / kw swapped ("_y"),
             # 2-D swept ones (kh, kw > 1) with (ky, kx) flattened into x ("_2d"); without such a pack: conv_gemm2
             key = wname + "_2d" if (k3[1] > 1 and k3[2] > 1) else wname + "_y" if (k3[2] == 1 and k3[1] > 1) else wname
             if key in self.pk.w:
                 packed3, bias3, _ = self.pk.w[key]
                 d.w, d.bias = packed3.data_ptr(), bias3.data_ptr()
-                return ConvOp(d, [packed3, bias3, *keep], 3)
-        if version == 2 and USE_YSWEEP and isinstance(wname, str) and k3[1] > 1:
+                return ConvOp(d, [packed3, bias3, *keep], 3, device=self.dev)
+        if USE_YSWEEP and isinstance(wname, str) and k3[1] > 1:
             # kh > 1 on a map the large-map kernel does not take: conv_gemm2 with one window for all taps of a (dt, chunk)
             # (y-swept "_y" pack for kw == 1, 2-D window "_2d" pack otherwise), when the halo'd window fits
             key = wname + ("_y" if k3[2] == 1 else "_2d")
             if (k3[2] == 1 or USE_WIN2D) and key in self.pk.w and self.lib.ppms_conv_gemm2_ysweep_slices(C.byref(d)) > 0:
                 packed_y, bias_y, _ = self.pk.w[key]
                 d.w, d.bias = packed_y.data_ptr(), bias_y.data_ptr()
-                return ConvOp(d, [packed_y, bias_y, *keep], 2, ysweep=True)
-        return ConvOp(d, [packed, bias, *keep], version)
+                return ConvOp(d, [packed_y, bias_y, *keep], 2, ysweep=True, device=self.dev)
+        return ConvOp(d, [packed, bias, *keep], version, device=self.dev)
 
     def _conv_padded(self, wname, *a, **k) -> ConvOp:
         """wname + "_p" (couts padded to a multiple of 128) when the large-map kernel takes it, else the tight pack."""
-        if USE_CONV3 and CONV_VERSION == 2 and wname + "_p" in self.pk.w:
+        if USE_CONV3 and wname + "_p" in self.pk.w:
             op = self._conv(wname + "_p", *a, **k)
             if op.version == 3:
                 return op
@@ -337,15 +335,16 @@ class ScaleEngine:
         o = self.op
         self._qk_ops: Dict[int, ConvOp] = {}
         o["init0"] = self._conv("init0", [inp], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=self.ZT.view(0, 64)))
-        if USE_PWCHAIN and CONV_VERSION == 2:
+        if USE_PWCHAIN:
             w = self.pk.w
             (w1, b1, _), _ = self.pk.dw
             dw1 = (w1.reshape(64).contiguous(), b1)
             # chain A: x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))      CORR -> C2
-            o["chainA"] = PwChain(self.CORR.view(), self.C2.view(), [(w["ffn1_0"], 54, False, None), (w["ffn1_2"], 36, True, dw1)], self.P, [dw1[0]])
+            o["chainA"] = PwChain(self.CORR.view(), self.C2.view(), [(w["ffn1_0"], 54, False, None), (w["ffn1_2"], 36, True, dw1)], self.P, [dw1[0]],
+                                 device=self.dev)
             # chain B: x4 = gelu(x3 + pw x3); cor = gelu(ffn2(x4))              C1 -> COR256
             o["chainB"] = PwChain(self.C1.view(), self.COR256.view(), [(w["pw"], 36, True, None), (w["ffn2_0"], 54, False, None),
-                                                                       (w["ffn2_2"], 256, False, None)], self.P, [])
+                                                                       (w["ffn2_2"], 256, False, None)], self.P, [], device=self.dev)
         o["ffn1_0"] = self._conv("ffn1_0", [self.CORR.view()], k1, E(act=L.ACT_GELU, n_valid=54, out_sp=self.T1.view()))
         o["ffn1_2"] = self._conv("ffn1_2", [self.T1.view()], k1, E(L.EPI_RESID, L.ACT_GELU, n_valid=36, out_sp=self.C1.view(), aux_sp=self.CORR.view()))
         o["pw"] = self._conv("pw", [self.C1.view()], k1, E(L.EPI_RESID, L.ACT_GELU, n_valid=36, out_sp=self.C2.view(), aux_sp=self.C1.view()))
@@ -572,12 +571,6 @@ class ScaleEngine:
     def block16_attention(self):
         """TimeAttnBlock + SpaceAttnBlock on x = [inp, mf, mfg] (update_block16 only, ppmtereo_update.py:593-631,
         980-983): LayerNorm / temporal attention / linear-attention kernels (attn16.hip) + seven 1x1 GEMMs."""
-        if ATTN16_TORCH:                           # A/B path: fp32 torch-ROCm tensor ops (ppmstereo_amd/attn16.py)
-            from .attn16 import time_space_attention
-            x = self.X.to_f32()                                                 # (P, 384)
-            x = time_space_attention(self.pk.attn, x, self.T, self.h, self.w)
-            self.XA.set_f32(x)
-            return
         o, s, lib, ln = self.op, self._s(), self.lib, self.pk.ln
         none_sp = L.SP(None, None, 0, 0)
         # TimeAttnBlock: x + fc(proj(attn_T(LN(x))))                                      ppmtereo_update.py:603-618

@@ -3,11 +3,10 @@
 Reference layout: Conv2d (Cout, Cin, kh, kw) / Conv3d (Cout, Cin, kt, kh, kw) fp32
 (/root/reference/models/core/ppmtereo_update.py, e.g. :254-289).
 
-Packed layout (ppmstereo_amd/csrc/conv_gemm.hip): bf16 [M/64][nk][2 planes (hi, lo)][64 couts][32 k] where the
-GEMM K axis is k = tap * Cpad + ci, tap = (kz*kh + ky)*kw + kx, ci runs over the input segments in order (each
-zero-padded to a multiple of 32 channels), and inside each [64][32] tile the four 16-byte chunks of row m are
-stored at chunk position c ^ ((m >> 2) & 3) (the kernel's bank-conflict-free read swizzle).  One (cout block,
-k-step) tile is therefore a contiguous 8 KiB block that a workgroup copies to LDS with linear 16-byte stores.
+Packed layout (ppmstereo_amd/csrc/conv_gemm2.hip, conv_gemm3.hip): bf16 [k-step][M/64][2 planes (hi, lo)][64 couts][32 k];
+the input segments are concatenated along K (each zero-padded to a multiple of 32 channels), and inside each [64][32]
+tile the four 16-byte chunks of row m are stored at chunk position c ^ ((m >> 2) & 3) (the kernels' bank-conflict-free
+read swizzle).  One (k-step, cout block) tile is a contiguous 8 KiB block that reaches LDS by a linear copy.
 """
 from __future__ import annotations
 
@@ -28,58 +27,13 @@ def split_bf16(x: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return hi, lo
 
 
-def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
-              seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
-              m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:
-    """weight: (Cout, Cin, [kt,] kh, kw); seg_channels: real channels of each input segment (sum == Cin);
-    seg_padded: channels of each segment's SP view (multiples of 32, >= real); cout_map[i] = packed row of
-    reference cout i (default identity) -- lets a conv route groups of couts to 64-aligned blocks.
-    Returns (packed bf16 tensor, bias fp32 [M], meta)."""
-    w = weight.detach().float()
-    if w.dim() == 4:
-        w = w[:, :, None]
-    cout, cin, kt, kh, kw = w.shape
-    assert sum(seg_channels) == cin, (seg_channels, cin)
-    seg_padded = [_pad_to(c, BK) for c in seg_channels] if seg_padded is None else list(seg_padded)
-    assert all(p % BK == 0 and p >= c for p, c in zip(seg_padded, seg_channels))
-    cpad = sum(seg_padded)
-    taps = kt * kh * kw
-    rows = list(range(cout)) if cout_map is None else list(cout_map)
-    M = _pad_to(max(rows) + 1, BM) if m_pad is None else m_pad
-    assert M % BM == 0 and max(rows) < M
-    wk = w.permute(0, 2, 3, 4, 1).reshape(cout, taps, cin)              # [cout][tap][ci]
-    full = torch.zeros(M, taps, cpad, dtype=torch.float32, device=w.device)
-    ridx = torch.tensor(rows, device=w.device)
-    src = 0
-    dst = 0
-    for c, p in zip(seg_channels, seg_padded):
-        full[ridx, :, dst:dst + c] = wk[:, :, src:src + c]
-        src += c
-        dst += p
-    K = taps * cpad
-    nk = K // BK
-    tiles = full.reshape(M // BM, BM, nk, 4, 8).permute(0, 2, 1, 3, 4).contiguous()      # [mblk][ks][m][chunk][8]
-    m = torch.arange(BM, device=w.device)
-    chunk = torch.arange(4, device=w.device)
-    pos = chunk[None, :] ^ ((m[:, None] >> 2) & 3)                        # [m][chunk] -> stored position
-    sw = torch.empty_like(tiles)
-    sw[:, :, m[:, None].expand(BM, 4), pos] = tiles                       # sw[.., m, pos[m,c], :] = tiles[.., m, c, :]
-    hi, lo = split_bf16(sw)
-    packed = torch.stack([hi, lo], dim=2).contiguous()                    # [mblk][ks][2][64][4][8]
-    b = torch.zeros(M, dtype=torch.float32, device=w.device)
-    if bias is not None:
-        b[ridx] = bias.detach().float()
-    meta = dict(M=M, nk=nk, taps=(kt, kh, kw), cpad=cpad, seg_padded=seg_padded)
-    return packed.reshape(-1), b, meta
-
-
 def pack_conv2(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
                seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
                m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:
     """Layout of the second-generation kernel (ppmstereo_amd/csrc/conv_gemm2.hip):
     bf16 [k-step][M/64][2 planes][64][32], k-step = ((kz*kh + ky) * nchunk + chunk) * kw + kx -- the kw taps along x
     of one (dt, dy, 32-channel chunk) are consecutive k-steps (they sweep one LDS activation window) and all cout
-    blocks of a k-step are contiguous (one workgroup stages them with a single linear copy).  Same swizzle as v1."""
+    blocks of a k-step are contiguous (one workgroup stages them with a single linear copy).  """
     w = weight.detach().float()
     if w.dim() == 4:
         w = w[:, :, None]
@@ -118,7 +72,7 @@ def pack_conv2(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
 
 
 def unpack_conv2_reference(packed: torch.Tensor, M: int, nk: int, taps, nchunk: int) -> torch.Tensor:
-    """Inverse of pack_conv2 -> fp32 [M][K] in the v1 K order (k = tap*Cpad + ci), for the host-logic tests."""
+    """Inverse of pack_conv2 -> fp32 [M][K] in the plain K order (k = tap*Cpad + ci, tap = (kz*kh + ky)*kw + kx), for the host-logic tests."""
     kt, kh, kw = taps
     t = packed.reshape(nk, M // BM, 2, BM, 4, 8).float()
     t = t[:, :, 0] + t[:, :, 1]
@@ -128,14 +82,3 @@ def unpack_conv2_reference(packed: torch.Tensor, M: int, nk: int, taps, nchunk: 
     un = t[:, :, m[:, None].expand(BM, 4), pos]                            # [ks][mblk][m][c][8]
     un = un.reshape(kt * kh, nchunk, kw, M // BM, BM, 32).permute(3, 4, 0, 2, 1, 5)      # [mblk][m][trow][kx][chunk][32]
     return un.reshape(M, kt * kh * kw * nchunk * 32)
-
-
-def unpack_conv_reference(packed: torch.Tensor, M: int, nk: int) -> torch.Tensor:
-    """Inverse of the tiling/swizzle (hi + lo, fp32 [M][nk*32]); used by the host-logic tests."""
-    t = packed.reshape(M // BM, nk, 2, BM, 4, 8).float()
-    t = t[:, :, 0] + t[:, :, 1]
-    m = torch.arange(BM)
-    chunk = torch.arange(4)
-    pos = chunk[None, :] ^ ((m[:, None] >> 2) & 3)
-    un = t[:, :, m[:, None].expand(BM, 4), pos]                            # un[.., m, c, :] = t[.., m, pos[m,c], :]
-    return un.permute(0, 2, 1, 3, 4).reshape(M, nk * BK)

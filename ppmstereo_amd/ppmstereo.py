@@ -61,23 +61,24 @@ def forward_update_block(self, image1, update_block: SequenceUpdateBlock3D, corr
         # the reference divides 0/0 in the temporal encoding (ppmtereo_update.py:34-36): every output is NaN
         warnings.warn("PPMStereo with a single frame produces NaN disparities (reference behaviour, T must be >= 2)")
     isc = int(interp_scale)
-    eng = update_block.engine(t, h, w, inp.device)
-    eng.set_inp(inp)
-    eng.set_net(net)
-    eng.set_flow(flow)
-    eng.set_mhs(motion_hidden_state)
-    eng.begin(corr_fn.levels, attn_block.packed(inp.device))
-    flow_out = None
-    for _ in range(iters):
-        flow_out = eng.iterate()
-        unc_up = bilinear(eng.UNC.view(t, 1, h, w), (4 * isc * h, 4 * isc * w), False)
-        if isc > 1:
-            flow_up = bilinear(flow_out[:, :1], (isc * 4 * h, isc * 4 * w), True, float(isc))
-        else:
-            flow_up = flow_out[:, :1].clone()
-        predictions.append(flow_up)
-        uncertainties.append(unc_up)
-    return flow_out.clone(), eng.get_net(), eng.get_mhs()
+    with torch.cuda.device(inp.device):         # kernels go to the current stream of the tensors' device
+        eng = update_block.engine(t, h, w, inp.device)
+        eng.set_inp(inp)
+        eng.set_net(net)
+        eng.set_flow(flow)
+        eng.set_mhs(motion_hidden_state)
+        eng.begin(corr_fn.levels, attn_block.packed(inp.device))
+        flow_out = None
+        for _ in range(iters):
+            flow_out = eng.iterate()
+            unc_up = bilinear(eng.UNC.view(t, 1, h, w), (4 * isc * h, 4 * isc * w), False)
+            if isc > 1:
+                flow_up = bilinear(flow_out[:, :1], (isc * 4 * h, isc * 4 * w), True, float(isc))
+            else:
+                flow_up = flow_out[:, :1].clone()
+            predictions.append(flow_up)
+            uncertainties.append(unc_up)
+        return flow_out.clone(), eng.get_net(), eng.get_mhs()
 
 
 class PPMStereoHotPath(nn.Module):

@@ -8,7 +8,8 @@ its checkpoints load unchanged); their ``forward`` is never called.  There is no
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Tuple
+from collections import OrderedDict
+from typing import Optional, Tuple
 
 import torch
 import torch.nn as nn
@@ -172,27 +173,39 @@ class SequenceUpdateBlock3D(nn.Module):
                 raise NotImplementedError("attention_type must contain both update_time and update_space (or be None)")
         self.aggregator = _Aggregate(128)
         self._pk: Optional[PackedBlock] = None
-        self._engines: Dict[Tuple, ScaleEngine] = {}
+        # engines hold every buffer of a scale (gigabytes at 736x1280): keep the two most recently used geometries only
+        # (a long video's last window may have a different T than the others)
+        self._engines: "OrderedDict[Tuple, ScaleEngine]" = OrderedDict()
         self.register_load_state_dict_post_hook(lambda m, k: m.invalidate())
+
+    MAX_ENGINES = 2
 
     # ------------------------------------------------------------------ engine plumbing
     def invalidate(self):
         """Call after changing parameters in place: weights are re-packed on next use."""
         self._pk = None
-        self._engines = {}
+        self._engines = OrderedDict()
 
     def packed(self, device) -> PackedBlock:
         if self._pk is None or self._pk.beta.device != torch.device(device):
             sd = {k: v for k, v in self.state_dict().items()}
-            self._pk = PackedBlock(sd, device)
-            self._engines = {}
+            with torch.cuda.device(device):
+                self._pk = PackedBlock(sd, device)
+            self._engines = OrderedDict()
         return self._pk
 
     def engine(self, T: int, h: int, w: int, device) -> ScaleEngine:
+        device = torch.device(device)
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         key = (T, h, w, str(device))
         pk = self.packed(device)
         if key not in self._engines:
-            self._engines[key] = ScaleEngine(pk, T, h, w, device)
+            while len(self._engines) >= self.MAX_ENGINES:
+                self._engines.popitem(last=False)
+            with torch.cuda.device(device):
+                self._engines[key] = ScaleEngine(pk, T, h, w, device)
+        self._engines.move_to_end(key)
         return self._engines[key]
 
     # ------------------------------------------------------------------ reference methods (NCHW in / NCHW out)
@@ -200,14 +213,15 @@ class SequenceUpdateBlock3D(nn.Module):
         """ppmtereo_update.py:945-950: (mf (N,128,h,w), mhs (N,64,h,w), value (N,128,h,w))."""
         L.require_gpu(flow, corr, inp)
         N, _, h, w = flow.shape
-        e = self.engine(N, h, w, flow.device)
-        e.set_flow(flow)
-        e.set_inp(inp)
-        e.set_mhs(motion_hidden_state)
-        e.load_nchw(corr, e.CORR.view(0, 36))
-        L.check(e.lib.ppms_f32_to_sp(e.FLOW.data_ptr(), 2, e.X.view(254, 2), e.P, L.stream_ptr()))
-        e.motion_and_value()
-        return e.get_mf(), e.get_mhs(), e.get_value()
+        with torch.cuda.device(flow.device):
+            e = self.engine(N, h, w, flow.device)
+            e.set_flow(flow)
+            e.set_inp(inp)
+            e.set_mhs(motion_hidden_state)
+            e.load_nchw(corr, e.CORR.view(0, 36))
+            L.check(e.lib.ppms_f32_to_sp(e.FLOW.data_ptr(), 2, e.X.view(254, 2), e.P, L.stream_ptr()))
+            e.motion_and_value()
+            return e.get_mf(), e.get_mhs(), e.get_value()
 
     def get_uncertainty(self, net):
         """ppmtereo_update.py:936-938 on cat([net, value]) (N,256,h,w) -> (N,1,h,w)."""
@@ -215,11 +229,12 @@ class SequenceUpdateBlock3D(nn.Module):
         N, c, h, w = net.shape
         if c != 256:
             raise RuntimeError("get_uncertainty expects cat([net, value]) with 256 channels")
-        e = self.engine(N, h, w, net.device)
-        e.set_net(net[:, :128])
-        e.load_nchw(net[:, 128:], e.VAL.view())
-        e.uncertainty()
-        return e.get_unc()
+        with torch.cuda.device(net.device):
+            e = self.engine(N, h, w, net.device)
+            e.set_net(net[:, :128])
+            e.load_nchw(net[:, 128:], e.VAL.view())
+            e.uncertainty()
+            return e.get_unc()
 
     def forward(self, net, inp, motion_features, motion_features_global, t=1):
         """ppmtereo_update.py:971-1003 -> (net, mask, delta_flow)."""
@@ -227,10 +242,11 @@ class SequenceUpdateBlock3D(nn.Module):
         N, _, h, w = net.shape
         if N != t:
             raise NotImplementedError("batch size 1 only: the frame axis of the 3-D convolutions is the whole batch")
-        e = self.engine(N, h, w, net.device)
-        e.set_net(net)
-        e.set_inp(inp)
-        e.set_mf(motion_features)
-        e.set_mfg(motion_features_global)
-        e.update()
-        return e.get_net(), e.get_mask(), e.get_dflow()
+        with torch.cuda.device(net.device):
+            e = self.engine(N, h, w, net.device)
+            e.set_net(net)
+            e.set_inp(inp)
+            e.set_mf(motion_features)
+            e.set_mfg(motion_features_global)
+            e.update()
+            return e.get_net(), e.get_mask(), e.get_dflow()

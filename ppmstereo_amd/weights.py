@@ -82,8 +82,8 @@ def update_block_param_shapes(with_attention: bool) -> "OrderedDict[str, Tuple[i
         for n in ("norm1", "norm2"):
             s[p + n + ".weight"] = (d,)
             s[p + n + ".bias"] = (d,)
+    s["aggregator.beta"] = (1,)                       # a module's own parameters precede its children's in state_dict()
     s["aggregator.to_v.weight"] = (128, 128, 1, 1)
-    s["aggregator.beta"] = (1,)
     return s
 
 

@@ -41,7 +41,7 @@ def test_argument_errors_are_reported_not_raised_in_c():
     ptrs = (ctypes.c_void_p * 5)()
     assert lib.ppms_corr_build(None, None, ptrs, 1, 256, 4, 8, None) == -1           # W < 16: pyramid impossible
     assert b"too small" in lib.ppms_last_error()
-    assert lib.ppms_conv_gemm(None, None, None) == -1
+    assert lib.ppms_conv_gemm2(None, None, 0, None) == -1
     with pytest.raises(RuntimeError):
         L.check(lib.ppms_bilinear(None, None, 1, 1, 1, 1, 1, 1, 0, 1.0, None))
 

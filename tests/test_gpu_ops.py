@@ -74,8 +74,7 @@ def test_ops_refuse_cpu_tensors(lib):
 def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None, nslice=None, ysweep=False):
     """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
     from ppmstereo_amd.engine import ConvOp, epilogue
-    from ppmstereo_amd.packing import pack_conv as pack1, pack_conv2
-    pack_conv = pack_conv2 if version >= 2 else pack1
+    from ppmstereo_amd.packing import pack_conv2 as pack_conv
     P = T * H * W
     segs, keep = [], []
     seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
@@ -150,7 +149,7 @@ CONV_CASES = [
 CONV_CASES += [("wide_1x15", 1, 3, 300, [64], 128, (1, 1, 15)), ("w80_3x3", 2, 46, 80, [32], 64, (1, 3, 3)), ("w18_1x5", 2, 10, 18, [64, 32], 192, (1, 1, 5))]
 
 
-@pytest.mark.parametrize("version,wm", [(2, 0), (2, 1), (1, 0)])
+@pytest.mark.parametrize("version,wm", [(2, 0), (2, 1)])
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV_CASES)
 def test_conv_gemm_vs_torch(lib, name, T, H, W, segs, cout, k3, version, wm):
     P = T * H * W
@@ -165,7 +164,7 @@ def test_conv_gemm_vs_torch(lib, name, T, H, W, segs, cout, k3, version, wm):
     assert maxdiff(got, ref) < tol, name
 
 
-@pytest.mark.parametrize("version", [2, 1])
+@pytest.mark.parametrize("version", [2])
 def test_conv_gemm_epilogues(lib, version):
     import functools
     global _run_conv
@@ -219,7 +218,7 @@ def test_conv_gemm3_vs_torch(lib, name, T, H, W, segs, cout, k3):
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
-@pytest.mark.parametrize("version", [3, 2, 1])
+@pytest.mark.parametrize("version", [3, 2])
 def test_conv_gemm_hoisted_input_share(lib, version):
     """conv([h | inp | rest]) == conv_h_rest([h | rest]) + pre, pre = conv_inp(inp) + bias computed by another launch
     (the engine hoists the inp share of the GRU gates out of the iteration loop): every epilogue adds pre_f32 to
@@ -291,7 +290,7 @@ def test_conv_gemm_rejects_bad_descriptors(lib):
     L = lib
     d = L.Conv()
     with pytest.raises(RuntimeError):
-        L.check(L.load().ppms_conv_gemm(C.byref(d), None, None))
+        L.check(L.load().ppms_conv_gemm2(C.byref(d), None, 0, None))
 
 
 # ------------------------------------------------------------------------------------------------ small ops

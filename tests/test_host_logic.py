@@ -7,19 +7,15 @@ import torch.nn.functional as F
 
 from oracle import ppm_oracle as O
 from ppmstereo_amd import weights as Wm
-from ppmstereo_amd.packing import BK, pack_conv, pack_conv2, unpack_conv2_reference, unpack_conv_reference
+from ppmstereo_amd.packing import BK, pack_conv2, unpack_conv2_reference
 from ppmstereo_amd.weights import hash_normal
 
 
 def emulate_kernel(packed, bias, meta, xs, seg_pad, T, H, W):
-    """(for the v2 layout the weight matrix is first brought back to the v1 K order)"""
-    """What conv_gemm.hip computes, restated with torch on the CPU from the PACKED weights: K order
-    k = tap*Cpad + ci, tap = (kz*kh + ky)*kw + kx, shifted zero-padded pixel rows."""
+    """What the implicit-GEMM kernels compute, restated with torch on the CPU from the PACKED weights (brought back to
+    the plain K order k = tap*Cpad + ci, tap = (kz*kh + ky)*kw + kx) and shifted zero-padded pixel rows."""
     kt, kh, kw = meta["taps"]
-    if meta.get("version") == 2:
-        Wm_ = unpack_conv2_reference(packed.cpu(), meta["M"], meta["nk"], meta["taps"], meta["cpad"] // BK)
-    else:
-        Wm_ = unpack_conv_reference(packed.cpu(), meta["M"], meta["nk"])        # [M][K]
+    Wm_ = unpack_conv2_reference(packed.cpu(), meta["M"], meta["nk"], meta["taps"], meta["cpad"] // BK)        # [M][K]
     P = T * H * W
     cols = []
     xp = []
@@ -43,8 +39,8 @@ def emulate_kernel(packed, bias, meta, xs, seg_pad, T, H, W):
 
 @pytest.mark.parametrize("segs,cout,k3", [([36], 54, (1, 1, 1)), ([128, 384], 256, (1, 1, 15)), ([128, 64], 128, (5, 1, 1)),
                                           ([128], 190, (3, 3, 3)), ([320], 190, (1, 3, 3))])
-@pytest.mark.parametrize("packer", [pack_conv, pack_conv2])
-def test_packing_reproduces_the_convolution(segs, cout, k3, packer):
+def test_packing_reproduces_the_convolution(segs, cout, k3):
+    packer = pack_conv2
     T, H, W = 3, 4, 6
     P = T * H * W
     cin = sum(segs)
@@ -63,8 +59,8 @@ def test_packing_reproduces_the_convolution(segs, cout, k3, packer):
 def test_packing_cout_map_routes_groups_to_aligned_blocks():
     wt, bs = hash_normal((190, 320, 3, 3), 30) / 50, hash_normal((190,), 31)
     rows = list(range(126)) + list(range(128, 192))
-    packed, bias, meta = pack_conv(wt, bs, [320], None, rows, 192)
-    full = unpack_conv_reference(packed, 192, meta["nk"])
+    packed, bias, meta = pack_conv2(wt, bs, [320], None, rows, 192)
+    full = unpack_conv2_reference(packed, 192, meta["nk"], meta["taps"], meta["cpad"] // BK)
     assert meta["M"] == 192 and (full[126:128] == 0).all() and (bias[126:128] == 0).all()
     assert torch.allclose(bias[128:192], bs[126:]) and torch.allclose(bias[:126], bs[:126])
 
@@ -75,7 +71,7 @@ def test_update_block_state_dict_is_the_reference_layout():
     for tag, attn in (("update_block16", True), ("update_block08", False), ("update_block04", False)):
         sd = getattr(m, tag).state_dict()
         want = Wm.update_block_param_shapes(attn)
-        assert list(sd.keys()) == list(sd.keys()) and set(sd.keys()) == set(want.keys())
+        assert list(sd.keys()) == list(want.keys()), "same parameter names in the same (registration) order as the reference module"
         for k, shape in want.items():
             assert tuple(sd[k].shape) == tuple(shape), k
     assert tuple(m.att[0].state_dict()["to_qk.weight"].shape) == (256, 128, 1, 1)

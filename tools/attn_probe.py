@@ -1,6 +1,9 @@
-#!/usr/bin/env python3
 """Runs the memory-attention kernel alone at the BASELINE 1/4-scale shape (T=5, n=10240, 5 picked frames) a few times:
-target for rocprofv3 --pmc passes.  usage: tools/attn_probe.py [reps] [split 0/1]"""
+target for rocprofv3 --pmc passes.  Put the interpreter binary itself after `--` (no env / bash / shebang hop: the profiler's
+preloaded library has initialised the GPU, and an exec from such a process takes the box down):
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -- /usr/bin/python3 tools/attn_probe.py 4 1
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -- /usr/bin/python3 tools/attn_probe.py 4 1
+arguments: [reps] [split 0/1]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Times individual engine ops at BASELINE config 2's 1/4 scale (T=5, 80x128) with HIP events.
 usage: tools/conv_probe.py op1,op2,... [reps]"""
 import os

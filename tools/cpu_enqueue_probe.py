@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """How long does the host need to ENQUEUE one clip (no sync) vs the GPU time?  If enqueue >= GPU time the loop is
 launch-bound and hipGraph capture would pay."""
 import os, sys, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Cost of the fused conv epilogues at BASELINE config 2's 1/4 scale: times a GRU conv as built by the engine and with
 its epilogue reduced step by step (no hoisted share, plain SP store).  usage: tools/epi_probe.py [op,...] [reps]"""
 import copy

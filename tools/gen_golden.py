@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
 
 The reference lives read-only at /root/reference and never travels: this script imports it in place

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Experiment: capture one cascade call (config 2) in a HIP graph (torch.cuda.CUDAGraph) and compare replay with eager."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Concurrency stress probe: runs small kernels of the library on the current stream while a conv kernel (or a torch GEMM) runs
 on another stream, and counts runs whose result differs from the kernel running alone.  This is how the packed-fp32 problem
 was found (ppmstereo_amd/build.py): with v_pk_*_f32 enabled, ppms_bilinear lost one of its four taps in lanes 48-63 of some

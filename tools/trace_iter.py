@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Summarise a rocprofv3 kernel trace of bench.py: per-scale wall/busy time and the per-launch durations of the last
 1/4-scale iteration.  usage: tools/trace_iter.py <kernel_trace.csv>"""
 import csv
