@@ -279,7 +279,8 @@ def space_attn(W, x: Tensor) -> Tensor:
 
 
 def update_block_forward(W, net, inp, mf, mfg, t: int, with_attention: bool):
-    """SequenceUpdateBlock3D.forward, ppmtereo_update.py:971-1003 (use_convex_3d=False)."""
+    """SequenceUpdateBlock3D.forward, ppmtereo_update.py:971-1003.  The mask head follows the weights: "mask_3d.*"
+    present = use_convex_3d=True (:993-996: 3x3x3 conv 128->256, ReLU, 1x1x1 conv 256->432 on the (b,c,t,h,w) state)."""
     x = torch.cat([inp, mf, mfg], 1)
     if with_attention:
         x = time_attn(W, x, t)
@@ -291,7 +292,10 @@ def update_block_forward(W, net, inp, mf, mfg, t: int, with_attention: bool):
     net5 = gru3d(W, to5(net), to5(x))
     dflow = to4(flow_head3d(W, net5))
     net = to4(net5)
-    mask = 0.25 * _c2(W, "mask_2d.2", F.relu(_c2(W, "mask_2d.0", net, 1)))
+    if "mask_3d.0.weight" in W:
+        mask = to4(0.25 * _c3(W, "mask_3d.2", F.relu(_c3(W, "mask_3d.0", net5, 1)), 0))
+    else:
+        mask = 0.25 * _c2(W, "mask_2d.2", F.relu(_c2(W, "mask_2d.0", net, 1)))
     return net, mask, dflow
 
 
@@ -304,6 +308,22 @@ def convex_upsample(flow: Tensor, mask: Tensor, rate: int = 4) -> Tensor:
     nb = torch.stack([fp[:, :, dy:dy + H, dx:dx + W] for dy in range(3) for dx in range(3)], 2)  # (N,2,9,H,W)
     up = (m * nb.view(N, 2, 9, 1, 1, H, W)).sum(2)                     # (N,2,r,r,H,W)
     return up.permute(0, 1, 4, 2, 5, 3).reshape(N, 2, rate * H, rate * W)
+
+
+def convex_upsample_3d(flow: Tensor, mask: Tensor, rate: int, T: int) -> Tensor:
+    """PPMStereo.convex_upsample_3d, ppmstereo.py:199-228, with unfoldNd.UnfoldNd([3,3,3], padding=1) (absent third-party
+    module, un-pinned) restated from its published semantics (N-d generalisation of nn.Unfold: channel c*27 + k,
+    k = (kt,kh,kw) row-major, zero padding) -- closed form
+    out[(b t),c,4y+i,4x+j] = sum_{k<27} softmax_k(mask[(b t),16k+4i+j,y,x]) * 4 flow[(b t+kt-1),c,y+ky-1,x+kx-1]."""
+    BT, _, H, W = flow.shape
+    b = BT // T
+    f5 = (rate * flow).reshape(b, T, 2, H, W).permute(0, 2, 1, 3, 4)               # (b,2,T,H,W)
+    m = torch.softmax(mask.reshape(b, T, 27, rate, rate, H, W), dim=2)              # (b,T,27,r,r,H,W)
+    fp = F.pad(f5, (1, 1, 1, 1, 1, 1))
+    nb = torch.stack([fp[:, :, a:a + T, y:y + H, x:x + W] for a in range(3) for y in range(3) for x in range(3)], 2)   # (b,2,27,T,H,W)
+    up = (m.permute(0, 2, 3, 4, 1, 5, 6)[:, None] * nb[:, :, :, None, None]).sum(2)                                     # (b,2,r,r,T,H,W)
+    up = up.permute(0, 1, 4, 5, 2, 6, 3).reshape(b, 2, T, rate * H, rate * W)
+    return up.permute(0, 2, 1, 3, 4).reshape(BT, 2, rate * H, rate * W)
 
 
 def interp(x: Tensor, size) -> Tensor:
@@ -353,7 +373,10 @@ def forward_update_block(Wb, Watt, pyr, flow, net, inp, mhs, iters: int, interp_
                 mfg[bi * t + clip] = mf[bi * t + clip] + beta * hid
         net, up_mask, dflow = update_block_forward(Wb, net, inp, mf, mfg, t, with_attention)
         flow = flow + dflow
-        flow_out = convex_upsample(flow, up_mask, 4)
+        if up_mask.shape[1] == 16 * 27:                                     # use_convex_3d=True (ppmstereo.py:573-574)
+            flow_out = convex_upsample_3d(flow, up_mask, 4, t)
+        else:
+            flow_out = convex_upsample(flow, up_mask, 4)
         unc_up = F.interpolate(unc, scale_factor=4 * interp_scale, mode="bilinear")
         flow_up = flow_out
         if interp_scale > 1:
@@ -452,3 +475,66 @@ def pre_loop_glue(fmap1: Tensor, fmap2: Tensor, c4: Tensor, c8: Tensor, c16: Ten
     feats["inp_8"] = F.relu((i8 + c8[:, hdim:]) / 2.0)
     feats.update(f1_16=f1_16, f2_16=f2_16, f1_8=f1_8, f2_8=f2_8, f1_4=fmap1, f2_4=fmap2)
     return feats
+
+
+class InputPadder:
+    """models/core/utils/utils.py:19-44 (mode "sintel"): replicate-pad H, W up to multiples of divis_by, split evenly."""
+
+    def __init__(self, dims, divis_by: int = 8):
+        self.ht, self.wd = dims[-2:]
+        pad_ht = (((self.ht // divis_by) + 1) * divis_by - self.ht) % divis_by
+        pad_wd = (((self.wd // divis_by) + 1) * divis_by - self.wd) % divis_by
+        self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
+
+    def pad(self, *inputs):
+        return [F.pad(x, self._pad, mode="replicate") for x in inputs]
+
+    def unpad(self, x):
+        ht, wd = x.shape[-2:]
+        return x[..., self._pad[2]:ht - self._pad[3], self._pad[0]:wd - self._pad[1]]
+
+
+def forward(W, fnet, cnet, image1: Tensor, image2: Tensor, iters: int, sst_fn=None):
+    """PPMStereo.forward(test_mode=True), ppmstereo.py:601-804, batch 1: image (1,T,3,H,W) in [0,255].  fnet / cnet stand
+    for the encoders (extractor.py / convnext.py, outside the path): fnet([im1, im2]) -> (fmap1, fmap2) (T,256,H/4,W/4),
+    cnet(im1) -> context at 1/4, 1/8, 1/16.  Returns (flow_up (1,T,1,H,W), uncertainty (1,T,1,H,W))."""
+    T = image1.shape[1]
+    im1 = (2 * (image1 / 255.0) - 1.0)[0].contiguous()
+    im2 = (2 * (image2 / 255.0) - 1.0)[0].contiguous()
+    fmap1, fmap2 = fnet([im1, im2])
+    c4, c8, c16 = cnet(im1)
+    feats = pre_loop_glue(fmap1, fmap2, c4, c8, c16, sst_fn)
+    disp, unc = cascade(W, feats, iters, T)
+    return disp[None], unc[None]
+
+
+def forward_batch_test(W, fnet, cnet, video: Tensor, kernel_size: int = 20, iters: int = 20, sst_fn=None) -> Dict[str, Tensor]:
+    """PPMStereo.forward_batch_test, ppmstereo.py:238-320: video (N,2,3,H,W); InputPadder(divis_by=32) per window, windows
+    of kernel_size frames every kernel_size//2, centre frames kept (:296-307), outputs .abs()[:, :1] (:309-310)."""
+    stride = kernel_size // 2
+    num_ims = len(video)
+
+    def run(lo, hi):
+        left, right = video[lo:hi, 0], video[lo:hi, 1]
+        padder = InputPadder(left.shape, divis_by=32)
+        left, right = padder.pad(left, right)
+        d, u = forward(W, fnet, cnet, left[None], right[None], iters, sst_fn)
+        return padder.unpad(d[0])[:, None], padder.unpad(u[0])[:, None]
+
+    if kernel_size > num_ims:
+        d, u = run(0, num_ims)
+        return {"disparity": d.squeeze(1).abs()[:, :1], "uncertainties": u.squeeze(1).abs()[:, :1]}
+    disp_preds, uncertainties = [], []
+    for i in range(0, num_ims, stride):
+        d, u = run(i, min(i + kernel_size, num_ims))       # (the reference also runs the trailing windows it then discards)
+        if len(disp_preds) > 0 and len(d) >= stride:
+            if len(d) < kernel_size:
+                disp_preds.append(d[stride // 2:])
+                uncertainties.append(u[stride // 2:])
+            else:
+                disp_preds.append(d[stride // 2: -stride // 2])
+                uncertainties.append(u[stride // 2: -stride // 2])
+        elif len(disp_preds) == 0:
+            disp_preds.append(d[: -stride // 2])
+            uncertainties.append(u[: -stride // 2])
+    return {"disparity": torch.cat(disp_preds).squeeze(1).abs()[:, :1], "uncertainties": torch.cat(uncertainties).squeeze(1).abs()[:, :1]}

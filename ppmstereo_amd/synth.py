@@ -17,18 +17,31 @@ from .weights import hash_normal
 
 
 def synth_scale_inputs(T: int, h: int, w: int, seed: int, with_mhs: bool = True, c: int = 256,
-                       shift: int = 3) -> Dict[str, torch.Tensor]:
+                       shift: int = 3, frame_contrast: float = 0.0) -> Dict[str, torch.Tensor]:
     """Inputs of one ``forward_update_block`` call at one scale: fmap1/fmap2 (T,c,h,w), net/inp (T,128,h,w),
-    flow (T,2,h,w), mhs (T,64,h,w) or None."""
+    flow (T,2,h,w), mhs (T,64,h,w) or None.
+
+    frame_contrast > 0 multiplies the context features of frame t by a per-(frame, 4x4 block) gain, so that the frames'
+    pooled q / k descriptors (ppmstereo.py:397-423) really differ: with i.i.d. noise all T x T frame similarities are
+    equal to ~1e-5 and the QAM top-k pick (ppmstereo.py:505-513) is decided by rounding noise, which no two
+    implementations share (matters once T >> top-k)."""
     f1 = hash_normal((T, c, h, w), seed * 16 + 1)
     noise = hash_normal((T, c, h, w), seed * 16 + 2)
     f2 = 0.8 * torch.roll(f1, shifts=-shift, dims=3) + 0.6 * noise
     net = torch.tanh(hash_normal((T, 128, h, w), seed * 16 + 3))
     inp = torch.relu(hash_normal((T, 128, h, w), seed * 16 + 4))
+    if frame_contrast > 0.0:
+        gain = (1.0 + frame_contrast * hash_normal((T, 1, (h + 3) // 4, (w + 3) // 4), seed * 16 + 7)).clamp_min(0.05)
+        inp = inp * gain.repeat_interleave(4, 2).repeat_interleave(4, 3)[:, :, :h, :w]
     flow = hash_normal((T, 2, h, w), seed * 16 + 5, std=1.5)
     flow[:, 0] -= float(shift)
     mhs = torch.relu(hash_normal((T, 64, h, w), seed * 16 + 6)) if with_mhs else None
     return dict(fmap1=f1, fmap2=f2, net=net, inp=inp, flow=flow, mhs=mhs)
+
+
+# T = 40 >> top-k parity cases (tools/gen_golden.py, tests): inputs whose QAM pick is well conditioned -- smallest gap between
+# the 5th and 6th frame score over all clips and iterations 2.3e-4 / 3.8e-4 (seeds found by search with the CPU restatement under tests)
+T40_CASES = {"fub04_T40": dict(seed=601, frame_contrast=2.0), "fub16_T40": dict(seed=710, frame_contrast=2.0)}
 
 
 def synth_cascade_feats(T: int, H: int, W: int, seed: int = 7) -> Dict[str, torch.Tensor]:

@@ -26,8 +26,9 @@ HIDDEN = 128
 COR_PLANES = 36  # 4 levels x 9 taps
 
 
-def update_block_param_shapes(with_attention: bool) -> "OrderedDict[str, Tuple[int, ...]]":
-    """Name -> shape of every parameter of one SequenceUpdateBlock3D (use_convex_3d=False)."""
+def update_block_param_shapes(with_attention: bool, use_convex_3d: bool = False) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Name -> shape of every parameter of one SequenceUpdateBlock3D, in state_dict() order.  use_convex_3d selects the
+    mask_3d head (ppmtereo_update.py:903-908) instead of mask_2d (:910-914)."""
     s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
 
     def conv(name, cout, cin, *k, bias=True):
@@ -63,8 +64,12 @@ def update_block_param_shapes(with_attention: bool) -> "OrderedDict[str, Tuple[i
     conv("flow_head.conv2", 2, 256, 3, 3, 3)
     conv("uncertainty.0", 128, 256, 3, 3)
     conv("uncertainty.2", 1, 128, 1, 1)
-    conv("mask_2d.0", 256, 128, 3, 3)
-    conv("mask_2d.2", 144, 256, 1, 1)
+    if use_convex_3d:
+        conv("mask_3d.0", 256, 128, 3, 3, 3)
+        conv("mask_3d.2", 16 * 27, 256, 1, 1, 1)
+    else:
+        conv("mask_2d.0", 256, 128, 3, 3)
+        conv("mask_2d.2", 144, 256, 1, 1)
     if with_attention:
         d = 384
         s["time_attn.temporal_attn.qkv.weight"] = (3 * d, d)   # dead parameter (never applied)
@@ -117,13 +122,13 @@ def procedural_state_dict(shapes: Dict[str, Tuple[int, ...]], prefix: str = "", 
     return out
 
 
-def hot_path_weights(seed: int = 0) -> Dict[str, "OrderedDict[str, torch.Tensor]"]:
+def hot_path_weights(seed: int = 0, use_convex_3d: bool = False) -> Dict[str, "OrderedDict[str, torch.Tensor]"]:
     """Weights of the three update blocks and three q/k projections (reference names:
     update_block16 / update_block08 / update_block04, att.0 / att.1 / att.2;
     /root/reference/models/core/ppmstereo.py:82-117)."""
     w = {}
     for tag, attn in (("update_block16", True), ("update_block08", False), ("update_block04", False)):
-        w[tag] = procedural_state_dict(update_block_param_shapes(attn), tag + ".", seed)
+        w[tag] = procedural_state_dict(update_block_param_shapes(attn, use_convex_3d), tag + ".", seed)
     for i in range(3):
         w[f"att.{i}"] = procedural_state_dict(att_param_shapes(), f"att.{i}.", seed)
     return w

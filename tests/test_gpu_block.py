@@ -7,7 +7,7 @@ import torch
 from golden_util import Golden
 from oracle import ppm_oracle as O
 from ppmstereo_amd import weights as Wm
-from ppmstereo_amd.synth import synth_cascade_feats, synth_scale_inputs
+from ppmstereo_amd.synth import T40_CASES, synth_cascade_feats, synth_scale_inputs
 from ppmstereo_amd.weights import hash_normal
 
 pytestmark = pytest.mark.gpu
@@ -66,7 +66,10 @@ def test_update_block_methods(model, tag):
 
 
 FUB = [("fub16", "update_block16", 0, 5, 8, 32, 2, 4, False), ("fub08", "update_block08", 1, 8, 8, 32, 3, 2, True),
-       ("fub04", "update_block04", 2, 5, 16, 64, 2, 1, True), ("fub04_T2", "update_block04", 2, 2, 8, 32, 2, 1, True)]
+       ("fub04", "update_block04", 2, 5, 16, 64, 2, 1, True), ("fub04_T2", "update_block04", 2, 2, 8, 32, 2, 1, True),
+       # BASELINE configs 4-5 have T = 40 >> top-k: QAM pick / usage counter over several iterations, temporal_pe(40) inside the
+       # kernels, T * ksel * n workspaces (inputs with a well-conditioned pick, ppmstereo_amd.synth.T40_CASES)
+       ("fub04_T40", "update_block04", 2, 40, 8, 32, 3, 1, True), ("fub16_T40", "update_block16", 0, 40, 8, 32, 2, 4, False)]
 
 
 @pytest.mark.parametrize("name,tag,ai,T,h,w,iters,isc,mh", FUB)
@@ -74,7 +77,7 @@ def test_forward_update_block(model, name, tag, ai, T, h, w, iters, isc, mh):
     """The loop itself (reference signature) vs oracle and vs the reference's own outputs (golden).
     Tolerances: 1e-3 px is the north-star EPE budget; the loop is compared well inside it."""
     from ppmstereo_amd.corr import CorrBlock1D
-    d = synth_scale_inputs(T, h, w, seed=50 + ai + 10 * T, with_mhs=mh)
+    d = synth_scale_inputs(T, h, w, with_mhs=mh, **T40_CASES.get(name, dict(seed=50 + ai + 10 * T)))
     cb = CorrBlock1D(g(d["fmap1"]), g(d["fmap2"]))
     preds, uncs = [], []
     fo, net, mhs = model.forward_update_block(None, getattr(model, tag), cb, g(d["flow"]), g(d["net"]), g(d["inp"]), g(d["mhs"]), model.att[ai],
@@ -120,6 +123,48 @@ def test_T1_gives_nan_like_reference(model):
         fo, _, _ = model.forward_update_block(None, model.update_block04, CorrBlock1D(g(d["fmap1"]), g(d["fmap2"])), g(d["flow"]), g(d["net"]),
                                               g(d["inp"]), g(d["mhs"]), model.att[2], [], [], 1, 1, 1)
     assert torch.isnan(fo).any() and bool(Golden("fub_T1_nan").raw("any_nan"))
+
+
+def test_config2_full_size_vs_oracle(model):
+    """BASELINE config 2 geometry at FULL size (T=5, 320x512) against the CPU oracle: the cascade with 1 / 1 / 2 iterations at
+    the 1/16, 1/8, 1/4 scales (the oracle needs ~15 s for it).  This is the comparison of mem_attn64_kernel at n = 10 240,
+    conv3_kernel at 5x80x128 and every launch planner at the sizes the headline number is measured on."""
+    T, H, Wd = 5, 320, 512
+    feats = synth_cascade_feats(T, H, Wd)
+    rp, ru = [], []
+    rd, rc = O.cascade(W, feats, 2, T, rp, ru)
+    p1, u1 = [], []
+    d1, c1 = model.cascade({k: v.to(DEV) for k, v in feats.items()}, 2, T, p1, u1)
+    assert len(p1) == len(rp) == 4
+    for i, (a, b) in enumerate(zip(p1, rp)):            # every prediction of the cascade, coarse to fine
+        err = (a.cpu() - b).abs()
+        print(f"prediction {i}: mean |d disparity| {err.mean().item():.3e} px, max {err.max().item():.3e} px")
+        assert err.mean().item() < 2e-4 and err.max().item() < 1e-3, (i, err.mean().item(), err.max().item())
+    assert maxdiff(c1, rc) < 2e-4
+
+
+def test_config3_geometry_vs_oracle(model):
+    """BASELINE config 3 geometry (720x1280 -> 736x1280): (a) one iteration of the 1/16 scale (46x80, n = 3 680: not a multiple
+    of 64, so the tail-masking attention kernel and the conv planners of that map run) against the oracle; (b) the whole
+    T=5, iters=20 cascade at full size: finite, bit-reproducible, bounded."""
+    from ppmstereo_amd.corr import CorrBlock1D
+    T, h, w = 5, 46, 80
+    d = synth_scale_inputs(T, h, w, seed=333, with_mhs=False)
+    preds, uncs, rp, ru = [], [], [], []
+    fo, net, mhs = model.forward_update_block(None, model.update_block16, CorrBlock1D(g(d["fmap1"]), g(d["fmap2"])), g(d["flow"]), g(d["net"]),
+                                              g(d["inp"]), None, model.att[0], preds, uncs, 1, 4, T)
+    rfo, rnet, rmhs = O.forward_update_block(W["update_block16"], W["att.0"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"], d["inp"],
+                                             None, 1, 4, T, True, rp, ru)
+    assert (fo[:, 0].cpu() - rfo[:, 0]).abs().mean().item() < 2e-4
+    assert maxdiff(fo, rfo) < 1e-3 and maxdiff(net, rnet) < 2e-3 and maxdiff(mhs, rmhs) < 5e-4
+    T, H, Wd = 5, 736, 1280
+    feats = {k: v.to(DEV) for k, v in synth_cascade_feats(T, H, Wd).items()}
+    d1, c1 = model.cascade(feats, 20, T)
+    torch.cuda.synchronize()
+    d2, c2 = model.cascade(feats, 20, T)
+    assert d1.shape == (T, 1, H, Wd) and torch.isfinite(d1).all() and torch.isfinite(c1).all()
+    assert torch.equal(d1, d2) and torch.equal(c1, c2)
+    assert (c1 > 0).all() and (c1 < 1).all() and d1.abs().max() < 4 * Wd
 
 
 def test_full_config_properties(model):

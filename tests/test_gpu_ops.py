@@ -376,6 +376,21 @@ def test_qam_select_sequence(lib):
 
 
 # ------------------------------------------------------------------------------------------------ memory attention
+def _attn_check(got, ref, operands, scale):
+    """Per-element bound in bf16 ulps OF THE ELEMENT (not of the tensor's range): with bf16 operands as the oracle uses them,
+    err <= 2^-9 * (P |V|) for the bf16-rounded probabilities + 2^-8 |ref| for the bf16 result (+ 1e-6 fp32 slop); and the
+    typical error must sit far inside the worst case (rounding errors do not all line up)."""
+    for i, (Q, K, V, _, _) in enumerate(operands):
+        Qb, Kb, Vb = (t.to(torch.bfloat16).float() for t in (Q, K, V))
+        P = torch.softmax((Qb @ Kb.t()) * scale, dim=-1)
+        bound = 2.0 ** -9 * (P @ Vb.abs()) + 2.0 ** -8 * ref[i].abs() + 1e-6
+        err = (got[i] - ref[i]).abs()
+        assert torch.isfinite(got[i]).all()
+        worst = (err / bound).max().item()
+        assert worst <= 1.0, f"clip {i}: element error {worst:.2f}x its bf16 bound"
+        assert err.mean().item() <= 0.25 * bound.mean().item(), (err.mean().item(), bound.mean().item())
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5)])
 def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split):
@@ -422,9 +437,9 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split):
     Q0, K0, _, _, _ = O.play_inputs(q, key, pe, value, score, mask, 0)
     assert torch.equal(qb[0].float().cpu(), Q0.to(torch.bfloat16).float())
     assert torch.equal(kb[0].reshape(-1, 128).float().cpu(), K0.to(torch.bfloat16).float())
-    # output: bf16 P in the PV product -> a few bf16 ulps of the value range
-    d = maxdiff(raw.float(), ref)
-    assert d < 0.02 * ref.abs().max().item() + 1e-3, d
+    # output, per element: the kernel rounds P to bf16 before the PV product (like flash-attention) and the result to bf16
+    # |err_d| <= 2^-9 * sum_k p_k |v_kd| (P rounding, worst case) + one bf16 ulp of the element (final rounding)
+    _attn_check(raw.float().cpu(), ref, [(O.play_inputs(q, key, pe, value, score, mask, i)) for i in range(T)], scale)
     mfg = X.to_f32(128, 128).cpu()
     # mfg is stored split (hi + lo): ~2^-16 relative
     assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 1e-4
@@ -456,7 +471,7 @@ def test_mem_attn_sharp_softmax(lib, boost):
         K = kb[i].reshape(-1, 128).float().cpu()
         V = torch.cat([vt[0].float().cpu().t(), vt[1].float().cpu().t()], 0)
         ref = O.flash_attn_math(qb[i].float().cpu(), K, V, scale)
-        assert maxdiff(raw[i].float(), ref) < 0.02 * ref.abs().max().item() + 1e-3
+        _attn_check(raw[i].float().cpu()[None], ref[None], [(qb[i].float().cpu(), K, V, None, None)], scale)
 
 
 # ------------------------------------------------------------------------------------------------ small fused ops

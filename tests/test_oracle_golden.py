@@ -7,7 +7,7 @@ import torch
 from golden_util import Golden
 from oracle import ppm_oracle as O
 from ppmstereo_amd import weights as Wm
-from ppmstereo_amd.synth import synth_scale_inputs
+from ppmstereo_amd.synth import T40_CASES, synth_scale_inputs
 from ppmstereo_amd.weights import hash_normal
 
 W = Wm.hot_path_weights()
@@ -77,13 +77,15 @@ def test_update_block_pieces():
 
 
 FUB = [("fub16", "update_block16", 0, 5, 8, 32, 2, 4, False), ("fub08", "update_block08", 1, 8, 8, 32, 3, 2, True),
-       ("fub04", "update_block04", 2, 5, 16, 64, 2, 1, True), ("fub04_T2", "update_block04", 2, 2, 8, 32, 2, 1, True)]
+       ("fub04", "update_block04", 2, 5, 16, 64, 2, 1, True), ("fub04_T2", "update_block04", 2, 2, 8, 32, 2, 1, True),
+       # T = 40 >> top-k (BASELINE configs 4-5): the QAM pick and usage counter over several iterations, temporal PE of 40 frames
+       ("fub04_T40", "update_block04", 2, 40, 8, 32, 3, 1, True), ("fub16_T40", "update_block16", 0, 40, 8, 32, 2, 4, False)]
 
 
 @pytest.mark.parametrize("name,tag,ai,T,h,w,iters,isc,mh", FUB)
 def test_forward_update_block(name, tag, ai, T, h, w, iters, isc, mh):
     g = Golden(name)
-    d = synth_scale_inputs(T, h, w, seed=50 + ai + 10 * T, with_mhs=mh)
+    d = synth_scale_inputs(T, h, w, with_mhs=mh, **T40_CASES.get(name, dict(seed=50 + ai + 10 * T)))
     pyr = O.corr_pyramid(d["fmap1"], d["fmap2"])
     preds, uncs, trace = [], [], []
     fo, net, mhs = O.forward_update_block(W[tag], W[f"att.{ai}"], pyr, d["flow"], d["net"], d["inp"], d["mhs"], iters, isc, T,
@@ -113,6 +115,46 @@ def test_cascade():
     disp, unc = O.cascade(W, feats, 4, T, preds, uncs)
     assert len(preds) == 2 + 2 + 4 and int(g.raw("n_attn_calls")) == T * 8
     g.check("disparity", disp[None], 5e-4), g.check("uncertainty", unc[None], 5e-5)
+
+
+def test_forward_batch_test_stitching():
+    """PPMStereo.forward_batch_test (ppmstereo.py:238-320) on 25 frames of 60x250 with kernel_size 20: InputPadder to
+    64x256, windows [0,20) [10,25) ([20,25) computed and dropped by the reference), kept frames 0-14 / 15-24."""
+    from stub_encoders import StubCNet, StubFNet, frame_video
+    g = Golden("fbt_N25_k20")
+    out = O.forward_batch_test(W, StubFNet(), StubCNet(), frame_video(25, 60, 250), kernel_size=20, iters=4)
+    assert tuple(out["disparity"].shape) == (25, 1, 60, 250)
+    g.check("disparity", out["disparity"], 5e-4), g.check("uncertainties", out["uncertainties"], 5e-5)
+    g1 = Golden("fbt_N7_k20")                                    # kernel_size > num_ims: one window with every frame
+    out = O.forward_batch_test(W, StubFNet(), StubCNet(), frame_video(7, 60, 250), kernel_size=20, iters=4)
+    g1.check("disparity", out["disparity"], 5e-4), g1.check("uncertainties", out["uncertainties"], 5e-5)
+
+
+def test_convex_3d_variant():
+    """use_convex_3d=True: mask_3d head (ppmtereo_update.py:903-908,993-996) and convex_upsample_3d (ppmstereo.py:199-228)."""
+    W3 = Wm.hot_path_weights(use_convex_3d=True)
+    fl, mk = hash_normal((4, 2, 6, 10), 33), hash_normal((4, 432, 6, 10), 34)
+    g = Golden("convex_upsample_3d")
+    g.check("out", O.convex_upsample_3d(fl, mk, 4, 4), 2e-6), g.check("out_T1", O.convex_upsample_3d(fl[:1], mk[:1], 4, 1), 2e-6)
+    T, h, w = 5, 8, 32
+    d = synth_scale_inputs(T, h, w, seed=41, with_mhs=False)
+    corr = hash_normal((T, 36, h, w), 42)
+    Wb = W3["update_block04"]
+    mf, _, _ = O.get_motion_and_value(Wb, d["flow"], corr, None, d["inp"])
+    mfg = mf + 0.3 * hash_normal((T, 128, h, w), 43)
+    net, mask, dflow = O.update_block_forward(Wb, d["net"], d["inp"], mf, mfg, T, False)
+    g = Golden("update_block04_c3d_pieces")
+    assert mask.shape[1] == 432
+    g.check("net", net, 2e-5), g.check("mask", mask, 2e-5), g.check("dflow", dflow, 2e-5)
+    for name, tag, ai, T, h, w, iters, isc, mh in (("fub04_c3d", "update_block04", 2, 5, 8, 32, 2, 1, True),
+                                                  ("fub16_c3d", "update_block16", 0, 3, 8, 32, 2, 4, False)):
+        d = synth_scale_inputs(T, h, w, seed=50 + ai + 10 * T, with_mhs=mh)
+        preds, uncs = [], []
+        fo, net, mhs = O.forward_update_block(W3[tag], W3[f"att.{ai}"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"], d["inp"],
+                                              d["mhs"], iters, isc, T, tag == "update_block16", preds, uncs)
+        g = Golden(name)
+        g.check("flow_out", fo, 3e-4), g.check("net", net, 6e-4), g.check("mhs", mhs, 2e-4)
+        g.check("preds", torch.stack(preds), 3e-4 * isc), g.check("uncs", torch.stack(uncs), 5e-5)
 
 
 def test_T1_is_nan_like_the_reference():
