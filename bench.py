@@ -1,18 +1,24 @@
 """Benchmark of the PPMStereo hot path on MI355X (contract: see the round prompt / DESIGN.md section 5).
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one clip of BASELINE config 2: T=5 frames, 320x512, iters=10
 (cascade 1/16 -> 1/8 -> 1/4: 3 correlation pyramid builds + 5/5/10 iterations of lookup, motion encoder,
 uncertainty, QAM pick, pick-and-play memory attention, ConvGRU3D, heads, convex upsample).  Inputs (the encoder / SST
-outputs the loop consumes) are synthetic and resident in HBM before the timed region.  For N > 1 every rank runs its
-own replica of the clip (T=5 does not divide across ranks without changing the result -- DESIGN.md section 6), so
-scaling is "weak" and value = N * pixels / max-over-ranks time.  Rank 0 prints ONE JSON line.
+outputs the loop consumes) are synthetic and resident in HBM before the timed region.
+
+N > 1, T = 5 (config 2): every rank runs its own replica of the clip (T=5 does not divide across ranks without changing
+the result -- DESIGN.md section 6), scaling "weak", value = N * pixels / max-over-ranks time.
+N > 1, --T divisible by N and >= 2 frames per rank (configs 4-5, e.g. --T 40): the window's frames are SHARDED over the
+ranks (ppmstereo_amd.dist.FrameShard: all-gather of the memory keys once per scale and of the values / confidences every
+iteration, +-2 / +-1 frame halos for the temporal convs), scaling "strong", value = pixels / max-over-ranks time.
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -22,6 +28,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+CONV_BOUND_TFLOPS = BF16_DENSE_PEAK_TFLOPS / 3.0     # bf16x3 split (hi*hi + hi*lo + lo*hi): 3 MFMAs per algorithmic product
+BASELINE_CONFIGS = {(5, 320, 512, 10): "BASELINE config 2", (5, 736, 1280, 20): "BASELINE config 3 (720x1280 padded to 736x1280)",
+                    (40, 320, 512, 20): "BASELINE config 4 (one T=40 window)", (40, 736, 1280, 20): "BASELINE config 5 (one T=40 window)"}
 
 
 def cpu_baseline(T, H, W, iters, threads):
@@ -56,14 +65,15 @@ def cpu_baseline(T, H, W, iters, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--H", type=int, default=320)
     ap.add_argument("--W", type=int, default=512)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event bracket around the attention kernel")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets around the attention / conv3 kernels")
+    ap.add_argument("--replicas", action="store_true", help="N > 1: force clip replicas even when T divides over the ranks")
     args = ap.parse_args()
 
     from ppmstereo_amd import dist as D
@@ -77,43 +87,59 @@ def main():
     from ppmstereo_amd.ppmstereo import PPMStereoHotPath
     from ppmstereo_amd.synth import synth_cascade_feats
     T, H, W, iters = args.T, args.H, args.W, args.iters
+    sharded = world > 1 and not args.replicas and T % world == 0 and T // world >= 2
     model = PPMStereoHotPath().load_hot_path_weights(Wm.hot_path_weights()).to(dev).eval()
-    feats = {k: v.to(dev) for k, v in synth_cascade_feats(T, H, W).items()}
+    feats = synth_cascade_feats(T, H, W)
+    shard = None
+    if sharded:                                    # this rank's contiguous block of frames
+        shard = D.FrameShard(rank, world, T)
+        feats = {k: v[shard.lo:shard.hi] for k, v in feats.items()}
+    feats = {k: v.to(dev) for k, v in feats.items()}
 
     def step():
-        return model.cascade(feats, iters, T)
+        return model.cascade(feats, iters, T, shard=shard, test_mode=True)
 
     for _ in range(max(1, args.warmup)):
         disp, _ = step()
     torch.cuda.synchronize()
     assert torch.isfinite(disp).all()
 
-    # HIP events around EVERY launch of the dominant kernel (memory attention, all three scales), on the stream it runs on
-    engs = [(model.update_block16.engine(T, H // 16, W // 16, dev), iters // 2), (model.update_block08.engine(T, H // 8, W // 8, dev), iters // 2),
-            (model.update_block04.engine(T, H // 4, W // 4, dev), iters)]
+    # HIP events around EVERY launch of the two dominant kernel families (memory attention; conv3_kernel = the large-map
+    # implicit-GEMM convolution), on the stream each is launched on
+    Tl = T // world if sharded else T
+    engs = [(model.update_block16.engine(Tl, H // 16, W // 16, dev, shard), iters // 2), (model.update_block08.engine(Tl, H // 8, W // 8, dev, shard), iters // 2),
+            (model.update_block04.engine(Tl, H // 4, W // 4, dev, shard), iters)]
+    conv3 = {}
     if not args.no_kernel_timing:
-        for e, n_it in engs:
+        for (e, n_it), sc in zip(engs, (16, 8, 4)):
             e.enable_attn_timing(args.steps * n_it)
+            for name, op in e.conv_ops(3).items():
+                op.events = []
+                conv3[(sc, name)] = op
 
+    step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for a, b in step_ev:
+        a.record()
         step()
+        b.record()
     torch.cuda.synchronize()
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    step_ms = [a.elapsed_time(b) for a, b in step_ev]
 
     px = T * H * W
-    value = world * args.steps * px / elapsed
+    value = (1 if sharded else world) * args.steps * px / elapsed
     ksel = min(5, T)
-    roof = None
+    roofs = []
     if not args.no_kernel_timing:
-        # algorithmic FLOPs of one launch = 4 * n * (ksel * n) * 128 * T (all T clips per launch)
+        # ---- memory attention: algorithmic FLOPs of one launch = 4 * n * (ksel * n) * 128 * (clips of this rank)
         tot_flop, tot_ms, n_launch, per_scale = 0.0, 0.0, 0, {}
         for (e, n_it), sc in zip(engs, (16, 8, 4)):
             ms = e.attn_times_ms()
-            fl = 4.0 * e.n * (ksel * e.n) * 128 * T
+            fl = 4.0 * e.n * (ksel * e.n) * 128 * Tl
             tot_flop += fl * len(ms)
             tot_ms += sum(ms)
             n_launch += len(ms)
@@ -121,27 +147,61 @@ def main():
                                         tflops=round(fl / (sum(ms) / len(ms) * 1e-3) / 1e12, 1))
         ach = tot_flop / (tot_ms * 1e-3) / 1e12
         traffic = None            # HBM bytes per 1/4-scale launch from the committed PMC passes (same kernel, same shape), if present
-        tfile = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+        tfile = os.path.join(ROOT, "profiles", "attn_traffic.json")
         if os.path.exists(tfile) and (T, H, W) == (5, 320, 512):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        roof = dict(bound="mfma", kernel="memory attention (mem_attn64_kernel + its fix-up pass + attn_combine_kernel = one ppms_mem_attn call), every call of the timed region "
-                                         "(3 scales: 1/16, 1/8, 1/4); algorithmic FLOPs = sum over launches of 4*n*(k*n)*128*T",
-                    achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                    traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/r01_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-                    launches=n_launch, avg_ms=round(tot_ms / n_launch, 4), flop_per_launch=tot_flop / n_launch, per_scale=per_scale)
+        roofs.append(dict(bound="mfma", kernel="memory attention = one ppms_mem_attn call (attention kernel + combine), every call of the timed region "
+                                               "(3 scales: 1/16, 1/8, 1/4); algorithmic FLOPs = sum over launches of 4*n*(k*n)*128*T",
+                          achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
+                          traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                          launches=n_launch, avg_ms=round(tot_ms / n_launch, 4), total_ms_per_step=round(tot_ms / args.steps, 3),
+                          flop_per_launch=tot_flop / n_launch, per_scale=per_scale))
+        # ---- conv3_kernel: algorithmic FLOPs of a launch = 2 * pixels * couts * cin * taps from its descriptor
+        if conv3:
+            torch.cuda.synchronize()
+            c_flop = c_ms = 0.0
+            c_n, per_op = 0, {}
+            for (sc, name), op in sorted(conv3.items()):
+                ms = [a.elapsed_time(b) for a, b in op.events]
+                if not ms:
+                    continue
+                c_flop += op.flops() * len(ms)
+                c_ms += sum(ms)
+                c_n += len(ms)
+                per_op[f"1/{sc}:{name}"] = dict(launches=len(ms), avg_ms=round(sum(ms) / len(ms), 4), gflop=round(op.flops() / 1e9, 2),
+                                                tflops=round(op.flops() / (sum(ms) / len(ms) * 1e-3) / 1e12, 1))
+            if c_n:
+                cach = c_flop / (c_ms * 1e-3) / 1e12
+                ctraffic = None
+                tfile = os.path.join(ROOT, "profiles", "conv3_traffic.json")
+                if os.path.exists(tfile) and (T, H, W) == (5, 320, 512):
+                    ctraffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                roofs.append(dict(bound="mfma", kernel="conv3_kernel (large-map implicit-GEMM convolution, bf16x3 split MFMA), every launch of the timed region; "
+                                                       "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / 3 (three MFMAs per product)",
+                                  achieved=round(cach, 2), peak=round(CONV_BOUND_TFLOPS, 1), unit="TFLOP/s", frac=round(cach / CONV_BOUND_TFLOPS, 4),
+                                  frac_of_bf16_dense=round(cach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=ctraffic,
+                                  traffic_note="HBM bytes of ONE zr1_0 launch at the 1/4 scale, profiles/conv3_traffic.json",
+                                  launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / args.steps, 3),
+                                  flop_per_launch=c_flop / c_n, per_op=per_op))
+        roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
             cores = min(16, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else min(16, os.cpu_count() or 1)
             cpu = cpu_baseline(T, H, W, iters, cores)
+        label = BASELINE_CONFIGS.get((T, H, W, iters), "custom configuration")
+        par = f"frames sharded {T // world}/GPU x{world} (RCCL all-gather of memory K/V + temporal halos)" if sharded else f"replicas x{world}"
         out = dict(metric="disparity-px/s", value=round(value, 1), unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="weak", vs_baseline=None, dtype="bf16", precision="attention: bf16 MFMA, fp32 softmax/accumulate; convs: bf16x3 split MFMA (fp32-accurate); correlation: fp32 MFMA",
-                   data="synthetic", frames_per_s=round(world * args.steps * T / elapsed, 2),
-                   config=dict(workload=f"BASELINE config 2: T={T} clip at {H}x{W}, iters={iters}, hot path only (3-scale cascade from encoder outputs: "
-                                        "corr pyramid build + lookup, QAM pick, pick-and-play memory attention, ConvGRU3D update, heads, convex upsample); "
-                                        "one clip replica per GPU", T=T, H=H, W=W, iters=iters, parallelism=f"replicas x{world}"),
-                   roofline=roof, cpu_baseline=cpu, library=os.path.relpath(L.lib_path(), ROOT))
+                   ms_per_step=round(1e3 * elapsed / args.steps, 3), ms_per_step_median=round(statistics.median(step_ms), 3),
+                   ms_per_step_min=round(min(step_ms), 3), higher_is_better=True, scaling="strong" if sharded else "weak", vs_baseline=None, dtype="bf16",
+                   precision="attention: bf16 MFMA, fp32 softmax/accumulate; convs: bf16x3 split MFMA (fp32-accurate); correlation: fp32 MFMA",
+                   data="synthetic", frames_per_s=round((1 if sharded else world) * args.steps * T / elapsed, 2),
+                   config=dict(workload=f"{label}: T={T} clip at {H}x{W}, iters={iters}, hot path only (3-scale cascade from encoder outputs: "
+                                        "corr pyramid build + lookup, QAM pick, pick-and-play memory attention, ConvGRU3D update, heads, convex upsample, "
+                                        "test_mode: only the last prediction is resized)", T=T, H=H, W=W, iters=iters, parallelism=par),
+                   roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None, cpu_baseline=cpu,
+                   library=os.path.relpath(L.lib_path(), ROOT))
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -157,6 +157,11 @@ int ppms_convex_upsample(const float* flow_nhwc, const float* mask, int mask_ld,
  * out = mul * interp(src). */
 int ppms_bilinear(const float* src, float* dst, int N, int C, int H, int W, int OH, int OW, int align_corners, float mul, void* stream);
 
+/* Scale-to-scale hand-over of the cascade without leaving the SP format (ppmstereo.py:726-732, 763-767): per frame,
+ * dst = a * dst + b * interp(src), interp = F.interpolate(mode="bilinear", align_corners=True) from HxW to OHxOW.
+ * src, dst: SP views with the same channel count (multiple of 8). */
+int ppms_sp_resize_blend(ppms_sp src, ppms_sp dst, int N, int H, int W, int OH, int OW, float a, float b, void* stream);
+
 /* ---------------------------------------------------------------- pick-and-play memory attention */
 /* PPMStereo.compute_qk_similarity, ppmstereo.py:397-423.  q,k: fp32 [T][H*W][ld] channel-last (128 channels);
  * pooled: workspace fp32 [2][T][(H/4)*(W/4)]; sim: fp32 [T][T], sim[i][j] = cos(kbar_i, qbar_j). */

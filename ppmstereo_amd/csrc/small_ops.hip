@@ -461,6 +461,65 @@ extern "C" int ppms_bilinear(const float* src, float* dst, int N, int C, int H, 
     return ppms_check_launch("bilinear");
 }
 
+// Scale-to-scale hand-over of the cascade on SP (channel-last split-bf16) tensors, no NCHW round trip:
+// dst = a * dst + b * interp(src) with F.interpolate(mode="bilinear", align_corners=True) semantics per frame
+// (ppmstereo.py:726-732,763-767: hidden state x2, net = (net_s + interp(net_2s)) / 2).  One thread = one output pixel x 8 channels.
+__global__ __launch_bounds__(256) void sp_resize_blend_kernel(ppms_sp src, ppms_sp dst, int H, int W, int OH, int OW, int C8, float sh, float sw,
+                                                              float a, float b, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int c = (int)(idx % C8) * 8;
+    const int64_t opix = idx / C8;
+    const int ox = (int)(opix % OW);
+    const int oy = (int)((opix / OW) % OH);
+    const int64_t frame = opix / ((int64_t)OW * OH);
+    const float fy = sh * oy, fx = sw * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + ((y0 < H - 1) ? 1 : 0), x1 = x0 + ((x0 < W - 1) ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0;
+    const float hy = 1.0f - ly, hx = 1.0f - lx;
+    const int64_t base = frame * H * W;
+    auto ld8 = [&](int y, int x, float* v) {
+        const int64_t o = (base + (int64_t)y * W + x) * src.ld + c;
+        const bf16x8 h8 = *(const bf16x8*)((const bf16_t*)src.hi + o), l8 = *(const bf16x8*)((const bf16_t*)src.lo + o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = join_bf16(h8[j], l8[j]);
+    };
+    float v00[8], v01[8], v10[8], v11[8];
+    ld8(y0, x0, v00);
+    ld8(y0, x1, v01);
+    ld8(y1, x0, v10);
+    ld8(y1, x1, v11);
+    const int64_t od = opix * dst.ld + c;
+    float d[8];
+    if (a != 0.0f) {
+        const bf16x8 h8 = *(const bf16x8*)((const bf16_t*)dst.hi + od), l8 = *(const bf16x8*)((const bf16_t*)dst.lo + od);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = join_bf16(h8[j], l8[j]);
+    }
+    bf16x8 oh, ol;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
+        const float y = (a != 0.0f) ? a * d[j] + b * v : b * v;
+        bf16_t hh, ll;
+        split_bf16(y, hh, ll);
+        oh[j] = hh;
+        ol[j] = ll;
+    }
+    *(bf16x8*)((bf16_t*)dst.hi + od) = oh;
+    *(bf16x8*)((bf16_t*)dst.lo + od) = ol;
+}
+extern "C" int ppms_sp_resize_blend(ppms_sp src, ppms_sp dst, int N, int H, int W, int OH, int OW, float a, float b, void* stream) {
+    PPMS_REQUIRE(src.hi && src.lo && dst.hi && dst.lo && N > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "sp_resize_blend: bad arguments");
+    PPMS_REQUIRE(src.c == dst.c && src.c % 8 == 0 && src.ld % 8 == 0 && dst.ld % 8 == 0, "sp_resize_blend: channel views must match, multiples of 8");
+    PPMS_REQUIRE((((uintptr_t)src.hi | (uintptr_t)src.lo | (uintptr_t)dst.hi | (uintptr_t)dst.lo) & 15) == 0, "sp_resize_blend: views must be 16-B aligned");
+    const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.0f, sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.0f;
+    const int64_t n = (int64_t)N * OH * OW * (src.c / 8);
+    hipLaunchKernelGGL(sp_resize_blend_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, OH, OW, src.c / 8, sh, sw, a, b, n);
+    return ppms_check_launch("sp_resize_blend");
+}
+
 // ------------------------------------------------------------------------------------------------ frame similarity
 // pooled[which][t][cell] = mean_c max_{adaptive window} x_t[c]  (AdaptiveMaxPool2d(h//4,w//4) + mean over channels)
 __global__ __launch_bounds__(128) void qk_pool_kernel(const float* __restrict__ q, const float* __restrict__ k, int ld,

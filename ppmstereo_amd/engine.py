@@ -70,6 +70,7 @@ class ConvOp:
         raw = bytes(desc)
         self.dev = torch.frombuffer(bytearray(raw), dtype=torch.uint8).clone().to(device)
         self.keep = keep            # tensors whose storage the descriptor points at
+        self.events = None          # list collecting (start, stop) HIP events per launch when kernel timing is on
         # small maps: K-sliced launch + reduce kernel (nslice None: ask the library; own workspace per op because ops
         # of the two streams run concurrently)
         self.nslice, self.ws = 1, None
@@ -79,7 +80,26 @@ class ConvOp:
             if self.nslice > 1:
                 self.ws = torch.empty(int(L.load().ppms_conv_gemm2_slice_workspace_bytes(C.byref(desc), self.nslice)), dtype=torch.uint8, device=device)
 
+    def flops(self) -> float:
+        """Algorithmic FLOPs of one launch: 2 * pixels * stored couts * input channels of the launch * taps (zero-padding
+        taps included, as a FLOP counter on the reference conv would)."""
+        d = self.desc
+        cout = d.epi[0].n_valid + (d.epi[1].n_valid if d.m_split < d.M else 0)
+        cin = sum(d.seg[i].c for i in range(d.nseg))
+        return 2.0 * d.T * d.H * d.W * cout * cin * d.kt * d.kh * d.kw
+
     def __call__(self):
+        ev = self.events
+        if ev is not None:                  # bench.py: HIP events on the launch stream around this launch
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+            self._launch()
+            pair[1].record()
+            ev.append(pair)
+        else:
+            self._launch()
+
+    def _launch(self):
         if self.ysweep:
             L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
         elif self.nslice > 1:
@@ -231,7 +251,9 @@ class PackedBlock:
 class ScaleEngine:
     """All state of one forward_update_block call: buffers, descriptors, iteration stages."""
 
-    def __init__(self, pk: PackedBlock, T: int, h: int, w: int, device):
+    def __init__(self, pk: PackedBlock, T: int, h: int, w: int, device, shard=None):
+        if shard is not None:
+            raise NotImplementedError("frame-sharded engine: see ppmstereo_amd/dist.py")
         if T > 64:
             raise NotImplementedError("more than 64 frames per window")
         self.pk, self.T, self.h, self.w = pk, T, h, w
@@ -441,6 +463,16 @@ class ScaleEngine:
         if mhs is not None:
             self.load_nchw(mhs, self.CF[self.parity].view(256, 64))
 
+    # SP views of the state the cascade hands to the next scale (ppmstereo.py:726-732, 763-767)
+    def net_view(self) -> L.SP:
+        return self.Hb[0].view()
+
+    def mhs_view(self) -> L.SP:
+        return self.CF[self.parity].view(256, 64)
+
+    def UNC_local(self) -> torch.Tensor:
+        return self.UNC
+
     def get_net(self):
         return self.store_nchw(self.Hb[0].view(), 128)
 
@@ -558,6 +590,10 @@ class ScaleEngine:
                                        self.ATT_WS.data_ptr(), s))
         if ev is not None:
             ev[1].record()
+
+    def conv_ops(self, version: Optional[int] = None):
+        """name -> ConvOp of every implicit-GEMM launch of an iteration (version 3: only the large-map kernel's)."""
+        return {k: v for k, v in self.op.items() if isinstance(v, ConvOp) and (version is None or v.version == version)}
 
     def enable_attn_timing(self, launches: int):
         """HIP events (on the stream the kernel is launched on) around the next `launches` mem_attn launches."""

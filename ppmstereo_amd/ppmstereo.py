@@ -42,6 +42,25 @@ def convex_upsample(flow: torch.Tensor, mask: torch.Tensor, rate: int = 4) -> to
     return out
 
 
+def _run_iterations(eng, iters: int, isc: int, t: int, h: int, w: int, predictions: List, uncertainties: List, emit: str = "all"):
+    """The iteration loop on a prepared engine (ppmstereo.py:482-591).  emit: which iterations resize their prediction and
+    uncertainty to full resolution and append them (:578-591): "all" (the reference's lists), "last" or "none" --
+    PPMStereo.forward(test_mode=True) returns predictions[-1] alone (:801-804), so every other resize is dead work there."""
+    flow_out = None
+    for it in range(iters):
+        flow_out = eng.iterate()
+        if emit == "none" or (emit == "last" and it + 1 < iters):
+            continue
+        unc_up = bilinear(eng.UNC_local().view(t, 1, h, w), (4 * isc * h, 4 * isc * w), False)
+        if isc > 1:
+            flow_up = bilinear(flow_out[:, :1], (isc * 4 * h, isc * 4 * w), True, float(isc))
+        else:
+            flow_up = flow_out[:, :1].clone()
+        predictions.append(flow_up)
+        uncertainties.append(unc_up)
+    return flow_out
+
+
 def forward_update_block(self, image1, update_block: SequenceUpdateBlock3D, corr_fn: CorrBlock1D, flow: torch.Tensor, net: torch.Tensor,
                          inp: torch.Tensor, motion_hidden_state: Optional[torch.Tensor], attn_block: Attention_qk, predictions: List,
                          uncertainties: List, iters: int, interp_scale: float, t: int):
@@ -68,16 +87,7 @@ def forward_update_block(self, image1, update_block: SequenceUpdateBlock3D, corr
         eng.set_flow(flow)
         eng.set_mhs(motion_hidden_state)
         eng.begin(corr_fn.levels, attn_block.packed(inp.device))
-        flow_out = None
-        for _ in range(iters):
-            flow_out = eng.iterate()
-            unc_up = bilinear(eng.UNC.view(t, 1, h, w), (4 * isc * h, 4 * isc * w), False)
-            if isc > 1:
-                flow_up = bilinear(flow_out[:, :1], (isc * 4 * h, isc * 4 * w), True, float(isc))
-            else:
-                flow_up = flow_out[:, :1].clone()
-            predictions.append(flow_up)
-            uncertainties.append(unc_up)
+        flow_out = _run_iterations(eng, iters, isc, t, h, w, predictions, uncertainties)
         return flow_out.clone(), eng.get_net(), eng.get_mhs()
 
 
@@ -121,27 +131,44 @@ class PPMStereoHotPath(nn.Module):
 
     @torch.no_grad()
     def cascade(self, feats: Dict[str, torch.Tensor], iters: int, t: int, predictions: Optional[list] = None,
-                uncertainties: Optional[list] = None):
-        """The 1/16 -> 1/8 -> 1/4 cascade of PPMStereo.forward (ppmstereo.py:696-804).  feats: f1_s, f2_s, net_s, inp_s
-        for s in (16, 8, 4) on the GPU.  Returns (flow_up (T,1,H,W), uncertainty (T,1,H,W)) = predictions[-1], uncertainties[-1]."""
+                uncertainties: Optional[list] = None, shard=None, test_mode: bool = False):
+        """The 1/16 -> 1/8 -> 1/4 cascade of PPMStereo.forward (ppmstereo.py:696-804), device resident: the state handed from
+        scale to scale (hidden state, motion hidden state) stays in the engines' SP buffers (ppms_sp_resize_blend), only the
+        2-channel flow passes through an NCHW resize.  feats: f1_s, f2_s, net_s, inp_s for s in (16, 8, 4) on the GPU
+        (with ``shard``: this rank's frames only).  test_mode: only the final prediction is produced (ppmstereo.py:801-804).
+        Returns (flow_up (T,1,H,W), uncertainty (T,1,H,W)) = predictions[-1], uncertainties[-1]."""
         preds = [] if predictions is None else predictions
         uncs = [] if uncertainties is None else uncertainties
-        f16 = feats["f1_16"]
-        fo, net16, mhs16 = self.forward_update_block(None, self.update_block16, CorrBlock1D(feats["f1_16"], feats["f2_16"]), self.zero_init(f16),
-                                                     feats["net_16"], feats["inp_16"], None, self.att[0], preds, uncs, iters // 2, 4, t)
-        h8, w8 = feats["f1_8"].shape[2:]
-        flow8 = bilinear(fo, (h8, w8), True, -(h8 / fo.shape[2]))                                      # :724-725 (sign flip kept)
-        mhs8 = bilinear(mhs16, (2 * mhs16.shape[2], 2 * mhs16.shape[3]), True)                        # :726-727
-        net8 = (feats["net_8"] + bilinear(net16, (2 * net16.shape[2], 2 * net16.shape[3]), True)) / 2.0   # :729-732
-        fo, net8, mhs8 = self.forward_update_block(None, self.update_block08, CorrBlock1D(feats["f1_8"], feats["f2_8"]), flow8, net8,
-                                                   feats["inp_8"], mhs8, self.att[1], preds, uncs, iters // 2, 2, t)
-        h4, w4 = feats["f1_4"].shape[2:]
-        flow4 = bilinear(fo, (h4, w4), True, -(h4 / fo.shape[2]))                                      # :760-761
-        mhs4 = bilinear(mhs8, (2 * mhs8.shape[2], 2 * mhs8.shape[3]), True)                           # :763-764
-        net4 = (feats["net_4"] + bilinear(net8, (2 * net8.shape[2], 2 * net8.shape[3]), True)) / 2.0   # :765-767
-        self.forward_update_block(None, self.update_block04, CorrBlock1D(feats["f1_4"], feats["f2_4"]), flow4, net4, feats["inp_4"], mhs4,
-                                  self.att[2], preds, uncs, iters, 1, t)
-        return preds[-1], uncs[-1]
+        dev = feats["f1_16"].device
+        tl = feats["f1_16"].shape[0]                      # frames on this rank (== t without sharding)
+        if shard is None and tl != t:
+            raise NotImplementedError("cascade: batch size 1 only (frames == t)")
+        if t == 1:
+            warnings.warn("PPMStereo with a single frame produces NaN disparities (reference behaviour, T must be >= 2)")
+        lib = L.load()
+        with torch.cuda.device(dev):
+            prev, fo = None, None
+            for s_, blk, ai, n_it, isc in ((16, self.update_block16, 0, iters // 2, 4), (8, self.update_block08, 1, iters // 2, 2),
+                                          (4, self.update_block04, 2, iters, 1)):
+                f1, f2 = feats[f"f1_{s_}"], feats[f"f2_{s_}"]
+                h, w = f1.shape[2:]
+                eng = blk.engine(tl, h, w, dev, shard)
+                eng.set_inp(feats[f"inp_{s_}"])
+                eng.set_net(feats[f"net_{s_}"])
+                if prev is None:
+                    eng.set_flow(self.zero_init(f1))                                                  # :231-236, :695
+                    eng.set_mhs(None)
+                else:
+                    ph, pw = prev.h, prev.w
+                    eng.set_flow(bilinear(fo, (h, w), True, -(h / fo.shape[2])))                      # :724-725, :760-761 (sign flip kept)
+                    eng.parity, eng.have_mhs = 0, True                                                # :726-727, :763-764: mhs x2
+                    L.check(lib.ppms_sp_resize_blend(prev.mhs_view(), eng.mhs_view(), tl, ph, pw, 2 * ph, 2 * pw, 0.0, 1.0, L.stream_ptr()))
+                    # :729-732, :765-767: net = (net_s + interp(net_2s)) / 2
+                    L.check(lib.ppms_sp_resize_blend(prev.net_view(), eng.net_view(), tl, ph, pw, 2 * ph, 2 * pw, 0.5, 0.5, L.stream_ptr()))
+                eng.begin(CorrBlock1D(f1, f2).levels, self.att[ai].packed(dev))
+                fo = _run_iterations(eng, n_it, isc, tl, h, w, preds, uncs, "all" if not test_mode else ("last" if s_ == 4 else "none"))
+                prev = eng
+            return preds[-1], uncs[-1]
 
 
 def window_plan(num_ims: int, kernel_size: int = 20):

@@ -40,8 +40,8 @@ def synth_scale_inputs(T: int, h: int, w: int, seed: int, with_mhs: bool = True,
 
 
 # T = 40 >> top-k parity cases (tools/gen_golden.py, tests): inputs whose QAM pick is well conditioned -- smallest gap between
-# the 5th and 6th frame score over all clips and iterations 2.3e-4 / 3.8e-4 (seeds found by search with the CPU restatement under tests)
-T40_CASES = {"fub04_T40": dict(seed=601, frame_contrast=2.0), "fub16_T40": dict(seed=710, frame_contrast=2.0)}
+# the 5th and 6th frame score over all clips and iterations 1.6e-4 / 4.9e-4 (seeds found by search with the CPU restatement under tests)
+T40_CASES = {"fub04_T40": dict(seed=813, frame_contrast=1.0), "fub16_T40": dict(seed=903, frame_contrast=1.0)}
 
 
 def synth_cascade_feats(T: int, H: int, W: int, seed: int = 7) -> Dict[str, torch.Tensor]:

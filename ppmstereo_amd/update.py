@@ -194,17 +194,17 @@ class SequenceUpdateBlock3D(nn.Module):
             self._engines = OrderedDict()
         return self._pk
 
-    def engine(self, T: int, h: int, w: int, device) -> ScaleEngine:
+    def engine(self, T: int, h: int, w: int, device, shard=None) -> ScaleEngine:
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (T, h, w, str(device))
+        key = (T, h, w, str(device), None if shard is None else (shard.rank, shard.world, shard.T))
         pk = self.packed(device)
         if key not in self._engines:
             while len(self._engines) >= self.MAX_ENGINES:
                 self._engines.popitem(last=False)
             with torch.cuda.device(device):
-                self._engines[key] = ScaleEngine(pk, T, h, w, device)
+                self._engines[key] = ScaleEngine(pk, T, h, w, device, shard)
         self._engines.move_to_end(key)
         return self._engines[key]
 

@@ -89,10 +89,11 @@ def test_forward_update_block(model, name, tag, ai, T, h, w, iters, isc, mh):
     assert preds[-1].shape == rp[-1].shape and uncs[-1].shape == ru[-1].shape
     epe = (fo[:, 0].cpu() - rfo[:, 0]).abs().mean().item()
     assert epe < 2e-4, f"mean |disparity diff| {epe}"
-    assert maxdiff(fo, rfo) < 1e-3 and maxdiff(net, rnet) < 2e-3 and maxdiff(mhs, rmhs) < 5e-4
+    mhs_tol = 1e-3 if name in T40_CASES else 5e-4          # the T = 40 inputs carry a per-frame gain: activations up to 4x larger
+    assert maxdiff(fo, rfo) < 1e-3 and maxdiff(net, rnet) < 2e-3 and maxdiff(mhs, rmhs) < mhs_tol
     assert maxdiff(torch.stack(preds), torch.stack(rp)) < 1e-3 * isc and maxdiff(torch.stack(uncs), torch.stack(ru)) < 2e-4
     gd = Golden(name)
-    gd.check("flow_out", fo, 1e-3), gd.check("net", net, 2e-3), gd.check("mhs", mhs, 5e-4)
+    gd.check("flow_out", fo, 1e-3), gd.check("net", net, 2e-3), gd.check("mhs", mhs, mhs_tol)
     gd.check("preds", torch.stack(preds), 1e-3 * isc), gd.check("uncs", torch.stack(uncs), 2e-4)
 
 

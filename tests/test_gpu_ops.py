@@ -377,18 +377,20 @@ def test_qam_select_sequence(lib):
 
 # ------------------------------------------------------------------------------------------------ memory attention
 def _attn_check(got, ref, operands, scale):
-    """Per-element bound in bf16 ulps OF THE ELEMENT (not of the tensor's range): with bf16 operands as the oracle uses them,
-    err <= 2^-9 * (P |V|) for the bf16-rounded probabilities + 2^-8 |ref| for the bf16 result (+ 1e-6 fp32 slop); and the
-    typical error must sit far inside the worst case (rounding errors do not all line up)."""
+    """Per-element bound in bf16 ulps OF THE ELEMENT (not of the tensor's range).  bf16 keeps 8 significant bits: round to
+    nearest moves a value by at most 2^-8 of itself (half an ulp).  With bf16 operands as the oracle uses them the kernel's
+    two extra roundings give err <= 2^-8 * (P |V|) (probabilities rounded to bf16 before the PV product, worst case: all
+    errors aligned) + 2^-8 |ref| (the bf16 result) + 1e-6 fp32 slop; and the typical error must sit far inside that worst
+    case (rounding errors do not all line up)."""
     for i, (Q, K, V, _, _) in enumerate(operands):
         Qb, Kb, Vb = (t.to(torch.bfloat16).float() for t in (Q, K, V))
         P = torch.softmax((Qb @ Kb.t()) * scale, dim=-1)
-        bound = 2.0 ** -9 * (P @ Vb.abs()) + 2.0 ** -8 * ref[i].abs() + 1e-6
+        bound = 2.0 ** -8 * (P @ Vb.abs()) + 2.0 ** -8 * ref[i].abs() + 1e-6
         err = (got[i] - ref[i]).abs()
         assert torch.isfinite(got[i]).all()
         worst = (err / bound).max().item()
         assert worst <= 1.0, f"clip {i}: element error {worst:.2f}x its bf16 bound"
-        assert err.mean().item() <= 0.25 * bound.mean().item(), (err.mean().item(), bound.mean().item())
+        assert err.mean().item() <= 0.2 * bound.mean().item(), (err.mean().item(), bound.mean().item())
 
 
 @pytest.mark.parametrize("split", [False, True])
@@ -438,7 +440,7 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split):
     assert torch.equal(qb[0].float().cpu(), Q0.to(torch.bfloat16).float())
     assert torch.equal(kb[0].reshape(-1, 128).float().cpu(), K0.to(torch.bfloat16).float())
     # output, per element: the kernel rounds P to bf16 before the PV product (like flash-attention) and the result to bf16
-    # |err_d| <= 2^-9 * sum_k p_k |v_kd| (P rounding, worst case) + one bf16 ulp of the element (final rounding)
+    # |err_d| <= 2^-8 * sum_k p_k |v_kd| (P rounding, worst case) + half a bf16 ulp of the element (final rounding)
     _attn_check(raw.float().cpu(), ref, [(O.play_inputs(q, key, pe, value, score, mask, i)) for i in range(T)], scale)
     mfg = X.to_f32(128, 128).cpu()
     # mfg is stored split (hi + lo): ~2^-16 relative
