@@ -122,6 +122,14 @@ int ppms_conv_gemm2_ysweep(const ppms_conv* desc, const ppms_conv* dev_desc, int
  * stay the true extents. */
 int ppms_conv_gemm3_applicable(const ppms_conv* desc);
 int ppms_conv_gemm3(const ppms_conv* desc, const ppms_conv* dev_desc, void* stream);
+/* Barrier-free k-loop variant for the same convolutions (conv_gemm4.hip): the weights are packed in MFMA-fragment order
+ * (ppmstereo_amd/packing.py pack_conv4, sweep-ordered like ppms_conv_gemm3's packs) and go from L2 straight to registers; the
+ * activation window holds 16 channels and is double buffered, so the loop synchronises once per window instead of once per
+ * k-step.  128 couts x 256 (or 128) pixels per workgroup.  Applicable: M % 128 == 0, kw > 1 or kh > 1 (>= 3 swept taps),
+ * segments with c % 16 == 0, a halo'd window of <= 384 pixel rows, >= 256 workgroups. */
+int ppms_conv_gemm4_applicable(const ppms_conv* desc);
+/* tile_px: pixels per workgroup, 0 = let the library choose (256 when that still gives >= 1.5 workgroups per CU, else 128) */
+int ppms_conv_gemm4(const ppms_conv* desc, const ppms_conv* dev_desc, int tile_px, void* stream);
 /* sizeof(ppms_sp), sizeof(ppms_epilogue), sizeof(ppms_conv) as compiled: lets a foreign-language binding check its
  * struct layout at load time */
 int ppms_struct_sizes(int* sp, int* epilogue, int* conv);

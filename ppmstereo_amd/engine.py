@@ -30,6 +30,7 @@ from . import packing as _packing
 
 TOP_K = 5
 # tuning switches between HIP code paths of the library (A/B measurements on the GPU box; every setting runs HIP kernels only)
+USE_CONV4 = os.environ.get("PPMS_CONV4", "1") != "0"      # barrier-free k-loop kernel (conv_gemm4.hip) where it applies
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
 _YS = os.environ.get("PPMS_YSWEEP", "1")                  # conv_gemm2 one-window forms: 0 = off, 1 = y-swept (1, kh, 1) convs (default),
@@ -100,7 +101,9 @@ class ConvOp:
             self._launch()
 
     def _launch(self):
-        if self.ysweep:
+        if self.version == 4:
+            L.check(L.load().ppms_conv_gemm4(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
+        elif self.ysweep:
             L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
         elif self.nslice > 1:
             L.check(L.load().ppms_conv_gemm2_sliced(C.byref(self.desc), self.dev.data_ptr(), self.nslice, self.ws.data_ptr(), L.stream_ptr()))
@@ -157,13 +160,21 @@ class PackedBlock:
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)
         self.w: Dict[str, tuple] = {}
 
+        self.w4: Dict[str, tuple] = {}             # conv_gemm4 packs (MFMA-fragment order, sweep-ordered taps, M padded to 128)
+
         def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
             self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
             w5 = weight if weight.dim() == 5 else weight[:, :, None]
+            sweep = w5                                                     # x sweep: natural order
             if w5.shape[3] > 1 and w5.shape[4] > 1:
-                # k-step order of the large-map kernel's 2-D window sweep: (ky, kx) flattened into the x axis
-                flat = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, w5.shape[3] * w5.shape[4]).contiguous()
-                self.w[name + "_2d"] = pack_conv(flat, bias, segs, seg_pad, cout_map, m_pad)
+                # k-step order of the 2-D window sweep: (ky, kx) flattened into the x axis
+                sweep = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, w5.shape[3] * w5.shape[4]).contiguous()
+                self.w[name + "_2d"] = pack_conv(sweep, bias, segs, seg_pad, cout_map, m_pad)
+            elif w5.shape[3] > 1:
+                sweep = w5.transpose(3, 4).contiguous()                      # y sweep: kh / kw swapped
+            if USE_CONV4 and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
+                rows = (max(cout_map) + 1) if cout_map is not None else w5.shape[0]
+                self.w4[name] = _packing.pack_conv4(sweep, bias, segs, seg_pad, cout_map, (rows + 127) // 128 * 128)
 
         e = "encoder."
         put("init0", g(e + "init_conv.0.weight"), g(e + "init_conv.0.bias"), [128])
@@ -323,6 +334,14 @@ class ScaleEngine:
         if epi1 is not None:
             d.epi[1] = epi1
         version = 2
+        if USE_CONV4 and isinstance(wname, str) and wname in self.pk.w4:
+            packed4, bias4, meta4 = self.pk.w4[wname]
+            d4 = L.Conv.from_buffer_copy(bytes(d))
+            d4.w, d4.bias, d4.M = packed4.data_ptr(), bias4.data_ptr(), meta4["M"]
+            if m_split is None:
+                d4.m_split = meta4["M"]
+            if self.lib.ppms_conv_gemm4_applicable(C.byref(d4)):
+                return ConvOp(d4, [packed4, bias4, *keep], 4, device=self.dev)
         if USE_CONV3 and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
             # the large-map kernel wants its k-steps in sweep order: y-swept convs packed with kh / kw swapped ("_y"),
             # 2-D swept ones (kh, kw > 1) with (ky, kx) flattened into x ("_2d"); without such a pack: conv_gemm2

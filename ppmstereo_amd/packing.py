@@ -71,6 +71,59 @@ def pack_conv2(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
     return packed.reshape(-1), b, meta
 
 
+def pack_conv4(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
+               seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
+               m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+    """Layout of the barrier-free kernel (ppmstereo_amd/csrc/conv_gemm4.hip): the weights in MFMA-fragment order, so that a
+    wave loads its A operands straight from global memory into registers with coalesced 1 KiB loads:
+        bf16 [k16-step][M/64][frag = 2*mb + plane][lane = 32*h + r][8]
+             = W[cout = 64*blk + 32*mb + r][cin = 16*chunk + 8*h + j] of tap (row-step, s), plane 0 = hi, 1 = lo,
+        k16-step = ((kz*kh + ky) * nchunk16 + chunk) * kw + kx.
+    As for conv_gemm3 the LAST kernel axis is the swept one: y-swept convs are passed with kh / kw swapped, 2-D swept ones
+    with (ky, kx) flattened into x."""
+    w = weight.detach().float()
+    if w.dim() == 4:
+        w = w[:, :, None]
+    cout, cin, kt, kh, kw = w.shape
+    assert sum(seg_channels) == cin, (seg_channels, cin)
+    seg_padded = [_pad_to(c, 16) for c in seg_channels] if seg_padded is None else list(seg_padded)
+    assert all(p % 16 == 0 and p >= c for p, c in zip(seg_padded, seg_channels))
+    cpad = sum(seg_padded)
+    nchunk = cpad // 16
+    rows = list(range(cout)) if cout_map is None else list(cout_map)
+    M = _pad_to(max(rows) + 1, 128) if m_pad is None else m_pad
+    assert M % 128 == 0 and max(rows) < M
+    wk = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh, kw, cin)              # [cout][trow][kx][ci]
+    full = torch.zeros(M, kt * kh, kw, cpad, dtype=torch.float32, device=w.device)
+    ridx = torch.tensor(rows, device=w.device)
+    src = dst = 0
+    for c, p in zip(seg_channels, seg_padded):
+        full[ridx, :, :, dst:dst + c] = wk[:, :, :, src:src + c]
+        src += c
+        dst += p
+    nk = kt * kh * nchunk * kw
+    # [blk][mb][r][trow][kx][chunk][h][j] -> [trow][chunk][kx][blk][mb][h][r][j]
+    t = full.reshape(M // 64, 2, 32, kt * kh, kw, nchunk, 2, 8).permute(3, 5, 4, 0, 1, 6, 2, 7).contiguous()
+    t = t.reshape(nk, M // 64, 2, 64, 8)
+    hi, lo = split_bf16(t)
+    packed = torch.stack([hi, lo], dim=3).contiguous()                    # [ks][blk][mb][plane][lane][8]
+    b = torch.zeros(M, dtype=torch.float32, device=w.device)
+    if bias is not None:
+        b[ridx] = bias.detach().float()
+    meta = dict(M=M, nk=nk, taps=(kt, kh, kw), cpad=cpad, seg_padded=seg_padded, version=4)
+    return packed.reshape(-1), b, meta
+
+
+def unpack_conv4_reference(packed: torch.Tensor, M: int, nk: int, taps, nchunk: int) -> torch.Tensor:
+    """Inverse of pack_conv4 -> fp32 [M][K] in the plain K order (k = tap*Cpad + ci), for the host-logic tests."""
+    kt, kh, kw = taps
+    t = packed.reshape(nk, M // 64, 2, 2, 64, 8).float()                  # [ks][blk][mb][plane][lane][8]
+    t = t[:, :, :, 0] + t[:, :, :, 1]                                      # [ks][blk][mb][lane][8]
+    t = t.reshape(kt * kh, nchunk, kw, M // 64, 2, 2, 32, 8)               # [trow][chunk][kx][blk][mb][h][r][j]
+    t = t.permute(3, 4, 6, 0, 2, 1, 5, 7)                                  # [blk][mb][r][trow][kx][chunk][h][j]
+    return t.reshape(M, kt * kh * kw * nchunk * 16)
+
+
 def unpack_conv2_reference(packed: torch.Tensor, M: int, nk: int, taps, nchunk: int) -> torch.Tensor:
     """Inverse of pack_conv2 -> fp32 [M][K] in the plain K order (k = tap*Cpad + ci, tap = (kz*kh + ky)*kw + kx), for the host-logic tests."""
     kt, kh, kw = taps

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 from oracle import ppm_oracle as O
 from ppmstereo_amd import weights as Wm
-from ppmstereo_amd.packing import BK, pack_conv2, unpack_conv2_reference
+from ppmstereo_amd.packing import BK, pack_conv2, pack_conv4, unpack_conv2_reference, unpack_conv4_reference
 from ppmstereo_amd.weights import hash_normal
 
 
@@ -54,6 +54,53 @@ def test_packing_reproduces_the_convolution(segs, cout, k3):
     x5 = torch.cat(xs, 1).reshape(1, T, H, W, cin).permute(0, 4, 1, 2, 3)
     ref = F.conv3d(x5, wt, bs, padding=tuple(k // 2 for k in k3)).permute(0, 2, 3, 4, 1).reshape(P, cout)
     assert (got - ref).abs().max() < 2e-4 * (1 + ref.abs().max())          # hi+lo weights carry ~16 mantissa bits
+
+
+@pytest.mark.parametrize("segs,cout,k3", [([128, 384], 256, (1, 1, 15)), ([48, 16], 190, (1, 3, 3)), ([128], 256, (3, 3, 3)), ([64], 128, (1, 5, 1))])
+def test_fragment_order_packing_reproduces_the_convolution(segs, cout, k3):
+    """pack_conv4 (conv_gemm4.hip: weights in MFMA-fragment order, 16-channel k-steps, taps in sweep order) unpacks to the same
+    weight matrix: checked against F.conv3d, with the sweep-axis conventions the engine uses (y sweep: kh / kw swapped; 2-D
+    sweep: (ky, kx) flattened into x)."""
+    T, H, W = 2, 5, 6
+    P = T * H * W
+    cin = sum(segs)
+    xs = [hash_normal((P, c), 10 + i) for i, c in enumerate(segs)]
+    wt = hash_normal((cout, cin, *k3), 20) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 21)
+    kt, kh, kw = k3
+    sweep = wt
+    if kh > 1 and kw > 1:
+        sweep = wt.reshape(cout, cin, kt, 1, kh * kw)
+    elif kh > 1:
+        sweep = wt.transpose(3, 4).contiguous()
+    seg_pad = [((c + 15) // 16) * 16 for c in segs]
+    packed, bias, meta = pack_conv4(sweep, bs, segs, seg_pad)
+    assert packed.dtype == torch.bfloat16 and meta["M"] % 128 == 0 and packed.numel() == 2 * meta["M"] * meta["nk"] * 16
+    Wm_ = unpack_conv4_reference(packed, meta["M"], meta["nk"], meta["taps"], meta["cpad"] // 16)      # [M][taps of the packed view * cpad]
+    # bring the packed view's tap order back to (kz, ky, kx) of the true kernel
+    cp = meta["cpad"]
+    Wv = Wm_.reshape(meta["M"], kt, meta["taps"][1], meta["taps"][2], cp)
+    if kh > 1 and kw > 1:
+        Wv = Wv.reshape(meta["M"], kt, kh, kw, cp)
+    elif kh > 1:
+        Wv = Wv.transpose(2, 3)
+    cols, xp = [], []
+    for x, c_ in zip(xs, seg_pad):
+        xp.append(F.pad(x, (0, c_ - x.shape[1])))
+    xcat = torch.cat(xp, 1).reshape(T, H, W, -1)
+    for kz in range(kt):
+        for ky in range(kh):
+            for kx in range(kw):
+                dt, dy, dx = kz - kt // 2, ky - kh // 2, kx - kw // 2
+                sh = torch.zeros_like(xcat)
+                t0, t1, y0, y1, x0, x1 = max(0, -dt), min(T, T - dt), max(0, -dy), min(H, H - dy), max(0, -dx), min(W, W - dx)
+                if t0 < t1 and y0 < y1 and x0 < x1:
+                    sh[t0:t1, y0:y1, x0:x1] = xcat[t0 + dt:t1 + dt, y0 + dy:y1 + dy, x0 + dx:x1 + dx]
+                cols.append(sh.reshape(P, -1))
+    got = (torch.cat(cols, 1) @ Wv.reshape(meta["M"], -1).t() + bias)[:, :cout]
+    x5 = torch.cat(xs, 1).reshape(1, T, H, W, cin).permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(x5, wt, bs, padding=tuple(k // 2 for k in k3)).permute(0, 2, 3, 4, 1).reshape(P, cout)
+    assert (got - ref).abs().max() < 2e-4 * (1 + ref.abs().max())
 
 
 def test_packing_cout_map_routes_groups_to_aligned_blocks():
