@@ -32,8 +32,9 @@ HEADERS = ["common.h", "conv_epilogue.h", os.path.join("..", "..", "include", "p
 # tools/race_probe.py, tests/test_gpu_concurrency.py).  Sources listed in PACKED_FP32_SOURCES keep the packed forms.
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+EXTRA = [x for x in os.environ.get("PPMS_BUILD_DEFINES", "").split() if x]        # build-time A/B only, e.g. "-DPPMS_CONV4_PRIO=2"
 PACKED_FP32_SOURCES: tuple = tuple(x for x in os.environ.get("PPMS_BUILD_PACKED_FP32", "").split(",") if x)   # build-time A/B only
-FLAGS = COMMON + NO_PK
+FLAGS = COMMON + NO_PK + EXTRA
 
 
 def _digest() -> str:
@@ -81,7 +82,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
                 procs = []
                 for src in SOURCES:                # compile the translation units in parallel (independent hipcc processes)
                     obj = os.path.join(tmp, src.replace(".hip", ".o"))
-                    cmd = [hipcc] + (COMMON if src in PACKED_FP32_SOURCES else FLAGS) + ["-c", os.path.join(CSRC, src), "-o", obj]
+                    cmd = [hipcc] + (COMMON + EXTRA if src in PACKED_FP32_SOURCES else FLAGS) + ["-c", os.path.join(CSRC, src), "-o", obj]
                     if verbose:
                         print("[ppmstereo_amd.build]", " ".join(cmd), file=sys.stderr)
                     procs.append((cmd, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))

@@ -46,12 +46,27 @@ __device__ __forceinline__ void dma16_4(const void* src, char* lds_dst) {
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
 __device__ __forceinline__ void vm_wait(int n) {
 #define PPMS_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    if (n == 8) {                                  // the steady state
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        return;
+    }
     switch (n) {
-        PPMS_VMW(4) PPMS_VMW(8) PPMS_VMW(9) PPMS_VMW(10) PPMS_VMW(11) PPMS_VMW(12) PPMS_VMW(13) PPMS_VMW(14)
+        PPMS_VMW(4) PPMS_VMW(9) PPMS_VMW(10) PPMS_VMW(11) PPMS_VMW(12) PPMS_VMW(13) PPMS_VMW(14)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // 0, and any other count: the safe full drain
     }
 #undef PPMS_VMW
 }
+
+// PRIO: 0 = no priority changes; 1 = priority 1 from a step's first MFMA to its last; 2 = priority 1 around each MFMA group
+#ifndef PPMS_CONV4_PRIO
+#define PPMS_CONV4_PRIO 1
+#endif
+constexpr int PRIO = PPMS_CONV4_PRIO;
+// timing ablations (diagnostic builds only: wrong results): skip the A loads / the B fragment reads / the window DMA / the epilogue
+#ifndef PPMS_ABL
+#define PPMS_ABL 0
+#endif
+constexpr bool ABL_A = PPMS_ABL & 1, ABL_B = PPMS_ABL & 2, ABL_D = PPMS_ABL & 4, ABL_E = PPMS_ABL & 8;
 
 template <int NB>
 __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restrict__ pd, const Geo4 g) {
@@ -70,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
     const int H = p.H, W = p.W, T = p.T;
     const int HW = H * W;
     const int ht = p.kt >> 1, hy = p.kh >> 1;
-    const int wbytes = g.Wr * 64;                  // one window buffer
+    const int wbytes = g.npieces * (NT * 16);      // one window buffer: whole 4 KiB DMA pieces (>= Wr * 64)
 
     // ---- window slots: LDS piece q = tid + i*256 (lane-linear destination); row = q >> 2, position q & 3 ---------------------
     // a 64-B row holds [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] of one pixel's 16-channel chunk, chunk c stored at position
@@ -91,9 +106,6 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
             if ((unsigned)x < (unsigned)W) sl_off[i] = (tf * H + y) * W + x;
         }
     }
-    // pieces are whole 1 KiB wave-instructions (Wr % 16 == 0): wave v issues piece i iff i*256 + v*64 < nq -- the last piece of a
-    // window is issued by the first waves only, and every wave counts ITS OWN pieces in the vmcnt arithmetic below
-    const int np_w = __builtin_amdgcn_readfirstlane((nq - wave * 64 + NT - 1) / NT);
     const int src_chunk = (tid & 3) ^ ((tid >> 4) & 3);          // 0,1: hi k0-7 / k8-15;  2,3: lo k0-7 / k8-15
     const int src_plane = src_chunk >> 1, src_k8 = (src_chunk & 1) * 8;
 
@@ -124,7 +136,8 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
         char* d = smem + buf * wbytes + wave * 1024;
 #pragma unroll
         for (int i = 0; i < MAXS4; ++i) {
-            if (i < np_w) {                                       // wave-uniform
+            if (i < g.npieces) {                                  // uniform: every wave issues every piece (lanes past the window
+                                                                  // read the zero page into the buffer's padding), so all waves count alike
                 const bool ok = tok && sl_off[i] >= 0 && (unsigned)(sl_y[i] + dy) < (unsigned)H;
                 const void* ps = ok ? (const void*)(sp + (int64_t)(sl_off[i] + shift) * ld + c0) : (const void*)zpage;
                 dma16_4(ps, d + i * NT * 16);
@@ -169,49 +182,75 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
     const int nsteps = nwin * g.nsweep;
     const int ks0 = win0 * g.nsweep;               // packed k16-steps are in (window, tap) order
 
+    // B fragments of one tap from a window buffer: cpos 0 = hi chunks, 2 = lo chunks.  The reads are inline asm so that the
+    // LDS counter is managed by hand below (reads return in order: with the NB youngest reads still in flight the older group has
+    // arrived) -- the compiler's own bookkeeping across the loop back-edge degenerates to lgkmcnt(0) in front of every MFMA group.
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    auto read_b = [&](bf16x8 (&dst)[NB], int buf, int trow_, int cpos) {
+        const unsigned bs = lds0 + buf * wbytes;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int row = brow[nb] + trow_;
+            const unsigned addr = bs + row * 64 + (((cpos + h) ^ ((row >> 2) & 3)) << 4);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dst[nb]) : "v"(addr) : "memory");
+        }
+    };
+    auto lgkm_wait_older = [&](bool younger_group_in_flight) {     // the older of the (at most) two fragment groups in flight has arrived
+        if (younger_group_in_flight) {
+            if (NB == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+    };
+
+    // ---- prologue: window 0, the first two A stages, then window 1 in flight; hi fragments of step 0 ------------------------
     dma_b(win0, 0);
     load_a(areg[0], ks0);
     load_a(areg[1], ks0 + 1);                      // (nsteps >= 3: nsweep >= 3)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // window 0 landed (everything but the 8 A loads)
+    __builtin_amdgcn_s_barrier();
+    if (nwin > 1) dma_b(win0 + 1, 1);
     int sw = 0, swx = 0, trow = 0, w = 0;
-    bool dma_young = false;                        // a window DMA was issued at the last window top
-    // one k16-step with static A stage U; JJ = global step index (a macro: the body must be inlined with U a literal so that the
-    // register arrays are indexed statically)
+    bf16x8 bh[NB], bl[NB];
+    read_b(bh, 0, 0, 0);
+    // One k16-step with static A stage U (a macro: the body must be inlined with U a literal so that the register arrays are
+    // indexed statically).  Software pipeline inside the step, so that the matrix pipe never waits for LDS:
+    //     lo fragments of THIS step are requested at its start and used by its last 8 MFMAs,
+    //     hi fragments of the NEXT step are requested after the 16th MFMA (the hi registers are dead by then).
+    // When the next step opens a new window, the window switch happens at that point too: wait for this wave's pieces of the
+    // next window (older than the 8 youngest A loads), barrier (all waves' pieces landed, all waves done reading the current
+    // window: their lo reads are retired by the lgkmcnt), then request the window after next into the buffer just left.
+    // vmcnt arithmetic: A(jj) was issued two steps ago; younger ops are A(jj+1), A(jj+2) (4 loads each, when they exist) and --
+    // when the last switch lies less than two steps back (tap index < 2) and issued a window -- that window's pieces.
 #define CONV4_STEP(U, JJ)                                                                                                      \
     {                                                                                                                          \
         const int jj = (JJ);                                                                                                   \
-        if (sw == 0) {                                                                                                         \
-            /* window top: this wave's pieces of window w have landed (everything but the 4 (DEPTH - 1) youngest ops, which */  \
-            /* are A loads issued later), then all waves'; everybody has also finished sweeping window w - 1 */                \
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                   \
-            __builtin_amdgcn_s_barrier();                                                                                      \
-            dma_young = (w + 1 < nwin);                                                                                        \
-            if (dma_young) dma_b(win0 + w + 1, (w + 1) & 1);                                                                   \
-        }                                                                                                                      \
         const int ahead = nsteps - 1 - jj; /* steps after this one */                                                          \
-        if (ahead >= DEPTH - 1) load_a(areg[((U) + DEPTH - 1) % DEPTH], ks0 + jj + DEPTH - 1);                                 \
-        /* A(jj) was issued DEPTH - 1 steps ago; younger: the A loads of up to DEPTH - 1 later steps and, when the last */     \
-        /* window top was less than DEPTH - 1 steps ago, that top's window pieces */                                           \
-        const int nyoung = 4 * (ahead < DEPTH - 1 ? ahead : DEPTH - 1) + ((dma_young && sw < DEPTH - 1) ? np_w : 0);           \
-        vm_wait(nyoung);                                                                                                       \
+        if (ahead >= DEPTH - 1 && !ABL_A) load_a(areg[((U) + DEPTH - 1) % DEPTH], ks0 + jj + DEPTH - 1);                       \
+        if (!ABL_B) read_b(bl, w & 1, trow, 2);                                                                                \
+        if (ABL_A) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                            \
+        else vm_wait(4 * (ahead < DEPTH - 1 ? ahead : DEPTH - 1) + ((sw < DEPTH - 1 && w + 1 < nwin && !ABL_D) ? g.npieces : 0)); \
+        lgkm_wait_older(true); /* hi fragments (requested in the previous step) are in; the lo requests may still fly */      \
         __builtin_amdgcn_sched_barrier(0);                                                                                     \
-        const char* bs = smem + (w & 1) * wbytes;                                                                              \
-        bf16x8 bh[NB], bl[NB];                                                                                                 \
-        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                                    \
-            const int row = brow[nb] + trow;                                                                                   \
-            const int sz = (row >> 2) & 3;                                                                                     \
-            bh[nb] = *(const bf16x8*)(bs + row * 64 + ((h ^ sz) << 4));                                                        \
-            bl[nb] = *(const bf16x8*)(bs + row * 64 + (((2 + h) ^ sz) << 4));                                                  \
-        }                                                                                                                      \
-        _Pragma("unroll") for (int mb = 0; mb < 2; ++mb) {                                                                     \
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, areg[U][2 * mb]), al = __builtin_bit_cast(bf16x8, areg[U][2 * mb + 1]); \
-            _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) {                                                                \
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[nb], acc[mb][nb], 0, 0, 0);                       \
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[nb], acc[mb][nb], 0, 0, 0);                       \
-                acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[nb], acc[mb][nb], 0, 0, 0);                       \
-            }                                                                                                                  \
-        }                                                                                                                      \
+        if (PRIO) __builtin_amdgcn_s_setprio(1);                                                                               \
+        const bf16x8 ah0 = __builtin_bit_cast(bf16x8, areg[U][0]), al0 = __builtin_bit_cast(bf16x8, areg[U][1]);               \
+        const bf16x8 ah1 = __builtin_bit_cast(bf16x8, areg[U][2]), al1 = __builtin_bit_cast(bf16x8, areg[U][3]);               \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[nb], acc[0][nb], 0, 0, 0); \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[nb], acc[1][nb], 0, 0, 0); \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[nb], acc[0][nb], 0, 0, 0); \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[nb], acc[1][nb], 0, 0, 0); \
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(0);                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        /* advance the tap state to the next step */                                                                          \
         if (++sw == g.nsweep) {                                                                                                \
             sw = swx = trow = 0;                                                                                               \
+            if (ahead > 0) {                                                                                                   \
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                               \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+                __builtin_amdgcn_s_barrier();                                                                                  \
+                if (w + 2 < nwin && !ABL_D) dma_b(win0 + w + 2, w & 1);                                                        \
+            }                                                                                                                  \
             ++w;                                                                                                               \
         } else {                                                                                                               \
             ++trow;                                                                                                            \
@@ -220,8 +259,15 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
                 trow += g.row_jump;                                                                                            \
             }                                                                                                                  \
         }                                                                                                                      \
+        if (ahead > 0 && !ABL_B) read_b(bh, w & 1, trow, 0);                                                                   \
+        lgkm_wait_older(ahead > 0); /* lo fragments are in */                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(1);                                                                          \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[nb], acc[0][nb], 0, 0, 0); \
+        _Pragma("unroll") for (int nb = 0; nb < NB; ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[nb], acc[1][nb], 0, 0, 0); \
+        if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                               \
     }
-    static_assert(DEPTH == 3, "the window-top wait is vmcnt(4 * (DEPTH - 1)); the step loop is unrolled DEPTH times");
+    static_assert(DEPTH == 3, "the switch waits are vmcnt(4 * (DEPTH - 1)); the step loop is unrolled DEPTH times");
     for (int j = 0; j < nsteps; j += DEPTH) {
         CONV4_STEP(0, j)
         if (j + 1 < nsteps) CONV4_STEP(1, j + 1)
@@ -245,6 +291,15 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
             b8[j] = b0[j];
             b8[4 + j] = b1[j];
         }
+    }
+    if (ABL_E) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)                               // keep every accumulator live (no dead-code elimination of MFMAs)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ((volatile float*)smem)[tid] = acc[a][b][i];
+        return;
     }
 #pragma unroll 1
     for (int nb = 0; nb < NB; ++nb) {              // (not unrolled: code size; the selects keep every accumulator index static)
@@ -392,7 +447,7 @@ extern "C" int ppms_conv_gemm4(const ppms_conv* d, const ppms_conv* dev_desc, in
     PPMS_REQUIRE(g.nsweep >= 3, "conv_gemm4: the sweep must have at least 3 taps");
     PPMS_REQUIRE(4 * (DEPTH - 1) + g.npieces <= 18 && g.npieces >= 1, "conv_gemm4: window of %d rows needs too many DMA pieces", g.Wr);
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
-    size_t lds = (size_t)2 * g.Wr * 64;
+    size_t lds = (size_t)2 * g.npieces * NT * 16;     // two window buffers of whole 4 KiB DMA pieces
     if (lds < (size_t)4 * STG_WAVE) lds = (size_t)4 * STG_WAVE;          // the epilogue's transposition patches reuse the windows
     PPMS_REQUIRE(lds <= 80 * 1024, "conv_gemm4: window of %d rows does not fit", g.Wr);
     static ppms_device_once once;

@@ -30,7 +30,7 @@ from . import packing as _packing
 
 TOP_K = 5
 # tuning switches between HIP code paths of the library (A/B measurements on the GPU box; every setting runs HIP kernels only)
-USE_CONV4 = os.environ.get("PPMS_CONV4", "1") != "0"      # barrier-free k-loop kernel (conv_gemm4.hip) where it applies
+USE_CONV4 = os.environ.get("PPMS_CONV4", "0") != "0"      # barrier-free k-loop kernel (conv_gemm4.hip): measured equal to conv_gemm3 so far, off
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
 _YS = os.environ.get("PPMS_YSWEEP", "1")                  # conv_gemm2 one-window forms: 0 = off, 1 = y-swept (1, kh, 1) convs (default),
