@@ -161,6 +161,10 @@ int ppms_flow_add(float* flow_nhwc, const float* dflow, int dflow_ld, int64_t pi
 /* PPMStereo.convex_upsample, ppmstereo.py:185-197.  flow: fp32 [pixel][2]; mask: fp32 [pixel][mask_ld] (144 used);
  * out: fp32 NCHW (BT,2,4H,4W). */
 int ppms_convex_upsample(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int BT, int H, int W, void* stream);
+/* PPMStereo.convex_upsample_3d, ppmstereo.py:199-228 (use_convex_3d=True): 27 spatio-temporal neighbours of one window of T
+ * frames; mask: fp32 [pixel][mask_ld] (432 = 27 * 16 used, channel 16 k + 4 i + j, k = (kt*3 + ky)*3 + kx);
+ * out: fp32 NCHW (T,2,4H,4W).  unfoldNd (absent third-party module) restated from its published semantics (zero padding). */
+int ppms_convex_upsample_3d(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int T, int H, int W, void* stream);
 /* F.interpolate(mode="bilinear") on NCHW fp32, both align_corners modes (ppmstereo.py:578,580-587; utils.py:10-16);
  * out = mul * interp(src). */
 int ppms_bilinear(const float* src, float* dst, int N, int C, int H, int W, int OH, int OW, int align_corners, float mul, void* stream);
@@ -169,6 +173,13 @@ int ppms_bilinear(const float* src, float* dst, int N, int C, int H, int W, int 
  * dst = a * dst + b * interp(src), interp = F.interpolate(mode="bilinear", align_corners=True) from HxW to OHxOW.
  * src, dst: SP views with the same channel count (multiple of 8). */
 int ppms_sp_resize_blend(ppms_sp src, ppms_sp dst, int N, int H, int W, int OH, int OW, float a, float b, void* stream);
+
+/* Pre-loop glue of PPMStereo.forward (ppmstereo.py:620-682), NCHW fp32: avg_pool2d(k, stride k) of `planes` HxW planes;
+ * out = a x + b y[i mod period] (plain or frame-broadcast axpby); net = tanh((f[:, :128] + c[:, :128]) / 2),
+ * inp = relu((f[:, 128:] + c[:, 128:]) / 2) for f, c of shape (N, 256, HW). */
+int ppms_avgpool(const float* src, float* dst, int planes, int H, int W, int k, void* stream);
+int ppms_axpby(const float* x, const float* y, float* out, float a, float b, int64_t period, int64_t n, void* stream);
+int ppms_ctx_mix(const float* fmap, const float* ctx, float* net, float* inp, int N, int HW, void* stream);
 
 /* ---------------------------------------------------------------- pick-and-play memory attention */
 /* PPMStereo.compute_qk_similarity, ppmstereo.py:397-423.  q,k: fp32 [T][H*W][ld] channel-last (128 channels);

@@ -74,8 +74,12 @@ _SIGS = {
     "ppms_tap_gather_sum": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_flow_add": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "ppms_convex_upsample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppms_convex_upsample_3d": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ppms_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ppms_sp_resize_blend": (c_int, [SP, SP, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
+    "ppms_avgpool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ppms_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64, c_int64, c_void_p]),
+    "ppms_ctx_mix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_qk_similarity": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ppms_qam_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppms_attn_prep_q": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),

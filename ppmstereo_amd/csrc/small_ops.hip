@@ -425,6 +425,57 @@ extern "C" int ppms_convex_upsample(const float* flow_nhwc, const float* mask, i
     return ppms_check_launch("convex_upsample");
 }
 
+// PPMStereo.convex_upsample_3d, ppmstereo.py:199-228 (use_convex_3d=True): 27 neighbours (kt, ky, kx) of the (t, y, x) volume,
+// out[t][c][4y+i][4x+j] = sum_k softmax_k(mask[t][16k + 4i + j][y][x]) * 4 flow[t+kt-1][c][y+ky-1][x+kx-1], zero padded
+// (unfoldNd.UnfoldNd([3,3,3], padding=1): k = (kt*3 + ky)*3 + kx).  One thread = one (pixel, sub-position i*4+j).
+__global__ __launch_bounds__(256) void convex_upsample3d_kernel(const float* __restrict__ flow, const float* __restrict__ mask, int mask_ld,
+                                                                float* __restrict__ out, int T, int H, int W, int64_t P) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P * 16) return;
+    const int sub = (int)(idx & 15);
+    const int64_t pix = idx >> 4;
+    const int x = (int)(pix % W), y = (int)((pix / W) % H);
+    const int64_t frame = pix / ((int64_t)W * H);
+    const float* mp = mask + pix * mask_ld + sub;
+    float mv[27];
+    float mx = mp[0];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        mv[k] = mp[16 * k];
+        mx = fmaxf(mx, mv[k]);
+    }
+    float den = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        mv[k] = expf(mv[k] - mx);
+        den += mv[k];
+    }
+    float o0 = 0.0f, o1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const int dt = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
+        const int tt = (int)frame + dt, yy = y + dy, xx = x + dx;
+        if ((unsigned)tt < (unsigned)T && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+            const int64_t q = pix + ((int64_t)dt * H + dy) * W + dx;
+            const float wgt = mv[k] / den;
+            o0 += wgt * (4.0f * flow[q * 2]);
+            o1 += wgt * (4.0f * flow[q * 2 + 1]);
+        }
+    }
+    const int i = sub >> 2, j = sub & 3;
+    const int64_t OW = 4 * (int64_t)W, OHW = 16 * (int64_t)H * W;
+    const int64_t o = (frame * 2) * OHW + (int64_t)(4 * y + i) * OW + 4 * x + j;
+    out[o] = o0;
+    out[o + OHW] = o1;
+}
+extern "C" int ppms_convex_upsample_3d(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int T, int H, int W, void* stream) {
+    PPMS_REQUIRE(flow_nhwc && mask && out && mask_ld >= 432 && T > 0 && H > 0 && W > 0, "convex_upsample_3d: bad arguments");
+    const int64_t P = (int64_t)T * H * W;
+    hipLaunchKernelGGL(convex_upsample3d_kernel, dim3(ceil_div(P * 16, 256)), dim3(256), 0, (hipStream_t)stream, flow_nhwc, mask, mask_ld,
+                       out, T, H, W, P);
+    return ppms_check_launch("convex_upsample_3d");
+}
+
 // ------------------------------------------------------------------------------------------------ bilinear resize
 // torch upsample_bilinear2d semantics (aten/native/UpSample.h area_pixel_compute_source_index)
 __global__ __launch_bounds__(256) void bilinear_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int OH, int OW,
@@ -518,6 +569,58 @@ extern "C" int ppms_sp_resize_blend(ppms_sp src, ppms_sp dst, int N, int H, int 
     const int64_t n = (int64_t)N * OH * OW * (src.c / 8);
     hipLaunchKernelGGL(sp_resize_blend_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, OH, OW, src.c / 8, sh, sw, a, b, n);
     return ppms_check_launch("sp_resize_blend");
+}
+
+// ------------------------------------------------------------------------------------------------ pre-loop glue of PPMStereo.forward
+// (ppmstereo.py:620-682, between the encoders and the loop: the caller of the hot path)
+// F.avg_pool2d(x, k, stride=k) on NCHW fp32 planes (k = 4: 1/4 -> 1/16 features :649-650, k = 2: :666-671)
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int W, int k, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    const int OW = W / k, OH = H / k;
+    const int ox = (int)(idx % OW), oy = (int)((idx / OW) % OH);
+    const int64_t plane = idx / ((int64_t)OW * OH);
+    const float* s = src + plane * H * W + (int64_t)oy * k * W + ox * k;
+    float acc = 0.0f;
+    for (int dy = 0; dy < k; ++dy)
+        for (int dx = 0; dx < k; ++dx) acc += s[dy * W + dx];
+    dst[idx] = acc / (float)(k * k);
+}
+extern "C" int ppms_avgpool(const float* src, float* dst, int planes, int H, int W, int k, void* stream) {
+    PPMS_REQUIRE(src && dst && planes > 0 && k > 0 && H >= k && W >= k, "avgpool: bad arguments");
+    const int64_t n = (int64_t)planes * (H / k) * (W / k);
+    hipLaunchKernelGGL(avgpool_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, k, n);
+    return ppms_check_launch("avgpool");
+}
+// out = a * x + b * y[i mod period]  (period = n: plain axpby; period = C*H*W: y broadcast over frames, the positional encoding
+// of :327-333; a = b = 0.5: the feature / context averages of :627-628, :666-671)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out, float a, float b,
+                                                    int64_t period, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx < n) out[idx] = a * x[idx] + b * y[idx % period];
+}
+extern "C" int ppms_axpby(const float* x, const float* y, float* out, float a, float b, int64_t period, int64_t n, void* stream) {
+    PPMS_REQUIRE(x && y && out && n > 0 && period > 0, "axpby: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, out, a, b, period, n);
+    return ppms_check_launch("axpby");
+}
+// net = tanh((f[:, :128] + c[:, :128]) / 2), inp = relu((f[:, 128:] + c[:, 128:]) / 2)   (:620-632, :660-664, :673-682);
+// f, c: NCHW (N, 256, HW); net, inp: NCHW (N, 128, HW).  tanhf: the library-accurate form (one-off per scale).
+__global__ __launch_bounds__(256) void ctx_mix_kernel(const float* __restrict__ f, const float* __restrict__ c, float* __restrict__ net,
+                                                      float* __restrict__ inp, int64_t chw, int64_t n) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over N * 128 * HW
+    if (idx >= n) return;
+    const int64_t frame = idx / chw, rem = idx - frame * chw;
+    const int64_t src = frame * 2 * chw + rem;
+    net[idx] = tanhf((f[src] + c[src]) / 2.0f);
+    const float v = (f[src + chw] + c[src + chw]) / 2.0f;
+    inp[idx] = v < 0.0f ? 0.0f : v;
+}
+extern "C" int ppms_ctx_mix(const float* fmap, const float* ctx, float* net, float* inp, int N, int HW, void* stream) {
+    PPMS_REQUIRE(fmap && ctx && net && inp && N > 0 && HW > 0, "ctx_mix: bad arguments");
+    const int64_t chw = (int64_t)128 * HW, n = (int64_t)N * chw;
+    hipLaunchKernelGGL(ctx_mix_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, fmap, ctx, net, inp, chw, n);
+    return ppms_check_launch("ctx_mix");
 }
 
 // ------------------------------------------------------------------------------------------------ frame similarity

@@ -240,8 +240,13 @@ class PackedBlock:
         w2 = g("flow_head.conv2.weight")                                     # (2, 256, 3, 3, 3)
         put("fh2", w2.permute(2, 3, 4, 0, 1).reshape(54, 256, 1, 1, 1).contiguous(), None, [256])
         self.fh2_bias = g("flow_head.conv2.bias").contiguous()
-        put("m1", g("mask_2d.0.weight"), g("mask_2d.0.bias"), [128])
-        put("m2", g("mask_2d.2.weight"), g("mask_2d.2.bias"), [256])
+        # upsampling-mask head: mask_2d (Conv2d 3x3 + 1x1 -> 144, ppmtereo_update.py:910-914) or, with use_convex_3d=True,
+        # mask_3d (Conv3d 3x3x3 + 1x1x1 -> 432, :903-908)
+        self.convex_3d = "mask_3d.0.weight" in sd
+        mk = "mask_3d." if self.convex_3d else "mask_2d."
+        put("m1", g(mk + "0.weight"), g(mk + "0.bias"), [128])
+        put("m2", g(mk + "2.weight"), g(mk + "2.bias"), [256])
+        self.mask_ch = 432 if self.convex_3d else 144
         self.beta = g("aggregator.beta").contiguous()
         self.attn = None
         if "time_attn.temporal_fc.weight" in sd:
@@ -286,7 +291,7 @@ class ScaleEngine:
             self.KVWS = f32(4 * T * 8 * 48 * 49)
         self.Hb = [sp(128), sp(128), sp(128)]
         self.ZT, self.RT, self.RH, self.FH1, self.M1 = sp(128), sp(128), sp(128), sp(256), sp(256)
-        self.Z, self.MASK, self.FLOW, self.QK = f32(P, 128), f32(P, 144), f32(P, 2), f32(P, 256)
+        self.Z, self.MASK, self.FLOW, self.QK = f32(P, 128), f32(P, pk.mask_ch), f32(P, 2), f32(P, 256)
         self.DFLOW = f32(P, 4)
         if pk.hoist:
             self.PRE = {k: torch.empty(P, m, dtype=torch.float32, device=device) for k, m in
@@ -434,8 +439,8 @@ class ScaleEngine:
                                       **pre("q" + n)))
         o["fh1"] = self._conv("fh1", [H[0].view()], (3, 3, 3), E(act=L.ACT_RELU, n_valid=256, out_sp=self.FH1.view()))
         o["fh2"] = self._conv("fh2", [self.FH1.view()], k1, E(n_valid=54, out_f32=self.FH2Y, out_f32_ld=64))
-        o["m1"] = self._conv("m1", [H[0].view()], k3, E(act=L.ACT_RELU, n_valid=256, out_sp=self.M1.view()))
-        o["m2"] = self._conv("m2", [self.M1.view()], k1, E(scale=0.25, n_valid=144, out_f32=self.MASK, out_f32_ld=144))
+        o["m1"] = self._conv("m1", [H[0].view()], (3, 3, 3) if self.pk.convex_3d else k3, E(act=L.ACT_RELU, n_valid=256, out_sp=self.M1.view()))
+        o["m2"] = self._conv("m2", [self.M1.view()], k1, E(scale=0.25, n_valid=self.pk.mask_ch, out_f32=self.MASK, out_f32_ld=self.pk.mask_ch))
 
     # ------------------------------------------------------------------ loading state (reference NCHW tensors)
     def _s(self):
@@ -518,8 +523,9 @@ class ScaleEngine:
         return out
 
     def get_mask(self):
-        out = torch.empty(self.T, 144, self.h, self.w, dtype=torch.float32, device=self.dev)
-        L.check(self.lib.ppms_nhwc_to_nchw(self.MASK.data_ptr(), 144, out.data_ptr(), self.T, 144, self.n, self._s()))
+        mc = self.pk.mask_ch
+        out = torch.empty(self.T, mc, self.h, self.w, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.ppms_nhwc_to_nchw(self.MASK.data_ptr(), mc, out.data_ptr(), self.T, mc, self.n, self._s()))
         return out
 
     def get_unc(self):
@@ -668,8 +674,8 @@ class ScaleEngine:
         self._join()
 
     def upsample(self) -> torch.Tensor:
-        L.check(self.lib.ppms_convex_upsample(self.FLOW.data_ptr(), self.MASK.data_ptr(), 144, self.FLOW_OUT.data_ptr(), self.T, self.h, self.w,
-                                              self._s()))
+        fn = self.lib.ppms_convex_upsample_3d if self.pk.convex_3d else self.lib.ppms_convex_upsample          # ppmstereo.py:573-576
+        L.check(fn(self.FLOW.data_ptr(), self.MASK.data_ptr(), self.pk.mask_ch, self.FLOW_OUT.data_ptr(), self.T, self.h, self.w, self._s()))
         return self.FLOW_OUT
 
     def iterate(self):

@@ -8,6 +8,7 @@ the three update blocks / q-k projections under the reference's attribute names 
 """
 from __future__ import annotations
 
+import math
 import warnings
 from typing import Dict, List, Optional
 
@@ -61,6 +62,25 @@ def _run_iterations(eng, iters: int, isc: int, t: int, h: int, w: int, predictio
     return flow_out
 
 
+def convex_upsample_3d(flow: torch.Tensor, mask: torch.Tensor, rate: int, T: int) -> torch.Tensor:
+    """PPMStereo.convex_upsample_3d, ppmstereo.py:199-228 (NCHW in, NCHW out; one window of T frames, batch 1)."""
+    if rate != 4:
+        raise NotImplementedError("convex_upsample_3d: rate 4 only")
+    L.require_gpu(flow, mask)
+    N, _, H, W = flow.shape
+    if N != T:
+        raise NotImplementedError("convex_upsample_3d: batch size 1 (N == T)")
+    lib, s = L.load(), L.stream_ptr()
+    f = torch.empty(N * H * W, 2, dtype=torch.float32, device=flow.device)
+    m = torch.empty(N * H * W, 432, dtype=torch.float32, device=flow.device)
+    fc, mc = flow.contiguous().float(), mask.contiguous().float()
+    L.check(lib.ppms_nchw_to_nhwc(fc.data_ptr(), f.data_ptr(), 2, N, 2, H * W, s))
+    L.check(lib.ppms_nchw_to_nhwc(mc.data_ptr(), m.data_ptr(), 432, N, 432, H * W, s))
+    out = torch.empty(N, 2, 4 * H, 4 * W, dtype=torch.float32, device=flow.device)
+    L.check(lib.ppms_convex_upsample_3d(f.data_ptr(), m.data_ptr(), 432, out.data_ptr(), T, H, W, s))
+    return out
+
+
 def forward_update_block(self, image1, update_block: SequenceUpdateBlock3D, corr_fn: CorrBlock1D, flow: torch.Tensor, net: torch.Tensor,
                          inp: torch.Tensor, motion_hidden_state: Optional[torch.Tensor], attn_block: Attention_qk, predictions: List,
                          uncertainties: List, iters: int, interp_scale: float, t: int):
@@ -99,22 +119,27 @@ class PPMStereoHotPath(nn.Module):
                  attention_type: Optional[str] = "self_stereo_temporal_update_time_update_space", use_3d_update_block: bool = True,
                  different_update_blocks: bool = True, use_convex_3d: bool = False, init_flow: bool = False):
         super().__init__()
-        if not (use_3d_update_block and different_update_blocks) or use_convex_3d or init_flow:
-            raise NotImplementedError("supported configuration: models/ppm_stereo_model.py:27-33 "
-                                      "(use_3d_update_block=True, different_update_blocks=True, use_convex_3d=False, init_flow=False)")
+        if not (use_3d_update_block and different_update_blocks) or init_flow:
+            raise NotImplementedError("supported configurations: models/ppm_stereo_model.py:27-33 (use_3d_update_block=True, "
+                                      "different_update_blocks=True, init_flow=False) with use_convex_3d False or True (train.py / test.py default)")
         self.hidden_dim = self.context_dim = 128
         self.mixed_precision = mixed_precision      # the engine's precision is fixed: fp32-accurate convs, bf16 attention
-        self.use_convex_3d = False
+        self.use_convex_3d = bool(use_convex_3d)
         self.num_frames = num_frames
         self.att = nn.ModuleList([Attention_qk(num_heads=1, dim_head=128) for _ in range(3)])
-        self.update_block08 = SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4)
-        self.update_block16 = SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4, attention_type=attention_type)
-        self.update_block04 = SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4)
+        c3 = self.use_convex_3d
+        self.update_block08 = SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4, use_convex_3d=c3)
+        self.update_block16 = SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4, use_convex_3d=c3, attention_type=attention_type)
+        self.update_block04 = SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4, use_convex_3d=c3)
 
     forward_update_block = forward_update_block
 
     def convex_upsample(self, flow, mask, rate: int = 4):
         return convex_upsample(flow, mask, rate)
+
+    def convex_upsample_3d(self, flow, mask, rate: int, T: int):
+        """PPMStereo.convex_upsample_3d, ppmstereo.py:199-228: flow (b*T,2,H,W), mask (b*T,432,H,W) -> (b*T,2,4H,4W); b = 1."""
+        return convex_upsample_3d(flow, mask, rate, T)
 
     def zero_init(self, fmap: torch.Tensor) -> torch.Tensor:
         """ppmstereo.py:231-236."""
@@ -169,6 +194,151 @@ class PPMStereoHotPath(nn.Module):
                 fo = _run_iterations(eng, n_it, isc, tl, h, w, preds, uncs, "all" if not test_mode else ("last" if s_ == 4 else "none"))
                 prev = eng
             return preds[-1], uncs[-1]
+
+
+def position_encoding_sine(d_model: int, h: int, w: int) -> torch.Tensor:
+    """PositionEncodingSine (temp_bug_fix=True), models/core/attention.py:23-64 -> (d_model, h, w); host table, same torch
+    op sequence as the reference (built once per geometry)."""
+    pe = torch.zeros((d_model, h, w))
+    y_position = torch.ones((h, w)).cumsum(0).float().unsqueeze(0)
+    x_position = torch.ones((h, w)).cumsum(1).float().unsqueeze(0)
+    div_term = torch.exp(torch.arange(0, d_model // 2, 2).float() * (-math.log(10000.0) / (d_model // 2)))[:, None, None]
+    pe[0::4, :, :] = torch.sin(x_position * div_term)
+    pe[1::4, :, :] = torch.cos(x_position * div_term)
+    pe[2::4, :, :] = torch.sin(y_position * div_term)
+    pe[3::4, :, :] = torch.cos(y_position * div_term)
+    return pe
+
+
+class InputPadder:
+    """models/core/utils/utils.py:19-44 (mode "sintel"): replicate-pads H, W to multiples of ``divis_by``, split evenly."""
+
+    def __init__(self, dims, mode: str = "sintel", divis_by: int = 8):
+        self.ht, self.wd = dims[-2:]
+        pad_ht = (((self.ht // divis_by) + 1) * divis_by - self.ht) % divis_by
+        pad_wd = (((self.wd // divis_by) + 1) * divis_by - self.wd) % divis_by
+        if mode == "sintel":
+            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
+        else:
+            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+
+    def pad(self, *inputs):
+        assert all((x.ndim == 4) for x in inputs)
+        return [torch.nn.functional.pad(x, self._pad, mode="replicate") for x in inputs]
+
+    def unpad(self, x):
+        assert x.ndim == 4
+        ht, wd = x.shape[-2:]
+        c = [self._pad[2], ht - self._pad[3], self._pad[0], wd - self._pad[1]]
+        return x[..., c[0]:c[1], c[2]:c[3]]
+
+
+class PPMStereo(PPMStereoHotPath):
+    """``models/core/ppmstereo.py:PPMStereo`` from the encoder outputs on: same constructor arguments, ``forward`` (:601-804)
+    and ``forward_batch_test`` (:238-320).  The encoders are outside the hot path: ``fnet`` /
+    ``cnet`` are modules the caller plugs in (the reference's ``BasicEncoder`` / ``Feature``, or any callable with the same
+    contract: ``fnet([im1, im2]) -> (fmap1, fmap2)`` (BT,256,H/4,W/4), ``cnet(im1) -> (c4, c8, c16)`` with 256 channels);
+    ``sst`` stands for ``forward_sst_block`` (:322-395) and defaults to its ``attention_type=None`` behaviour (positional
+    encoding only).  Everything between the encoders and the returned disparity runs on the gfx950 kernels."""
+
+    def __init__(self, *args, fnet=None, cnet=None, sst=None, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.fnet, self.cnet, self.sst = fnet, cnet, sst
+        self.dim = 256
+        self._pe_cache: Dict[tuple, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ pre-loop glue (ppmstereo.py:620-682)
+    def _pe(self, h: int, w: int, device) -> torch.Tensor:
+        key = (h, w, str(device))
+        if key not in self._pe_cache:
+            self._pe_cache[key] = position_encoding_sine(self.dim, h, w).to(device).contiguous()
+        return self._pe_cache[key]
+
+    def pre_loop(self, fmap1: torch.Tensor, fmap2: torch.Tensor, c4: torch.Tensor, c8: torch.Tensor, c16: torch.Tensor, t: int):
+        """fmap (BT,256,h,w) at 1/4, context features at 1/4, 1/8, 1/16 -> the dict ``cascade`` consumes."""
+        L.require_gpu(fmap1, fmap2, c4, c8, c16)
+        lib, st = L.load(), L.stream_ptr
+        N, C, h, w = fmap1.shape
+        if C != 256 or h % 4 or w % 4:
+            raise RuntimeError("pre_loop: 256-channel 1/4-resolution features with h, w multiples of 4 expected")
+        dev = fmap1.device
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        fm = [fmap1.contiguous().float(), fmap2.contiguous().float()]
+        feats: Dict[str, torch.Tensor] = {"f1_4": fm[0], "f2_4": fm[1]}
+
+        def mix(f, c, tag):                                   # net = tanh(avg), inp = relu(avg) of the two 128-channel halves
+            c = c.contiguous().float()
+            net, inp = f32(N, 128, f.shape[2], f.shape[3]), f32(N, 128, f.shape[2], f.shape[3])
+            L.check(lib.ppms_ctx_mix(f.data_ptr(), c.data_ptr(), net.data_ptr(), inp.data_ptr(), N, f.shape[2] * f.shape[3], st()))
+            feats["net_" + tag], feats["inp_" + tag] = net, inp
+
+        mix(fm[0], c4, "4")
+        h16, w16, h8, w8 = h // 4, w // 4, h // 2, w // 2
+        f16 = []
+        for f in fm:                                           # :649-652 avg_pool 4x4, then the SST block
+            p = f32(N, C, h16, w16)
+            L.check(lib.ppms_avgpool(f.data_ptr(), p.data_ptr(), N * C, h, w, 4, st()))
+            f16.append(p)
+        if self.sst is not None:
+            f16 = list(self.sst(f16[0], f16[1], t))
+        else:                                                  # forward_sst_block with attention_type=None: + positional encoding
+            pe = self._pe(h16, w16, dev)
+            for p in f16:
+                L.check(lib.ppms_axpby(p.data_ptr(), pe.data_ptr(), p.data_ptr(), 1.0, 1.0, pe.numel(), p.numel(), st()))
+        feats["f1_16"], feats["f2_16"] = f16
+        mix(f16[0], c16, "16")
+        for i, f in enumerate(fm):                             # :666-671 (avg_pool2 + interp(1/16)) / 2
+            p = f32(N, C, h8, w8)
+            L.check(lib.ppms_avgpool(f.data_ptr(), p.data_ptr(), N * C, h, w, 2, st()))
+            q = bilinear(f16[i], (h8, w8), True)
+            L.check(lib.ppms_axpby(p.data_ptr(), q.data_ptr(), p.data_ptr(), 0.5, 0.5, p.numel(), p.numel(), st()))
+            feats[f"f{i + 1}_8"] = p
+        mix(feats["f1_8"], c8, "8")
+        return feats
+
+    @torch.no_grad()
+    def forward(self, image1: torch.Tensor, image2: torch.Tensor, flow_init=None, iters: int = 10, test_mode: bool = False):
+        """PPMStereo.forward (ppmstereo.py:601-804): image (b, T, 3, H, W) in [0, 255], H, W multiples of 32, b = 1.
+        test_mode: (flow_up, uncertainty), each (b, T, 1, H, W); else (predictions (D, b, T, 1, H, W), uncertainties)."""
+        if flow_init is not None:
+            raise NotImplementedError("flow_init: the reference's own path for it reads undefined state (ppmstereo.py:691-693, 763)")
+        if self.fnet is None or self.cnet is None:
+            raise RuntimeError("PPMStereo.forward needs the encoders: pass fnet= / cnet= (outside the hot path, SURVEY.md section 8 f3-f5)")
+        b, T, c, h, w = image1.shape
+        if b != 1:
+            raise NotImplementedError("PPMStereo.forward: batch size 1 (inference)")
+        with torch.cuda.device(image1.device):
+            im1 = (2 * (image1 / 255.0) - 1.0).contiguous().reshape(b * T, c, h, w)
+            im2 = (2 * (image2 / 255.0) - 1.0).contiguous().reshape(b * T, c, h, w)
+            fmap1, fmap2 = self.fnet([im1, im2])
+            c4, c8, c16 = self.cnet(im1)
+            feats = self.pre_loop(fmap1, fmap2, c4, c8, c16, T)
+            preds, uncs = [], []
+            self.cascade(feats, iters, T, preds, uncs, test_mode=test_mode)
+            if test_mode:
+                return preds[-1][None], uncs[-1][None]
+            return torch.stack(preds)[:, None], torch.stack(uncs)[:, None]
+
+    @torch.no_grad()
+    def forward_batch_test(self, batch_dict: Dict, kernel_size: int = 20, iters: int = 20, device=None):
+        """PPMStereo.forward_batch_test (ppmstereo.py:238-320): batch_dict["stereo_video"] (N, 2, 3, H, W) on the host;
+        per window: InputPadder(divis_by=32), one host->device copy, forward(test_mode=True), unpad, one device->host copy;
+        windows of ``kernel_size`` frames every ``kernel_size // 2``, centre frames kept (:296-307).  Windows whose output the
+        reference computes and then drops are not run.  Returns {"disparity", "uncertainties"}: (N, 1, H, W) CPU tensors."""
+        video = batch_dict["stereo_video"]
+        num_ims = len(video)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        disp_preds, uncertainties = [], []
+        for start, stop, keep_from, keep_to in window_plan(num_ims, kernel_size):
+            left, right = video[start:stop, 0], video[start:stop, 1]
+            padder = InputPadder(left.shape, divis_by=32)
+            left, right = padder.pad(left, right)
+            d, u = self.forward(left[None].to(dev), right[None].to(dev), iters=iters, test_mode=True)      # host -> device: once per window
+            d = padder.unpad(d[0])[:, None].cpu()                                                           # device -> host
+            u = padder.unpad(u[0])[:, None].cpu()
+            disp_preds.append(d[keep_from:keep_to])
+            uncertainties.append(u[keep_from:keep_to])
+        return {"disparity": torch.cat(disp_preds).squeeze(1).abs()[:, :1], "uncertainties": torch.cat(uncertainties).squeeze(1).abs()[:, :1]}
 
 
 def window_plan(num_ims: int, kernel_size: int = 20):

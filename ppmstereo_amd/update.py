@@ -147,22 +147,24 @@ class Attention_qk(nn.Module):
 
 
 class SequenceUpdateBlock3D(nn.Module):
-    """ppmtereo_update.py:880-1003 (use_convex_3d=False)."""
+    """ppmtereo_update.py:880-1003; use_convex_3d selects the mask_3d head (:903-908, 993-996) instead of mask_2d."""
 
     def __init__(self, hidden_dim, cor_planes, mask_size=8, use_convex_3d=False, attention_type=None):
         super().__init__()
         if hidden_dim != 128 or cor_planes != 36 or mask_size != 4:
             raise NotImplementedError("SequenceUpdateBlock3D: hidden_dim=128, cor_planes=36, mask_size=4 (the PPMStereo configuration)")
-        if use_convex_3d:
-            raise NotImplementedError("use_convex_3d=True (mask_3d / convex_upsample_3d) is a 'next' row, SURVEY.md section 8f-2")
         self.encoder = _MotionEncoder(cor_planes)
         self.gru = _GRU(hidden_dim, 256 + hidden_dim)
         self.flow_head = _FlowHead(hidden_dim, 256)
         self.uncertainty = nn.Sequential(nn.Conv2d(hidden_dim + 128, hidden_dim, 3, padding=1), nn.ReLU(inplace=True),
                                          nn.Conv2d(hidden_dim, 1, 1), nn.Sigmoid())
-        self.use_convex_3d = False
-        self.mask_2d = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim + 128, 3, padding=1), nn.ReLU(inplace=True),
-                                     nn.Conv2d(hidden_dim + 128, (mask_size ** 2) * 9, 1))
+        self.use_convex_3d = bool(use_convex_3d)
+        if self.use_convex_3d:                               # ppmtereo_update.py:903-908
+            self.mask_3d = nn.Sequential(nn.Conv3d(hidden_dim, hidden_dim + 128, 3, padding=1), nn.ReLU(inplace=True),
+                                         nn.Conv3d(hidden_dim + 128, (mask_size ** 2) * 27, 1, padding=0))
+        else:                                                # :910-914
+            self.mask_2d = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim + 128, 3, padding=1), nn.ReLU(inplace=True),
+                                         nn.Conv2d(hidden_dim + 128, (mask_size ** 2) * 9, 1))
         self.attention_type = attention_type
         if attention_type is not None:
             if "update_time" in attention_type:

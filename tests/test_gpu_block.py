@@ -117,6 +117,66 @@ def test_cascade_golden(model):
     gd.check("uncertainty", unc[None], 1e-3)
 
 
+def test_convex_3d_variant_vs_reference():
+    """use_convex_3d=True (the default of the reference's train.py / test.py): mask_3d head (Conv3d 3x3x3 + 1x1x1 -> 432,
+    ppmtereo_update.py:903-908, 993-996) and convex_upsample_3d (ppmstereo.py:199-228) against the reference's outputs
+    (tools/gen_golden.py G9; unfoldNd restated there) and the oracle."""
+    from ppmstereo_amd.corr import CorrBlock1D
+    from ppmstereo_amd.ppmstereo import PPMStereoHotPath, convex_upsample_3d
+    W3 = Wm.hot_path_weights(use_convex_3d=True)
+    m3 = PPMStereoHotPath(use_convex_3d=True).load_hot_path_weights(W3).to(DEV).eval()
+    fl, mk = hash_normal((4, 2, 6, 10), 33), hash_normal((4, 432, 6, 10), 34)
+    gd = Golden("convex_upsample_3d")
+    gd.check("out", convex_upsample_3d(g(fl), g(mk), 4, 4), 5e-6)
+    gd.check("out_T1", m3.convex_upsample_3d(g(fl[:1]), g(mk[:1]), 4, 1), 5e-6)
+    T, h, w = 5, 8, 32
+    d = synth_scale_inputs(T, h, w, seed=41, with_mhs=False)
+    corr = hash_normal((T, 36, h, w), 42)
+    mf, _, _ = O.get_motion_and_value(W3["update_block04"], d["flow"], corr, None, d["inp"])
+    mfg = mf + 0.3 * hash_normal((T, 128, h, w), 43)
+    net, mask, dflow = m3.update_block04(g(d["net"]), g(d["inp"]), g(mf), g(mfg), t=T)
+    assert mask.shape[1] == 432
+    gd = Golden("update_block04_c3d_pieces")
+    gd.check("net", net, 1e-4), gd.check("mask", mask, 2e-4), gd.check("dflow", dflow, 1e-4)
+    for name, tag, ai, T, h, w, iters, isc, mh in (("fub04_c3d", "update_block04", 2, 5, 8, 32, 2, 1, True),
+                                                  ("fub16_c3d", "update_block16", 0, 3, 8, 32, 2, 4, False)):
+        d = synth_scale_inputs(T, h, w, seed=50 + ai + 10 * T, with_mhs=mh)
+        preds, uncs, rp, ru = [], [], [], []
+        fo, net, mhs = m3.forward_update_block(None, getattr(m3, tag), CorrBlock1D(g(d["fmap1"]), g(d["fmap2"])), g(d["flow"]), g(d["net"]),
+                                               g(d["inp"]), g(d["mhs"]), m3.att[ai], preds, uncs, iters, isc, T)
+        rfo, rnet, rmhs = O.forward_update_block(W3[tag], W3[f"att.{ai}"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"], d["inp"],
+                                                 d["mhs"], iters, isc, T, tag == "update_block16", rp, ru)
+        assert (fo[:, 0].cpu() - rfo[:, 0]).abs().mean().item() < 2e-4
+        assert maxdiff(fo, rfo) < 1e-3 and maxdiff(net, rnet) < 2e-3 and maxdiff(mhs, rmhs) < 5e-4
+        gd = Golden(name)
+        gd.check("flow_out", fo, 1e-3), gd.check("net", net, 2e-3), gd.check("mhs", mhs, 5e-4)
+        gd.check("preds", torch.stack(preds), 1e-3 * isc), gd.check("uncs", torch.stack(uncs), 2e-4)
+
+
+def test_forward_batch_test_vs_reference():
+    """PPMStereo.forward_batch_test (padder, sliding windows, centre-frame stitching, H->D / D->H per window) against the
+    REFERENCE's own forward_batch_test output (tests/golden/fbt_*.npz, tools/gen_golden.py G8) with stub encoders: 25 frames
+    of 60x250 -> padded 64x256, kernel_size 20 -> windows [0,20) [10,25), kept frames 0-14 / 15-24; and the single-window
+    branch (7 frames < kernel_size)."""
+    from ppmstereo_amd.ppmstereo import PPMStereo
+    from stub_encoders import StubCNet, StubFNet, frame_video
+    m = PPMStereo(fnet=StubFNet(), cnet=StubCNet()).load_hot_path_weights(W).to(DEV).eval()
+    for name, N in (("fbt_N25_k20", 25), ("fbt_N7_k20", 7)):
+        out = m.forward_batch_test({"stereo_video": frame_video(N, 60, 250)}, kernel_size=20, iters=4)
+        assert tuple(out["disparity"].shape) == (N, 1, 60, 250) and not out["disparity"].is_cuda
+        gd = Golden(name)
+        k, step = gd.keys["disparity"]
+        err = abs(out["disparity"].float().numpy().reshape(-1)[::step] - gd.raw("disparity"))
+        print(f"{name}: EPE vs reference {err.mean():.3e} px, max {err.max():.3e} px")
+        assert err.mean() < 6e-4 and err.max() < 5e-3, (name, err.mean(), err.max())
+        gd.check("uncertainties", out["uncertainties"], 1e-3)
+    # forward() without test_mode returns every prediction of the cascade (ppmstereo.py:795-810)
+    v = frame_video(3, 64, 256).to(DEV)
+    preds, uncs = m.forward(v[None, :, 0], v[None, :, 1], iters=4, test_mode=False)
+    last, _ = m.forward(v[None, :, 0], v[None, :, 1], iters=4, test_mode=True)
+    assert tuple(preds.shape) == (8, 1, 3, 1, 64, 256) and torch.equal(preds[-1], last)
+
+
 def test_T1_gives_nan_like_reference(model):
     from ppmstereo_amd.corr import CorrBlock1D
     d = synth_scale_inputs(1, 8, 32, seed=81)

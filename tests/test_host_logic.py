@@ -112,18 +112,21 @@ def test_packing_cout_map_routes_groups_to_aligned_blocks():
     assert torch.allclose(bias[128:192], bs[126:]) and torch.allclose(bias[:126], bs[:126])
 
 
-def test_update_block_state_dict_is_the_reference_layout():
+@pytest.mark.parametrize("c3d", [False, True])
+def test_update_block_state_dict_is_the_reference_layout(c3d):
     from ppmstereo_amd.ppmstereo import PPMStereoHotPath
-    m = PPMStereoHotPath()
+    m = PPMStereoHotPath(use_convex_3d=c3d)
     for tag, attn in (("update_block16", True), ("update_block08", False), ("update_block04", False)):
         sd = getattr(m, tag).state_dict()
-        want = Wm.update_block_param_shapes(attn)
+        want = Wm.update_block_param_shapes(attn, c3d)
+        assert ("mask_3d.0.weight" in sd) == c3d and ("mask_2d.0.weight" in sd) != c3d
         assert list(sd.keys()) == list(want.keys()), "same parameter names in the same (registration) order as the reference module"
         for k, shape in want.items():
             assert tuple(sd[k].shape) == tuple(shape), k
     assert tuple(m.att[0].state_dict()["to_qk.weight"].shape) == (256, 128, 1, 1)
     n = sum(p.numel() for p in m.update_block16.parameters())
-    assert abs(n - 9.39e6) < 0.01e6                       # update_block16 has 9.39 M parameters
+    if not c3d:
+        assert abs(n - 9.39e6) < 0.01e6                   # update_block16 has 9.39 M parameters (mask_2d variant)
 
 
 def test_unsupported_configurations_raise():
