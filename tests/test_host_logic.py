@@ -133,9 +133,12 @@ def test_unsupported_configurations_raise():
     from ppmstereo_amd.ppmstereo import PPMStereoHotPath
     from ppmstereo_amd.update import SequenceUpdateBlock3D
     with pytest.raises(NotImplementedError):
-        PPMStereoHotPath(use_convex_3d=True)
+        PPMStereoHotPath(use_3d_update_block=False)           # the 2-D block's signatures do not match the call sites (SURVEY hazard 7)
     with pytest.raises(NotImplementedError):
-        SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4, use_convex_3d=True)
+        PPMStereoHotPath(init_flow=True)                      # calls a non-existent update_block04.mask in the reference
+    with pytest.raises(NotImplementedError):
+        SequenceUpdateBlock3D(hidden_dim=96, cor_planes=36, mask_size=4)
+    assert hasattr(SequenceUpdateBlock3D(hidden_dim=128, cor_planes=36, mask_size=4, use_convex_3d=True), "mask_3d")
 
 
 def test_ops_refuse_cpu_tensors_without_touching_a_gpu():
