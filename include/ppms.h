@@ -24,7 +24,7 @@ extern "C" {
 #define PPMS_ELAUNCH (-2)  /* HIP launch error */
 #define PPMS_ENODEV (-3)   /* no gfx950 device */
 
-#define PPMS_ABI_VERSION 1
+#define PPMS_ABI_VERSION 2
 
 int ppms_version(void);
 const char* ppms_last_error(void);
@@ -90,6 +90,11 @@ typedef struct ppms_conv {
     int32_t kt, kh, kw;           /* odd kernel extents, "same" zero padding                       */
     int32_t M;                    /* padded couts, multiple of 64                                  */
     int32_t m_split;              /* couts >= m_split use epi[1] with cout - m_split (multiple of 64; >= M: unused) */
+    int32_t t_halo;               /* frames that exist (and may be read by temporal taps) before frame 0 and after frame T-1 of
+                                   * every input segment: 0 = zero padding at both ends (one GPU holds the whole window); > 0 when
+                                   * the window's frames are sharded over GPUs and the neighbours' boundary frames sit in halo
+                                   * slabs around this rank's T frames (ppmstereo_amd/dist.py).  Outputs cover [0, T) only. */
+    int32_t reserved;
     ppms_epilogue epi[2];
 } ppms_conv;
 
@@ -155,7 +160,7 @@ int ppms_sp_to_f32(ppms_sp src, float* dst, int dst_ld, int64_t pixels, void* st
 /* Tail of a few-output-channel conv evaluated as a 1x1 GEMM to (taps*cout) channels followed by a shifted sum:
  * out[p][c] = bias[c] + sum_tap y[p + d(tap)][tap*cout + c] (zero padded).  FlowHead3D.conv2, ppmtereo_update.py:674. */
 int ppms_tap_gather_sum(const float* y, int y_ld, const float* bias, float* out, int out_ld, int cout, int kt, int kh, int kw,
-                        int T, int H, int W, void* stream);
+                        int T, int H, int W, int t_halo, void* stream);    /* t_halo: frames of y readable beyond [0, T) (see ppms_conv) */
 /* flow = flow + delta_flow (ppmstereo.py:571); flow: fp32 [pixel][2], dflow: fp32 [pixel][dflow_ld] */
 int ppms_flow_add(float* flow_nhwc, const float* dflow, int dflow_ld, int64_t pixels, void* stream);
 /* PPMStereo.convex_upsample, ppmstereo.py:185-197.  flow: fp32 [pixel][2]; mask: fp32 [pixel][mask_ld] (144 used);
@@ -164,7 +169,7 @@ int ppms_convex_upsample(const float* flow_nhwc, const float* mask, int mask_ld,
 /* PPMStereo.convex_upsample_3d, ppmstereo.py:199-228 (use_convex_3d=True): 27 spatio-temporal neighbours of one window of T
  * frames; mask: fp32 [pixel][mask_ld] (432 = 27 * 16 used, channel 16 k + 4 i + j, k = (kt*3 + ky)*3 + kx);
  * out: fp32 NCHW (T,2,4H,4W).  unfoldNd (absent third-party module) restated from its published semantics (zero padding). */
-int ppms_convex_upsample_3d(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int T, int H, int W, void* stream);
+int ppms_convex_upsample_3d(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int T, int H, int W, int t_halo, void* stream);
 /* F.interpolate(mode="bilinear") on NCHW fp32, both align_corners modes (ppmstereo.py:578,580-587; utils.py:10-16);
  * out = mul * interp(src). */
 int ppms_bilinear(const float* src, float* dst, int N, int C, int H, int W, int OH, int OW, int align_corners, float mul, void* stream);
@@ -185,6 +190,10 @@ int ppms_ctx_mix(const float* fmap, const float* ctx, float* net, float* inp, in
 /* PPMStereo.compute_qk_similarity, ppmstereo.py:397-423.  q,k: fp32 [T][H*W][ld] channel-last (128 channels);
  * pooled: workspace fp32 [2][T][(H/4)*(W/4)]; sim: fp32 [T][T], sim[i][j] = cos(kbar_i, qbar_j). */
 int ppms_qk_similarity(const float* q, const float* k, int ld, float* pooled, float* sim, int T, int H, int W, void* stream);
+/* its two halves, for a window whose frames are sharded over GPUs: pooled descriptors of this rank's frames
+ * (pooled: fp32 [2][T][(H/4)*(W/4)]), then -- after an all-gather of the descriptors -- the T x T cosine matrix */
+int ppms_qk_pool(const float* q, const float* k, int ld, float* pooled, int T, int H, int W, void* stream);
+int ppms_qk_cos(const float* pooled, float* sim, int T, int cells, void* stream);
 /* QAM score + top-k pick + usage counter, ppmstereo.py:501-513, and the normalised play scores of :532-533.
  * conf_partial: output of ppms_unc_tail; strive: fp32 [T][T] in/out; sel: int32 [T][5] ascending frame ids;
  * shat: fp32 [T][5]; score (optional): fp32 [T][T]. */

@@ -32,7 +32,7 @@ class Conv(C.Structure):
     _fields_ = [("seg", SP * 2), ("nseg", C.c_int32), ("w", c_void_p), ("bias", c_void_p),
                 ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("kt", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
-                ("M", C.c_int32), ("m_split", C.c_int32), ("epi", Epilogue * 2)]
+                ("M", C.c_int32), ("m_split", C.c_int32), ("t_halo", C.c_int32), ("reserved", C.c_int32), ("epi", Epilogue * 2)]
 
 
 class ChainLayer(C.Structure):
@@ -71,16 +71,18 @@ _SIGS = {
     "ppms_nhwc_to_nchw": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ppms_f32_to_sp": (c_int, [c_void_p, c_int, SP, c_int64, c_void_p]),
     "ppms_sp_to_f32": (c_int, [SP, c_void_p, c_int, c_int64, c_void_p]),
-    "ppms_tap_gather_sum": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ppms_tap_gather_sum": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_flow_add": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "ppms_convex_upsample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "ppms_convex_upsample_3d": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppms_convex_upsample_3d": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_bilinear": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ppms_sp_resize_blend": (c_int, [SP, SP, c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p]),
     "ppms_avgpool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64, c_int64, c_void_p]),
     "ppms_ctx_mix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_qk_similarity": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppms_qk_pool": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ppms_qk_cos": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_qam_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ppms_attn_prep_q": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_attn_prep_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -115,7 +117,7 @@ def load() -> C.CDLL:
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.ppms_version() != 1:
+    if lib.ppms_version() != 2:
         raise RuntimeError("ppmstereo_amd: libppms.so ABI version mismatch")
     a, b, c = c_int(), c_int(), c_int()
     lib.ppms_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
@@ -148,27 +150,37 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 class SPTensor:
-    """Owner of a split-bf16 channel-last activation: data (2, P, ld) bf16; views select a channel range."""
+    """Owner of a split-bf16 channel-last activation: data (2, before + P + after, ld) bf16; views select a channel range of
+    the P "own" pixels.  before / after: extra pixel rows around them -- the temporal halo slabs of a frame-sharded window
+    (ppmstereo_amd/dist.py) or, for gathered tensors, the other ranks' frames."""
 
-    def __init__(self, pixels: int, channels: int, device, zero: bool = True):
+    def __init__(self, pixels: int, channels: int, device, zero: bool = True, before: int = 0, after: int = 0):
         alloc = torch.zeros if zero else torch.empty
-        self.data = alloc((2, pixels, channels), dtype=torch.bfloat16, device=device)
-        self.pixels, self.channels = pixels, channels
+        self.data = alloc((2, before + pixels + after, channels), dtype=torch.bfloat16, device=device)
+        self.pixels, self.channels, self.before, self.after = pixels, channels, before, after
 
-    def view(self, c0: int = 0, c: Optional[int] = None) -> SP:
+    def view(self, c0: int = 0, c: Optional[int] = None, all_rows: bool = False) -> SP:
+        """SP view of channels [c0, c0 + c) starting at the first own pixel (all_rows: at the first allocated row)."""
         c = self.channels - c0 if c is None else c
         assert 0 <= c0 and c0 + c <= self.channels
-        base = self.data.data_ptr()
-        plane = self.pixels * self.channels * 2
+        total = self.before + self.pixels + self.after
+        base = self.data.data_ptr() + (0 if all_rows else self.before) * self.channels * 2
+        plane = total * self.channels * 2
         return SP(base + c0 * 2, base + plane + c0 * 2, self.channels, c)
 
+    def own(self) -> torch.Tensor:
+        """(2, P, ld) view of the own pixels."""
+        return self.data[:, self.before:self.before + self.pixels]
+
     def to_f32(self, c0: int = 0, c: Optional[int] = None) -> torch.Tensor:
-        """(P, c) fp32 = hi + lo (torch ops; for tests and glue)."""
+        """(P, c) fp32 = hi + lo of the own pixels (torch ops; for tests and glue)."""
         c = self.channels - c0 if c is None else c
-        return self.data[0, :, c0:c0 + c].float() + self.data[1, :, c0:c0 + c].float()
+        d = self.own()
+        return d[0, :, c0:c0 + c].float() + d[1, :, c0:c0 + c].float()
 
     def set_f32(self, x: torch.Tensor, c0: int = 0) -> None:
         hi = x.to(torch.bfloat16)
         lo = (x - hi.float()).to(torch.bfloat16)
-        self.data[0, :, c0:c0 + x.shape[1]] = hi
-        self.data[1, :, c0:c0 + x.shape[1]] = lo
+        d = self.own()
+        d[0, :, c0:c0 + x.shape[1]] = hi
+        d[1, :, c0:c0 + x.shape[1]] = lo

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         const bf16_t* sh = (const bf16_t*)p.seg[s].hi;
         const bf16_t* sl = (const bf16_t*)p.seg[s].lo;
         const int ld = p.seg[s].ld;
-        const bool tok = (unsigned)(tf + dt) < (unsigned)T;
+        const bool tok = (unsigned)(tf + dt + p.t_halo) < (unsigned)(T + 2 * p.t_halo);
         const int shift = (dt * H + dy) * W;
 #pragma unroll
         for (int i = 0; i < MAXSLOT; ++i) {
@@ -163,8 +163,8 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     // k-step state of the step being LOADED: (trow, chunk, kx)
     // temporal taps that fall outside [0, T) for this tile's frame contribute zeros: skip their k-steps altogether
     // (T = 5: 24 % of the (5,1,1) GRU pass, 13 % of the 3x3x3 flow head).  Valid kz form one contiguous range.
-    const int kz0 = (ht - tf) > 0 ? (ht - tf) : 0;
-    const int kz1 = (ht + T - 1 - tf) < (p.kt - 1) ? (ht + T - 1 - tf) : (p.kt - 1);
+    const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
+    const int kz1 = (ht + T + p.t_halo - 1 - tf) < (p.kt - 1) ? (ht + T + p.t_halo - 1 - tf) : (p.kt - 1);
     const int rs_per_kz = ((g.ysweep || g.hs2) ? 1 : p.kh) * g.nchunk;
     const int rs_end = (kz1 + 1) * rs_per_kz;
     const int kstride = KG * g.nslice;        // row-step = trow * nchunk + chunk; K-group kg of slice s takes every kstride-th one
@@ -476,6 +476,7 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
     PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm2: null descriptor (host copy and device copy are both required)");
     PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm2: nseg=%d", d->nseg);
     PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm2: bad volume %dx%dx%d", d->T, d->H, d->W);
+    PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm2: t_halo=%d", d->t_halo);
     PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15, "conv_gemm2: kernel extents must be odd, kw <= 15");
     PPMS_REQUIRE(d->M > 0 && d->M % 64 == 0 && d->m_split % 64 == 0, "conv_gemm2: M=%d / m_split=%d not multiples of 64", d->M, d->m_split);
     PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm2: weights/bias missing");

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv* __restri
         const bf16_t* sh = (const bf16_t*)p.seg[sg].hi;
         const bf16_t* sl = (const bf16_t*)p.seg[sg].lo;
         const int ld = p.seg[sg].ld;
-        const bool tok = (unsigned)(tf + dt) < (unsigned)T;
+        const bool tok = (unsigned)(tf + dt + p.t_halo) < (unsigned)(T + 2 * p.t_halo);
         const int shift = (dt * H + dy) * W;
         char* d = sB + wave * 1024;
 #pragma unroll
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv* __restri
         for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
 
     // temporal taps outside [0, T) contribute zeros: skip them (contiguous kz range)
-    const int kz0 = (ht - tf) > 0 ? (ht - tf) : 0;
-    const int kz1 = (ht + T - 1 - tf) < (p.kt - 1) ? (ht + T - 1 - tf) : (p.kt - 1);
+    const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
+    const int kz1 = (ht + T + p.t_halo - 1 - tf) < (p.kt - 1) ? (ht + T + p.t_halo - 1 - tf) : (p.kt - 1);
     const int rows_per_kz = g.rdy ? p.kh : 1;
     int rs = kz0 * rows_per_kz * g.nchunk;                       // row-step index = rowstep * nchunk + chunk
     const int rs_end = (kz1 + 1) * rows_per_kz * g.nchunk;
@@ -296,6 +296,7 @@ extern "C" int ppms_conv_gemm3(const ppms_conv* d, const ppms_conv* dev_desc, vo
     PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15 && d->kh <= 15, "conv_gemm3: odd kernel extents <= 15");
     PPMS_REQUIRE(d->kw > 1 || d->kh > 1, "conv_gemm3: needs a spatial sweep axis (kw > 1 or kh > 1)");
     PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm3: weights/bias missing");
+    PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm3: t_halo=%d", d->t_halo);
     PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 31) / 512, "conv_gemm3: volume too large for 32-bit pixel offsets");
     int nchunk = 0;
     for (int s = 0; s < d->nseg; ++s) {

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
         const int c0 = (chunk - (sg ? g.n0 : 0)) * 16 + src_k8;
         const bf16_t* sp = sg ? sp1 : sp0;
         const int ld = sg ? ld1 : ld0;
-        const bool tok = (unsigned)(tf + dt) < (unsigned)T;
+        const bool tok = (unsigned)(tf + dt + p.t_halo) < (unsigned)(T + 2 * p.t_halo);
         const int shift = (dt * H + dy) * W;
         char* d = smem + buf * wbytes + wave * 1024;
 #pragma unroll
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
         for (int b = 0; b < NB; ++b) acc[a][b] = (f32x16){0};
 
     // temporal taps outside [0, T) contribute zeros: skip them (contiguous kz range)
-    const int kz0 = (ht - tf) > 0 ? (ht - tf) : 0;
-    const int kz1 = (ht + T - 1 - tf) < (p.kt - 1) ? (ht + T - 1 - tf) : (p.kt - 1);
+    const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
+    const int kz1 = (ht + T + p.t_halo - 1 - tf) < (p.kt - 1) ? (ht + T + p.t_halo - 1 - tf) : (p.kt - 1);
     const int rows_per_kz = g.rdy ? p.kh : 1;
     const int win0 = kz0 * rows_per_kz * g.nchunk;
     const int nwin = (kz1 + 1 - kz0) * rows_per_kz * g.nchunk;
@@ -421,6 +421,7 @@ extern "C" int ppms_conv_gemm4(const ppms_conv* d, const ppms_conv* dev_desc, in
     PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15 && d->kh <= 15, "conv_gemm4: odd kernel extents <= 15");
     PPMS_REQUIRE(d->kw > 1 || d->kh > 1, "conv_gemm4: needs a spatial sweep axis (kw > 1 or kh > 1)");
     PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm4: weights/bias missing");
+    PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm4: t_halo=%d", d->t_halo);
     PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 31) / 512, "conv_gemm4: volume too large for 32-bit pixel offsets");
     for (int s = 0; s < d->nseg; ++s) {
         PPMS_REQUIRE(d->seg[s].hi && d->seg[s].lo && d->seg[s].c > 0 && d->seg[s].c % 16 == 0 && d->seg[s].ld % 8 == 0,

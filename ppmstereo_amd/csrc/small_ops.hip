@@ -339,7 +339,7 @@ extern "C" int ppms_sp_to_f32(ppms_sp src, float* dst, int dst_ld, int64_t pixel
 // Used for FlowHead3D.conv2 (256 -> 2, 3x3x3, ppmtereo_update.py:674): 8 GEMM k-steps instead of 216.
 __global__ __launch_bounds__(256) void tap_gather_sum_kernel(const float* __restrict__ y, int y_ld, const float* __restrict__ bias,
                                                              float* __restrict__ out, int out_ld, int cout, int kt, int kh, int kw, int T,
-                                                             int H, int W, int64_t total) {
+                                                             int H, int W, int t_halo, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % cout);
@@ -351,17 +351,17 @@ __global__ __launch_bounds__(256) void tap_gather_sum_kernel(const float* __rest
         for (int ky = 0; ky < kh; ++ky)
             for (int kx = 0; kx < kw; ++kx, ++tap) {
                 const int tt = t + kz - kt / 2, y2 = yy + ky - kh / 2, x2 = x + kx - kw / 2;
-                if ((unsigned)tt < (unsigned)T && (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
+                if ((unsigned)(tt + t_halo) < (unsigned)(T + 2 * t_halo) && (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
                     acc += y[(((int64_t)tt * H + y2) * W + x2) * y_ld + tap * cout + c];
             }
     out[pix * out_ld + c] = acc;
 }
 extern "C" int ppms_tap_gather_sum(const float* y, int y_ld, const float* bias, float* out, int out_ld, int cout, int kt, int kh, int kw,
-                                   int T, int H, int W, void* stream) {
-    PPMS_REQUIRE(y && out && cout > 0 && kt * kh * kw * cout <= y_ld && out_ld >= cout, "tap_gather_sum: bad arguments");
+                                   int T, int H, int W, int t_halo, void* stream) {
+    PPMS_REQUIRE(y && out && cout > 0 && kt * kh * kw * cout <= y_ld && out_ld >= cout && t_halo >= 0, "tap_gather_sum: bad arguments");
     const int64_t total = (int64_t)T * H * W * cout;
     hipLaunchKernelGGL(tap_gather_sum_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, y, y_ld, bias, out, out_ld, cout,
-                       kt, kh, kw, T, H, W, total);
+                       kt, kh, kw, T, H, W, t_halo, total);
     return ppms_check_launch("tap_gather_sum");
 }
 
@@ -429,7 +429,7 @@ extern "C" int ppms_convex_upsample(const float* flow_nhwc, const float* mask, i
 // out[t][c][4y+i][4x+j] = sum_k softmax_k(mask[t][16k + 4i + j][y][x]) * 4 flow[t+kt-1][c][y+ky-1][x+kx-1], zero padded
 // (unfoldNd.UnfoldNd([3,3,3], padding=1): k = (kt*3 + ky)*3 + kx).  One thread = one (pixel, sub-position i*4+j).
 __global__ __launch_bounds__(256) void convex_upsample3d_kernel(const float* __restrict__ flow, const float* __restrict__ mask, int mask_ld,
-                                                                float* __restrict__ out, int T, int H, int W, int64_t P) {
+                                                                float* __restrict__ out, int T, int H, int W, int t_halo, int64_t P) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= P * 16) return;
     const int sub = (int)(idx & 15);
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void convex_upsample3d_kernel(const float* __r
     for (int k = 0; k < 27; ++k) {
         const int dt = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
         const int tt = (int)frame + dt, yy = y + dy, xx = x + dx;
-        if ((unsigned)tt < (unsigned)T && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+        if ((unsigned)(tt + t_halo) < (unsigned)(T + 2 * t_halo) && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
             const int64_t q = pix + ((int64_t)dt * H + dy) * W + dx;
             const float wgt = mv[k] / den;
             o0 += wgt * (4.0f * flow[q * 2]);
@@ -468,11 +468,11 @@ __global__ __launch_bounds__(256) void convex_upsample3d_kernel(const float* __r
     out[o] = o0;
     out[o + OHW] = o1;
 }
-extern "C" int ppms_convex_upsample_3d(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int T, int H, int W, void* stream) {
-    PPMS_REQUIRE(flow_nhwc && mask && out && mask_ld >= 432 && T > 0 && H > 0 && W > 0, "convex_upsample_3d: bad arguments");
+extern "C" int ppms_convex_upsample_3d(const float* flow_nhwc, const float* mask, int mask_ld, float* out, int T, int H, int W, int t_halo, void* stream) {
+    PPMS_REQUIRE(flow_nhwc && mask && out && mask_ld >= 432 && T > 0 && H > 0 && W > 0 && t_halo >= 0, "convex_upsample_3d: bad arguments");
     const int64_t P = (int64_t)T * H * W;
     hipLaunchKernelGGL(convex_upsample3d_kernel, dim3(ceil_div(P * 16, 256)), dim3(256), 0, (hipStream_t)stream, flow_nhwc, mask, mask_ld,
-                       out, T, H, W, P);
+                       out, T, H, W, t_halo, P);
     return ppms_check_launch("convex_upsample_3d");
 }
 
@@ -662,6 +662,17 @@ __global__ __launch_bounds__(64) void qk_cos_kernel(const float* __restrict__ po
         nk += __shfl_xor(nk, s);
     }
     if (threadIdx.x == 0) sim[i * T + j] = dot / (fmaxf(sqrtf(nq), 1e-8f) * fmaxf(sqrtf(nk), 1e-8f));
+}
+extern "C" int ppms_qk_pool(const float* q, const float* k, int ld, float* pooled, int T, int H, int W, void* stream) {
+    PPMS_REQUIRE(q && k && pooled && T > 0 && H >= 4 && W >= 4 && ld >= 128, "qk_pool: bad arguments (H,W >= 4)");
+    const int OH = H / 4, OW = W / 4;
+    hipLaunchKernelGGL(qk_pool_kernel, dim3(OH * OW, T, 2), dim3(128), 0, (hipStream_t)stream, q, k, ld, pooled, T, H, W, OH, OW);
+    return ppms_check_launch("qk_pool");
+}
+extern "C" int ppms_qk_cos(const float* pooled, float* sim, int T, int cells, void* stream) {
+    PPMS_REQUIRE(pooled && sim && T > 0 && cells > 0, "qk_cos: bad arguments");
+    hipLaunchKernelGGL(qk_cos_kernel, dim3(T, T), dim3(64), 0, (hipStream_t)stream, pooled, sim, T, cells);
+    return ppms_check_launch("qk_cos");
 }
 extern "C" int ppms_qk_similarity(const float* q, const float* k, int ld, float* pooled, float* sim, int T, int H, int W, void* stream) {
     PPMS_REQUIRE(q && k && pooled && sim && T > 0 && H >= 4 && W >= 4 && ld >= 128, "qk_similarity: bad arguments (H,W >= 4)");

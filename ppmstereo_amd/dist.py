@@ -1,9 +1,36 @@
 """One process per GPU over torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" for CPU rehearsals).
 
-The hot path of one window does not need a collective at BASELINE config 2 (T = 5 frames fit one GPU and do not
-divide across 2/4/8 ranks without changing the temporal encoding and top-k pick -- SURVEY.md section 8e), so ranks
-run independent units ("replicas only"): either replicas of the clip (bench.py) or the windows of a long video
-dealt round-robin (``shard_windows``), with one gather of the kept disparities at the end.
+Two levels of parallelism:
+
+1. Independent units, no data-path collective: replicas of a clip (bench.py at BASELINE config 2 -- T = 5 frames do not
+   divide across 2/4/8 ranks without changing the temporal encoding and the top-k pick) or the sliding windows of a
+   long video dealt round-robin (``shard_windows``), with one gather of the kept disparities at the end
+   (``gather_kept_frames``).
+2. ``FrameShard``: the T frames of ONE window in contiguous blocks of f = T / G frames per rank (BASELINE configs 4-5:
+   T = 40, 5 frames per GPU).  What couples frames inside forward_update_block, and how it is exchanged:
+
+   ====================================  ======================  ==============================================================
+   coupling (reference lines)            when                    exchange
+   ====================================  ======================  ==============================================================
+   pooled q / k frame descriptors        once per scale          all-gather, (f, 2, h/4*w/4) fp32 per rank  (ppmstereo.py:397-423)
+   memory keys K (constant per scale)    once per scale          all-gather, f*n*128 fp32 per rank: kept fp32 so that
+                                                                 bf16(K s + PE) rounds exactly as unsharded         (:524-548)
+   memory values V (new every iteration) every iteration         all-gather, f*128*n bf16 per rank (the reference casts V to bf16) (:550)
+   frame confidences (QAM)               every iteration         all-gather, f*nblk fp32 partial sums; every rank then runs the
+                                                                 same T x T pick and keeps the rows of its clips    (:505-513)
+   GRU pass T, (5,1,1) convs             every iteration, twice  +-2-frame halo of [h | mf, mfg] before the z/r conv and of
+                                                                 r*h before the q conv (inp's halo: once per scale)
+                                                                 (ppmtereo_update.py:281-289, 305-310)
+   FlowHead3D 3x3x3 (+ mask_3d head)     every iteration         +-1-frame halo of the new hidden state, +-1 of the 54-channel
+                                                                 pre-gather flow-head output                         (:670-678)
+   convex_upsample_3d (use_convex_3d)    every iteration         +-1-frame halo of the 2-channel flow     (ppmstereo.py:199-228)
+   update_block16 TimeAttnBlock          every iteration (1/16)  all-gather of x = [inp, mf, mfg], f*n*384 (640 pixels per frame)
+   ====================================  ======================  ==============================================================
+
+   Contiguous blocks make every halo a nearest-neighbour exchange (one xGMI link each way); the all-gathers are direct
+   (every rank pushes its block to all peers: xGMI is point to point, a ring would be bound by one ~153 GB/s link).  Sizes at
+   320x512, 1/4 scale, 5 frames per GPU: K 13 MB per rank once per scale, V 6.6 MB per rank and iteration, halos 2 x 15.7 MB
+   ([h | x], split-bf16 = 4 B per value) + 2 x 5.2 MB (r*h) + small ones per iteration.
 """
 from __future__ import annotations
 
@@ -90,3 +117,111 @@ def gather_kept_frames(local: List[tuple], num_frames: int, H: int, W: int, devi
         if keep.any():
             out[ii[keep]] = ff[keep]
     return out
+
+
+class _Done:
+    def wait(self):
+        return None
+
+
+class _Staged:
+    """Handle of an exchange staged through host memory (gloo with device tensors): completes the copy back on wait()."""
+
+    def __init__(self, finish):
+        self._finish = finish
+
+    def wait(self):
+        if self._finish is not None:
+            self._finish()
+            self._finish = None
+
+
+class FrameShard:
+    """Contiguous block of f = T / world frames of one window on each rank, and the two exchange primitives the sharded loop
+    is built from: ``all_gather`` (frame blocks of every rank, in rank order) and ``halo`` (boundary frames with the two
+    neighbours).  Works on host tensors (gloo) and on device tensors (RCCL; under gloo device tensors are staged through the
+    host, which is how one GPU box rehearses two ranks).  Every rank must call the same sequence of exchanges."""
+
+    HALO = 2            # frames of slack on both sides of a rank's block in halo'd buffers (the GRU's (5,1,1) convs need 2)
+
+    def __init__(self, rank: int, world: int, T: int, group=None):
+        if T % world != 0:
+            raise ValueError(f"FrameShard: {T} frames do not divide over {world} ranks")
+        self.rank, self.world, self.T, self.group = rank, world, T, group
+        self.f = T // world
+        if world > 1 and self.f < self.HALO:
+            raise ValueError("FrameShard: at least 2 frames per rank (the temporal GRU pass reads +-2 frames: one neighbour each side)")
+        self.lo, self.hi = rank * self.f, (rank + 1) * self.f
+
+    # ------------------------------------------------------------------ helpers
+    def _stage(self, t: torch.Tensor) -> bool:
+        return self.world > 1 and t.is_cuda and dist.get_backend(self.group) != "nccl"
+
+    # ------------------------------------------------------------------ all-gather of frame blocks
+    def all_gather(self, local: torch.Tensor, out: Optional[torch.Tensor] = None, async_op: bool = False):
+        """local: this rank's block, leading dimension = frames (or any per-rank leading extent); returns (out, handle) with
+        out = the blocks of all ranks concatenated along dimension 0 in rank order.  async_op: the caller waits on the handle."""
+        local = local.contiguous()
+        if out is None:
+            out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        if self.world == 1:
+            out.copy_(local)
+            return out, _Done()
+        if self._stage(local):
+            h_out = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(h_out, local.cpu(), group=self.group)
+            out.copy_(h_out)
+            return out, _Done()
+        work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=async_op)
+        return out, (work if async_op else _Done())
+
+    # ------------------------------------------------------------------ halo exchange with the two neighbours
+    def halo(self, buf: torch.Tensor, k: int, async_op: bool = False):
+        """buf: (..., HALO + f + HALO frames, ...) viewed as buf[frame_dim]; here the frame axis is dimension 0 of ``buf`` after
+        the caller's reshape: buf[HALO - k:HALO] receives the left neighbour's last k frames, buf[HALO + f:HALO + f + k] the
+        right neighbour's first k frames; rank 0's left and the last rank's right halo are left untouched (zeros = the
+        convolution's zero padding at the window's ends).  Returns a handle (wait() before the halo is read)."""
+        H, f = self.HALO, self.f
+        assert buf.shape[0] == f + 2 * H and 1 <= k <= H
+        if self.world == 1:
+            return _Done()
+        left, right = self.rank - 1, self.rank + 1
+        ops, finish = [], []
+        stage = self._stage(buf)
+
+        def send(src, peer):
+            src = src.contiguous()
+            ops.append(dist.P2POp(dist.isend, src.cpu() if stage else src, peer, group=self.group))
+
+        def recv(dst, peer):
+            if stage:
+                tmp = torch.empty(dst.shape, dtype=dst.dtype)
+                ops.append(dist.P2POp(dist.irecv, tmp, peer, group=self.group))
+                finish.append((dst, tmp))
+            elif dst.is_contiguous():
+                ops.append(dist.P2POp(dist.irecv, dst, peer, group=self.group))
+            else:
+                tmp = torch.empty(dst.shape, dtype=dst.dtype, device=dst.device)
+                ops.append(dist.P2POp(dist.irecv, tmp, peer, group=self.group))
+                finish.append((dst, tmp))
+
+        if left >= 0:
+            send(buf[H:H + k], left)
+            recv(buf[H - k:H], left)
+        if right < self.world:
+            send(buf[H + f - k:H + f], right)
+            recv(buf[H + f:H + f + k], right)
+        if not ops:
+            return _Done()
+        works = dist.batch_isend_irecv(ops)
+
+        def done():
+            for w in works:
+                w.wait()
+            for dst, tmp in finish:
+                dst.copy_(tmp)
+
+        if async_op and not stage:
+            return _Staged(done)
+        done()
+        return _Done()

@@ -268,16 +268,26 @@ class ScaleEngine:
     """All state of one forward_update_block call: buffers, descriptors, iteration stages."""
 
     def __init__(self, pk: PackedBlock, T: int, h: int, w: int, device, shard=None):
-        if shard is not None:
-            raise NotImplementedError("frame-sharded engine: see ppmstereo_amd/dist.py")
-        if T > 64:
+        """T: frames held by THIS engine.  shard (ppmstereo_amd.dist.FrameShard, optional): the window's frames are split in
+        contiguous blocks over the ranks; T == shard.f, global frame ids shard.lo .. shard.hi - 1 (see dist.py for what is
+        exchanged when)."""
+        if shard is not None and shard.world == 1:
+            shard = None
+        if shard is not None and T != shard.f:
+            raise ValueError(f"sharded engine: {T} local frames, the shard holds {shard.f}")
+        self.shard = shard
+        self.Tg = Tg = T if shard is None else shard.T          # frames of the whole window
+        self.f0 = 0 if shard is None else shard.lo               # global id of local frame 0
+        self.halo = 0 if shard is None else shard.HALO           # halo frames around the local block in pixel-indexed buffers
+        if Tg > 64:
             raise NotImplementedError("more than 64 frames per window")
         self.pk, self.T, self.h, self.w = pk, T, h, w
-        self.n = h * w
+        self.n = n = h * w
         self.P = P = T * h * w
         self.dev = device
-        self.ksel = min(TOP_K, T)
-        sp = lambda c: L.SPTensor(P, c, device)
+        self.ksel = min(TOP_K, Tg)
+        hp = self.halo * n                                        # halo pixels on each side
+        sp = lambda c: L.SPTensor(P, c, device, before=hp, after=hp)
         f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=device)
         self.CORR, self.T1, self.C1, self.C2 = sp(64), sp(64), sp(64), sp(64)
         self.COR256, self.CF, self.PATCH, self.FLO1 = sp(256), [sp(320), sp(320)], sp(128), sp(128)
@@ -286,40 +296,63 @@ class ScaleEngine:
         # local of SequenceUpdateBlock3D.forward, ppmtereo_update.py:976-983: inp itself must survive the iteration)
         self.XA = sp(384) if pk.attn is not None else self.X
         if pk.attn is not None:
-            self.O1, self.O2, self.XT, self.MSG, self.MSGN, self.H1 = sp(384), sp(384), sp(384), sp(384), sp(384), sp(768)
+            self.O2, self.XT, self.MSG, self.MSGN, self.H1 = sp(384), sp(384), sp(384), sp(384), sp(768)
+            # the temporal attention needs all frames of a pixel: gathered copy of x and its output for every frame of the
+            # window; the own block of O1 feeds the (per-frame) layers behind it
+            self.O1 = L.SPTensor(P, 384, device, before=self.f0 * n, after=(Tg - self.f0 - T) * n)
+            self.XG = self.X if shard is None else L.SPTensor(Tg * n, 384, device)
             self.QKF, self.VF, self.M2, self.M3 = f32(P, 768), f32(P, 384), f32(P, 384), f32(P, 384)
             self.KVWS = f32(4 * T * 8 * 48 * 49)
         self.Hb = [sp(128), sp(128), sp(128)]
         self.ZT, self.RT, self.RH, self.FH1, self.M1 = sp(128), sp(128), sp(128), sp(256), sp(256)
-        self.Z, self.MASK, self.FLOW, self.QK = f32(P, 128), f32(P, pk.mask_ch), f32(P, 2), f32(P, 256)
+        self.Z, self.MASK, self.QK = f32(P, 128), f32(P, pk.mask_ch), f32(P, 256)
+        self._FLOW_full, self._FH2Y_full = f32(P + 2 * hp, 2), f32(P + 2 * hp, 64)       # read across frames (3x3x3 taps): halo'd
+        self.FLOW, self.FH2Y = self._FLOW_full[hp:hp + P], self._FH2Y_full[hp:hp + P]
         self.DFLOW = f32(P, 4)
         if pk.hoist:
             self.PRE = {k: torch.empty(P, m, dtype=torch.float32, device=device) for k, m in
                         (("zr1_0", 256), ("q1", 128), ("zr2", 256), ("q2", 128), ("zr3", 256), ("q3", 128))}
             self._pre_stream, self._ev_pre, self._pre_pending = torch.cuda.Stream(device=device), torch.cuda.Event(), False
-        self.FH2Y = f32(P, 64)
-        self.VT = torch.zeros(T, 128, self.n, dtype=torch.bfloat16, device=device)
-        self.QB = torch.zeros(T, self.n, 128, dtype=torch.bfloat16, device=device)
-        self.KB = torch.zeros(T, self.ksel, self.n, 128, dtype=torch.bfloat16, device=device)
-        self.ATT_WS = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, self.ksel, self.n)), dtype=torch.uint8, device=device)
-        self.nblk = (self.n + 255) // 256
+        self.VT = torch.zeros(T, 128, n, dtype=torch.bfloat16, device=device)
+        self.VTG = self.VT if shard is None else torch.zeros(Tg, 128, n, dtype=torch.bfloat16, device=device)     # values of every frame
+        self.KG = None if shard is None else f32(Tg * n, 128)                                                     # keys of every frame
+        self.QB = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=device)
+        self.KB = torch.zeros(T, self.ksel, n, 128, dtype=torch.bfloat16, device=device)
+        self.ATT_WS = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, self.ksel, n)), dtype=torch.uint8, device=device)
+        self.nblk = (n + 255) // 256
         self.UNC, self.PART = f32(P), f32(T, self.nblk)
-        self.SIM, self.STRIVE, self.SCORE = f32(T, T), f32(T, T), f32(T, T)
-        self.SEL = torch.zeros(T, 5, dtype=torch.int32, device=device)
-        self.SHAT = f32(T, 5)
-        self.POOL = f32(2, T, max(1, (h // 4) * (w // 4)))
-        self.PE = temporal_pe(T, 128).to(device)
+        self.PARTG = self.PART if shard is None else f32(Tg, self.nblk)
+        self.SIM, self.STRIVE, self.SCORE = f32(Tg, Tg), f32(Tg, Tg), f32(Tg, Tg)
+        self.SEL = torch.zeros(Tg, 5, dtype=torch.int32, device=device)
+        self.SHAT = f32(Tg, 5)
+        self.cells = max(1, (h // 4) * (w // 4))
+        self.POOL = f32(2, T, self.cells)
+        self.POOLG = self.POOL if shard is None else f32(2, Tg, self.cells)
+        self.PE = temporal_pe(Tg, 128).to(device)
         self.FLOW_OUT = f32(T, 2, 4 * h, 4 * w)
         self.scale = softmax_scale(128)
         self.parity = 0             # which CF buffer holds the current motion hidden state
         self.have_mhs = False
         self.lib = L.load()
         self._ev, self._ev_i = None, 0
+        self._pending = []          # handles of exchanges in flight (waited for right before their data is read)
         # independent branches of an iteration (flow encoder || correlation encoder, r-gate || z-gate, mask head || flow
         # head) run on a second HIP stream, fork/joined with events: they fill each other's launch tails
         self._side = torch.cuda.Stream(device=device)
         self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         self._build_descriptors()
+
+    # ------------------------------------------------------------------ exchanges of a frame-sharded window (dist.FrameShard)
+    def _halo_sp(self, t: L.SPTensor, k: int):
+        """+-k boundary frames of an SP tensor with the neighbour ranks (both planes)."""
+        if self.shard is not None:
+            fr = self.T + 2 * self.halo
+            for p in (0, 1):
+                self.shard.halo(t.data[p].view(fr, self.n, t.channels), k)
+
+    def _halo_f32(self, full: torch.Tensor, k: int):
+        if self.shard is not None:
+            self.shard.halo(full.view(self.T + 2 * self.halo, self.n, full.shape[1]), k)
 
     # ------------------------------------------------------------------ descriptors
     def _conv(self, wname, segs: List[L.SP], k3, epi0: L.Epilogue, epi1: Optional[L.Epilogue] = None, m_split: Optional[int] = None,
@@ -332,6 +365,7 @@ class ScaleEngine:
         assert [s.c for s in segs] == meta["seg_padded"], (wname, [s.c for s in segs], meta["seg_padded"])
         d.w, d.bias = packed.data_ptr(), bias.data_ptr()
         d.T, d.H, d.W = self.T, self.h, self.w
+        d.t_halo = self.halo if k3[0] > 1 else 0        # temporal taps read the neighbour ranks' boundary frames from the halo slabs
         d.kt, d.kh, d.kw = k3
         d.M = meta["M"]
         d.m_split = meta["M"] if m_split is None else m_split
@@ -458,6 +492,7 @@ class ScaleEngine:
 
     def set_inp(self, inp: torch.Tensor):
         self.load_nchw(inp, self.X.view(0, 128))
+        self._halo_sp(self.X, 2)                    # (sharded window) inp's +-2 frames: read by the hoisted (5,1,1) gate convs
         if self.pk.hoist:                          # inp share of the GRU gate pre-activations, once per scale, on its own stream
             self._ev_fork.record()
             self._pre_stream.wait_event(self._ev_fork)
@@ -542,9 +577,16 @@ class ScaleEngine:
             self._qk_ops[key] = self._conv(qk_pack, [self.X.view(0, 128)], (1, 1, 1), epilogue(n_valid=256, out_f32=self.QK, out_f32_ld=256))
         self._qk_ops[key]()
         s = self._s()
-        L.check(self.lib.ppms_attn_prep_q(self.QK.data_ptr(), 256, self.PE.data_ptr(), self.QB.data_ptr(), self.T, self.n, s))
-        L.check(self.lib.ppms_qk_similarity(self.QK.data_ptr(), self.QK.data_ptr() + 128 * 4, 256, self.POOL.data_ptr(), self.SIM.data_ptr(),
-                                            self.T, self.h, self.w, s))
+        pe_local = self.PE.data_ptr() + self.f0 * 128 * 4
+        L.check(self.lib.ppms_attn_prep_q(self.QK.data_ptr(), 256, pe_local, self.QB.data_ptr(), self.T, self.n, s))
+        L.check(self.lib.ppms_qk_pool(self.QK.data_ptr(), self.QK.data_ptr() + 128 * 4, 256, self.POOL.data_ptr(), self.T, self.h, self.w, s))
+        if self.shard is not None:
+            # frame descriptors and keys of every frame of the window: once per scale (keys stay fp32: K' = bf16(K s + PE) must
+            # round exactly as in the unsharded loop)
+            g, _ = self.shard.all_gather(self.POOL.permute(1, 0, 2).contiguous())               # (Tg, 2, cells)
+            self.POOLG.copy_(g.permute(1, 0, 2))
+            self.shard.all_gather(self.QK[:, 128:].contiguous(), out=self.KG)
+        L.check(self.lib.ppms_qk_cos(self.POOLG.data_ptr(), self.SIM.data_ptr(), self.Tg, self.cells, s))
         self.STRIVE.fill_(1.0)
 
     # ------------------------------------------------------------------ iteration stages
@@ -596,21 +638,29 @@ class ScaleEngine:
         self.op["unc0"]()
         L.check(self.lib.ppms_unc_tail(self.U1.view(), self.pk.unc2_w.data_ptr(), self.pk.unc2_b, self.UNC.data_ptr(), self.PART.data_ptr(),
                                        self.T, self.n, self._s()))
+        if self.shard is not None:                  # every rank scores all T x T frame pairs from the same gathered confidences
+            self.shard.all_gather(self.PART, out=self.PARTG)
 
     def pick(self):
-        L.check(self.lib.ppms_qam_select(self.SIM.data_ptr(), self.STRIVE.data_ptr(), self.PART.data_ptr(), self.nblk, self.n, self.SEL.data_ptr(),
-                                         self.SHAT.data_ptr(), self.SCORE.data_ptr(), self.T, self._s()))
+        L.check(self.lib.ppms_qam_select(self.SIM.data_ptr(), self.STRIVE.data_ptr(), self.PARTG.data_ptr(), self.nblk, self.n, self.SEL.data_ptr(),
+                                         self.SHAT.data_ptr(), self.SCORE.data_ptr(), self.Tg, self._s()))
 
     def attend(self, out_bf16: Optional[torch.Tensor] = None):
         s = self._s()
-        L.check(self.lib.ppms_attn_prep_k(self.QK.data_ptr() + 128 * 4, 256, self.PE.data_ptr(), self.SEL.data_ptr(), self.SHAT.data_ptr(),
-                                          self.KB.data_ptr(), self.T, self.ksel, self.n, s))
+        sel = self.SEL.data_ptr() + self.f0 * 5 * 4                   # rows of this engine's clips
+        shat = self.SHAT.data_ptr() + self.f0 * 5 * 4
+        if self.shard is None:
+            key, key_ld = self.QK.data_ptr() + 128 * 4, 256
+        else:
+            key, key_ld = self.KG.data_ptr(), 128
+            self.shard.all_gather(self.VT, out=self.VTG)               # the values of every frame, new every iteration (bf16, as the reference casts them)
+        L.check(self.lib.ppms_attn_prep_k(key, key_ld, self.PE.data_ptr(), sel, shat, self.KB.data_ptr(), self.T, self.ksel, self.n, s))
         ev = None
         if self._ev is not None and self._ev_i < len(self._ev):
             ev = self._ev[self._ev_i]
             self._ev_i += 1
             ev[0].record()
-        L.check(self.lib.ppms_mem_attn(self.QB.data_ptr(), self.KB.data_ptr(), self.VT.data_ptr(), self.SEL.data_ptr(), self.ksel, self.scale,
+        L.check(self.lib.ppms_mem_attn(self.QB.data_ptr(), self.KB.data_ptr(), self.VTG.data_ptr(), sel, self.ksel, self.scale,
                                        self.pk.beta.data_ptr(), self.X.view(128, 128), self.X.view(256, 128), L.ptr(out_bf16), self.T, self.n,
                                        self.ATT_WS.data_ptr(), s))
         if ev is not None:
@@ -635,7 +685,11 @@ class ScaleEngine:
         o, s, lib, ln = self.op, self._s(), self.lib, self.pk.ln
         none_sp = L.SP(None, None, 0, 0)
         # TimeAttnBlock: x + fc(proj(attn_T(LN(x))))                                      ppmtereo_update.py:603-618
-        L.check(lib.ppms_time_attn(self.X.view(), ln["ta"][0].data_ptr(), ln["ta"][1].data_ptr(), self.O1.view(), self.T, self.n, 8, s))
+        if self.shard is not None:                  # attention over the T frames of a pixel: x of every frame of the window
+            for pl in (0, 1):
+                self.shard.all_gather(self.X.own()[pl], out=self.XG.data[pl])
+        L.check(lib.ppms_time_attn(self.XG.view(all_rows=True), ln["ta"][0].data_ptr(), ln["ta"][1].data_ptr(), self.O1.view(all_rows=True),
+                                   self.Tg, self.n, 8, s))
         o["ta_proj"]()
         o["ta_fc"]()
         # SpaceAttnBlock = LoFTR encoder layer with linear attention, x = source                 attention.py:164-190
@@ -661,21 +715,34 @@ class ScaleEngine:
             o["r1_2"]()
         o["z1_2"]()
         self._join()
-        for k in ("q1", "zr2", "q2", "zr3", "q3"):
+        for k in ("q1", "zr2", "q2"):
             o[k]()
+        # GRU pass along T, (5,1,1) convs (ppmtereo_update.py:305-310): +-2 frames of [h | mf, mfg], then of r*h
+        self._halo_sp(self.XA, 2)
+        self._halo_sp(self.Hb[2], 2)
+        o["zr3"]()
+        self._halo_sp(self.RH, 2)
+        o["q3"]()
+        self._halo_sp(self.Hb[0], 1)                # FlowHead3D / mask_3d: 3x3x3 convs of the new hidden state
         with self._fork():                        # mask head || flow head
             o["m1"]()
             o["m2"]()
         o["fh1"]()
         o["fh2"]()
+        self._halo_f32(self._FH2Y_full, 1)          # the second 3x3x3 conv gathers the 54 pre-gather channels over +-1 frame
         L.check(self.lib.ppms_tap_gather_sum(self.FH2Y.data_ptr(), 64, self.pk.fh2_bias.data_ptr(), self.DFLOW.data_ptr(), 4, 2, 3, 3, 3,
-                                             self.T, self.h, self.w, self._s()))
+                                             self.T, self.h, self.w, self.halo, self._s()))
         L.check(self.lib.ppms_flow_add(self.FLOW.data_ptr(), self.DFLOW.data_ptr(), 4, self.P, self._s()))   # ppmstereo.py:571
         self._join()
 
     def upsample(self) -> torch.Tensor:
-        fn = self.lib.ppms_convex_upsample_3d if self.pk.convex_3d else self.lib.ppms_convex_upsample          # ppmstereo.py:573-576
-        L.check(fn(self.FLOW.data_ptr(), self.MASK.data_ptr(), self.pk.mask_ch, self.FLOW_OUT.data_ptr(), self.T, self.h, self.w, self._s()))
+        if self.pk.convex_3d:                       # ppmstereo.py:573-576
+            self._halo_f32(self._FLOW_full, 1)      # 27 spatio-temporal neighbours: +-1 frame of the flow
+            L.check(self.lib.ppms_convex_upsample_3d(self.FLOW.data_ptr(), self.MASK.data_ptr(), self.pk.mask_ch, self.FLOW_OUT.data_ptr(), self.T,
+                                                     self.h, self.w, self.halo, self._s()))
+        else:
+            L.check(self.lib.ppms_convex_upsample(self.FLOW.data_ptr(), self.MASK.data_ptr(), self.pk.mask_ch, self.FLOW_OUT.data_ptr(), self.T,
+                                                  self.h, self.w, self._s()))
         return self.FLOW_OUT
 
     def iterate(self):

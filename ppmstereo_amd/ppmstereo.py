@@ -77,7 +77,7 @@ def convex_upsample_3d(flow: torch.Tensor, mask: torch.Tensor, rate: int, T: int
     L.check(lib.ppms_nchw_to_nhwc(fc.data_ptr(), f.data_ptr(), 2, N, 2, H * W, s))
     L.check(lib.ppms_nchw_to_nhwc(mc.data_ptr(), m.data_ptr(), 432, N, 432, H * W, s))
     out = torch.empty(N, 2, 4 * H, 4 * W, dtype=torch.float32, device=flow.device)
-    L.check(lib.ppms_convex_upsample_3d(f.data_ptr(), m.data_ptr(), 432, out.data_ptr(), T, H, W, s))
+    L.check(lib.ppms_convex_upsample_3d(f.data_ptr(), m.data_ptr(), 432, out.data_ptr(), T, H, W, 0, s))
     return out
 
 

@@ -48,3 +48,83 @@ def test_window_sharding_two_ranks(tmp_path):
     want = torch.arange(40, dtype=torch.float32)[:, None, None, None].expand(40, 1, 4, 6)
     assert torch.equal(res["full"], want), "every frame exactly once, in order, identical to the single-process stitching"
     assert res["t"] == 2.0 and res["tot"] == 20.0
+
+
+def _shard_worker(rank, world, port, out, c3d, drop=None):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(4)
+    from oracle import ppm_oracle as O
+    from ppmstereo_amd import dist as D
+    from ppmstereo_amd import weights as Wm
+    from ppmstereo_amd.synth import synth_scale_inputs
+    import sharded_oracle
+    from sharded_oracle import forward_update_block_sharded
+    sharded_oracle.DROP = drop                              # fault injection: skip one exchange (the test must then fail)
+    r, w, _ = D.init_from_env("gloo")
+    T, h, wd, iters = 8, 8, 32, 2
+    shard = D.FrameShard(rank, world, T)
+    W = Wm.hot_path_weights(use_convex_3d=c3d)
+    res = {}
+    for tag, ai, isc, attn, mh in (("update_block04", 2, 1, False, True), ("update_block16", 0, 4, True, False)):
+        d = synth_scale_inputs(T, h, wd, seed=77, with_mhs=mh, frame_contrast=1.0)
+        sl = slice(shard.lo, shard.hi)
+        pyr = O.corr_pyramid(d["fmap1"][sl], d["fmap2"][sl])                  # per frame: built from the local frames only
+        preds, uncs = [], []
+        fo, net, mhs = forward_update_block_sharded(shard, W[tag], W[f"att.{ai}"], pyr, d["flow"][sl], d["net"][sl], d["inp"][sl],
+                                                    None if d["mhs"] is None else d["mhs"][sl], iters, isc, attn, preds, uncs)
+        res[tag] = dict(fo=fo, net=net, mhs=mhs, pred=preds[-1], unc=uncs[-1], lo=shard.lo, hi=shard.hi)
+    torch.save(res, out + f".{rank}")
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_frame_sharded_loop_equals_unsharded(tmp_path):
+    """SURVEY.md section 8e level 2 (BASELINE configs 4-5): a T = 8 window sharded 4 frames per rank over two gloo ranks -- K /
+    V / confidence / descriptor all-gathers, +-2 and +-1 frame halos (dist.FrameShard), oracle math per rank -- gives the same
+    flow, hidden state and predictions as the unsharded loop, for update_block04 and update_block16 (time attention), with the
+    2-D and the 3-D convex upsampling."""
+    from oracle import ppm_oracle as O
+    from ppmstereo_amd import weights as Wm
+    from ppmstereo_amd.synth import synth_scale_inputs
+    for c3d in (False, True):
+        out = str(tmp_path / f"shard{int(c3d)}.pt")
+        port = _free_port()
+        mp.spawn(_shard_worker, args=(2, port, out, c3d), nprocs=2, join=True)
+        parts = [torch.load(out + f".{r}") for r in range(2)]
+        W = Wm.hot_path_weights(use_convex_3d=c3d)
+        T, h, wd, iters = 8, 8, 32, 2
+        for tag, ai, isc, attn, mh in (("update_block04", 2, 1, False, True), ("update_block16", 0, 4, True, False)):
+            d = synth_scale_inputs(T, h, wd, seed=77, with_mhs=mh, frame_contrast=1.0)
+            rp, ru = [], []
+            rfo, rnet, rmhs = O.forward_update_block(W[tag], W[f"att.{ai}"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"], d["inp"],
+                                                     d["mhs"], iters, isc, T, attn, rp, ru)
+            for p_ in parts:
+                sl = slice(p_[tag]["lo"], p_[tag]["hi"])
+                for key, ref in (("fo", rfo), ("net", rnet), ("mhs", rmhs), ("pred", rp[-1]), ("unc", ru[-1])):
+                    # not bit for bit on CPU: the fp32 conv library blocks a 4 + 4-frame tensor differently from an 8-frame one
+                    # (~1e-7 relative), and a bf16 rounding of an attention operand that flips on such a difference moves the
+                    # result by ~1e-4 -- the same tolerances as oracle vs reference (test_oracle_golden.py).  A dropped or
+                    # misplaced exchange is two orders larger (checked below by leaving one out).
+                    err = (p_[tag][key] - ref[sl]).abs().max().item()
+                    tol = {"fo": 3e-4, "pred": 3e-4 * isc, "net": 6e-4, "mhs": 2e-4, "unc": 5e-5}[key]
+                    assert err <= tol, (c3d, tag, key, err)
+
+
+def test_sharded_check_detects_a_dropped_exchange(tmp_path):
+    """Power of the comparison above: with the r*h halo of the temporal GRU pass left out the sharded result is wrong at the
+    block boundary by far more than the tolerance."""
+    from oracle import ppm_oracle as O
+    from ppmstereo_amd import weights as Wm
+    from ppmstereo_amd.synth import synth_scale_inputs
+    out = str(tmp_path / "drop.pt")
+    mp.spawn(_shard_worker, args=(2, _free_port(), out, False, "rh"), nprocs=2, join=True)
+    parts = [torch.load(out + f".{r}") for r in range(2)]
+    W = Wm.hot_path_weights()
+    T, h, wd, iters = 8, 8, 32, 2
+    d = synth_scale_inputs(T, h, wd, seed=77, with_mhs=True, frame_contrast=1.0)
+    rfo, rnet, _ = O.forward_update_block(W["update_block04"], W["att.2"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"], d["inp"],
+                                          d["mhs"], iters, 1, T, False, [], [])
+    worst = max((p_["update_block04"]["net"] - rnet[p_["update_block04"]["lo"]:p_["update_block04"]["hi"]]).abs().max().item() for p_ in parts)
+    assert worst > 1e-2, worst

@@ -554,7 +554,7 @@ def test_tap_gather_sum(lib, T, H, W):
     yd[:, :54] = y.to(DEV)
     out = torch.zeros(P, 4, device=DEV)
     bd = bs.to(DEV)
-    L.check(L.load().ppms_tap_gather_sum(yd.data_ptr(), 64, bd.data_ptr(), out.data_ptr(), 4, 2, 3, 3, 3, T, H, W, L.stream_ptr()))
+    L.check(L.load().ppms_tap_gather_sum(yd.data_ptr(), 64, bd.data_ptr(), out.data_ptr(), 4, 2, 3, 3, 3, T, H, W, 0, L.stream_ptr()))
     torch.cuda.synchronize()
     ref = _ref_conv([x], wt, bs, (3, 3, 3), T, H, W)
     assert maxdiff(out[:, :2], ref) < 3e-5

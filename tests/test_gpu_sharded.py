@@ -1,0 +1,66 @@
+"""GPU: the frame-sharded engine (SURVEY.md section 8e level 2, BASELINE configs 4-5) on the real kernels.  One GPU box has one
+GPU, so two ranks share it and talk over gloo (dist.FrameShard stages device tensors through the host in that case; on a
+multi-GPU node the same calls go through RCCL).  Each rank runs its block of frames of a T = 8 window through the whole 3-scale
+cascade and compares with the unsharded cascade run in the same process."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out, c3d):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ppmstereo_amd import dist as D
+    from ppmstereo_amd import weights as Wm
+    from ppmstereo_amd.ppmstereo import PPMStereoHotPath
+    from ppmstereo_amd.synth import synth_cascade_feats
+    D.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    T, H, W, iters = 8, 64, 256, 4
+    model = PPMStereoHotPath(use_convex_3d=c3d).load_hot_path_weights(Wm.hot_path_weights(use_convex_3d=c3d)).to(dev).eval()
+    feats = synth_cascade_feats(T, H, W, seed=5)
+    shard = D.FrameShard(rank, world, T)
+    local = {k: v[shard.lo:shard.hi].to(dev) for k, v in feats.items()}
+    p1, u1 = [], []
+    d_sh, c_sh = model.cascade(local, iters, T, p1, u1, shard=shard)
+    torch.cuda.synchronize()
+    D.barrier()
+    d_full, c_full = model.cascade({k: v.to(dev) for k, v in feats.items()}, iters, T)
+    torch.cuda.synchronize()
+    sl = slice(shard.lo, shard.hi)
+    res = dict(disp=(d_sh - d_full[sl]).abs().max().item(), unc=(c_sh - c_full[sl]).abs().max().item(), npred=len(p1),
+               finite=bool(torch.isfinite(d_sh).all()), scale=d_full.abs().max().item())
+    torch.save(res, out + f".{rank}")
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("c3d", [False, True])
+def test_sharded_cascade_equals_unsharded_on_the_gpu(tmp_path, c3d):
+    """All three scales (update_block16 with its temporal attention gather, 08, 04), 2 / 2 / 4 iterations, K / V / confidence
+    all-gathers and every temporal halo, against the same cascade on one rank.  The kernels compute every pixel identically
+    whichever rank holds it (zero halos stand for the window's zero padding), so the two agree to fp32 rounding of the
+    differently ordered temporal taps: <= 1e-5 px."""
+    out = str(tmp_path / "sh.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out, c3d), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(out + f".{r}")
+        assert res["finite"] and res["npred"] == 8
+        assert res["disp"] <= 1e-5 * max(1.0, res["scale"]), res
+        assert res["unc"] <= 1e-5, res
