@@ -47,7 +47,6 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
         const int flagged = *f;
         if (flagged == 0) return;                // (uniform)
         __syncthreads();
-        if (tid == 0) *f = 0;                    // leave the flag array clean for the next launch
     }
     const int q0 = blockIdx.x * (QW * NW) + wave * QW;
     const int qi = q0 + r;                       // this lane's query
@@ -473,10 +472,13 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     }
 
     // ---- (O, m, l) -> this workgroup's partial slot; attn_combine_kernel finishes the softmax and the aggregation ------
-    if (__any(bail) && lane == 0) {               // both 128-query halves of this workgroup are redone by the fix-up pass
-        int32_t* f = redo + ((int64_t)(clip * nsplit + slot0) * gridDim.x + blockIdx.x) * 2;
-        f[0] = 1;
-        f[1] = 1;
+    {                                             // both 128-query halves of this workgroup are redone by the fix-up pass when any
+        const int flag = __syncthreads_or(bail);  // of its queries bailed; written either way (no memset of the flags per call)
+        if (tid == 0) {
+            int32_t* f = redo + ((int64_t)(clip * nsplit + slot0) * gridDim.x + blockIdx.x) * 2;
+            f[0] = flag ? 1 : 0;
+            f[1] = flag ? 1 : 0;
+        }
     }
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
@@ -566,7 +568,6 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
     if (use64) {
         const int g64 = (int)ceil_div(n, 64 * NW);
         int32_t* redo = (int32_t*)(part_ml + (size_t)T * ksel * n * 2);
-        (void)hipMemsetAsync(redo, 0, (size_t)T * ksel * g64 * 2 * sizeof(int32_t), st);
         dim3 grid64(g64, T, ksel), grid32(ceil_div(n, QW * NW), T, ksel);
         hipLaunchKernelGGL(mem_attn64_kernel, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                            sel, ksel, scale_log2, n, part_o, part_ml, redo);
