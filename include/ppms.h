@@ -135,6 +135,11 @@ int ppms_conv_gemm3(const ppms_conv* desc, const ppms_conv* dev_desc, void* stre
 int ppms_conv_gemm4_applicable(const ppms_conv* desc);
 /* tile_px: pixels per workgroup, 0 = let the library choose (256 when that still gives >= 1.5 workgroups per CU, else 128) */
 int ppms_conv_gemm4(const ppms_conv* desc, const ppms_conv* dev_desc, int tile_px, void* stream);
+/* The same k-loop with one 8-wave workgroup per CU that owns ALL couts (M == 256, or M == 128 with the K loop split between two
+ * wave groups) of a tile of nbt = 7 or 8 blocks of 32 pixels, split 4 + 3 (4 + 4) so that every SIMD carries the same load
+ * (conv_gemm5.hip): 51 200 pixels = 240 tiles of 224 on 256 CUs.  Weights: pack_conv4.  nbt = 0: the library picks. */
+int ppms_conv_gemm5_applicable(const ppms_conv* desc);
+int ppms_conv_gemm5(const ppms_conv* desc, const ppms_conv* dev_desc, int nbt, void* stream);
 /* sizeof(ppms_sp), sizeof(ppms_epilogue), sizeof(ppms_conv) as compiled: lets a foreign-language binding check its
  * struct layout at load time */
 int ppms_struct_sizes(int* sp, int* epilogue, int* conv);

@@ -1,0 +1,464 @@
+// Implicit-GEMM convolution, one 8-wave workgroup per CU with SIMD-balanced 7- or 8-block pixel tiles (gfx950).
+//
+// Same math, descriptor and epilogues as conv_gemm2/3/4 (bf16x3 split MFMA: hi*hi + hi*lo + lo*hi, fp32 accumulate) and the
+// barrier-light k-loop of conv_gemm4 (weights from L2 straight to registers in MFMA-fragment order, 16-channel activation
+// windows double buffered by LDS-DMA, B fragments prefetched inside the step, one barrier per window).  What it adds is the
+// TILE: at BASELINE config 2 the 1/4-scale map has 51 200 pixels = 200 per CU, and power-of-two tiles (256 pixels x 128 couts,
+// two workgroups per CU) leave 22 % of the CU-slots empty while the others hold two workgroups -- 1.28x the balanced time.
+// Here a workgroup owns ALL couts of a tile of NBT = 7 (or 8) blocks of 32 pixels and a CU holds exactly one workgroup:
+// 51 200 / 224 -> 240 workgroups on 256 CUs (89 % vs 78 %).  A 7-block tile splits 4 + 3 between the two pixel halves (wn) of
+// the wave grid; the eight waves are laid out so that the two waves sharing a SIMD (w and w + 4) take 4 + 3 blocks:
+//   M = 256: wave w -> cout block wm = w & 3 (4 x 64 couts), wn = w >> 2;
+//   M = 128: two K-groups of four waves (kg = w >> 2) each own every other activation window of the K loop and their own pair
+//            of window buffers; (wm, wn) = ((w & 3) >> 1, (w & 1) ^ kg), partial tiles summed through LDS in fixed order.
+// Weights: pack_conv4 layout (ppmstereo_amd/packing.py).  LDS: <= 4 window buffers of <= 24 KiB, reused by the K-group
+// reduction (128 KiB) and the epilogue's transposition patches.
+#include "common.h"
+#include "conv_epilogue.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int NT5 = 512;
+constexpr int MAXS5 = 6;                      // window 16-B pieces per thread of a K-group
+constexpr int DEPTH5 = 3;                     // A-fragment stages in registers (2 steps of prefetch)
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page5[64];     // zero-initialised: source of padded rows
+
+struct Geo5 {
+    int C, R, logC;          // patch R x C pixels, R*C = 32 * NBT
+    int NBT;                 // 32-pixel blocks per tile: 7 (4 + 3) or 8 (4 + 4)
+    int tiles_x, tiles_y;
+    int WRL, Wr;             // window row length (pixels) and rows (padded to 16)
+    int hxw, hyw;            // halo of the window in x / y
+    int swx_n, row_jump;     // sweep: the LDS row advances by 1 per tap and by row_jump more after every swx_n taps
+    int nsweep;              // taps swept inside one window (kw, kh or kh*kw)
+    int rdy;                 // 1: the row-step index carries a dy (x sweep), 0: only dt
+    int nchunk, n0;          // 16-channel chunks per tap (all segments), chunks of segment 0
+    int kgroups;             // 1: M = 256 (4 cout blocks x 2 pixel halves), 2: M = 128 (2 x 2 x two K-groups)
+    int npieces;             // DMA pieces per thread of a K-group and window
+};
+
+__device__ __forceinline__ void dma16_5(const void* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const PPMS_GLOBAL void*)(uintptr_t)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void vm_wait5(int n) {
+#define PPMS_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    if (n == 8) {                                  // the steady state
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        return;
+    }
+    switch (n) {
+        PPMS_VMW(4) PPMS_VMW(9) PPMS_VMW(10) PPMS_VMW(11) PPMS_VMW(12) PPMS_VMW(13) PPMS_VMW(14)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // 0, and any other count: the safe full drain
+    }
+#undef PPMS_VMW
+}
+
+__global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restrict__ pd, const Geo5 g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ppms_conv& p = *pd;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the role branches below must be scalar
+    const int r = lane & 31, h = lane >> 5;
+    // wave roles (the two waves of a SIMD, w and w + 4, get 4 + (NBT - 4) pixel blocks)
+    const int kg = (g.kgroups == 2) ? (wave >> 2) : 0;
+    const int wm = (g.kgroups == 2) ? ((wave & 3) >> 1) : (wave & 3);
+    const int wn = (g.kgroups == 2) ? ((wave & 1) ^ kg) : (wave >> 2);
+    const int nbw = wn == 0 ? 4 : g.NBT - 4;       // 32-pixel blocks of this wave
+    const int blk0 = wn == 0 ? 0 : 4;              // its first block in the tile
+    const int GT = NT5 / g.kgroups;                // threads of a K-group (they gather the group's windows)
+    const int gt = tid - kg * GT;
+    const int gwave = gt >> 6;
+    int tile = blockIdx.x;
+    const int tx = tile % g.tiles_x;
+    tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y;
+    const int tf = tile / g.tiles_y;
+    const int x0 = tx * g.C, y0 = ty * g.R;
+    const int H = p.H, W = p.W, T = p.T;
+    const int HW = H * W;
+    const int ht = p.kt >> 1, hy = p.kh >> 1;
+    const int wbytes = g.npieces * (GT * 16);      // one window buffer: whole DMA pieces of the group (>= Wr * 64)
+    char* const wbase = smem + kg * 2 * wbytes;    // this K-group's pair of window buffers
+
+    // ---- window slots: LDS piece q = gt + i*GT (lane-linear destination); row = q >> 2, position q & 3 ------------------------
+    // a 64-B row holds [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] of one pixel's 16-channel chunk, chunk c stored at position
+    // c ^ ((row >> 2) & 3); GT is a multiple of 256, so ((row >> 2) & 3) = (gt >> 4) & 3 for every piece of a thread
+    int sl_off[MAXS5];          // pixel offset at (dt, dy) = 0, -1: column outside the image / slot unused
+    int sl_y[MAXS5];
+    const int nq = g.Wr * 4;
+#pragma unroll
+    for (int i = 0; i < MAXS5; ++i) {
+        const int q = gt + i * GT;
+        sl_off[i] = -1;
+        sl_y[i] = 0;
+        if (q < nq) {
+            const int wrow = q >> 2;
+            const int wy = wrow / g.WRL, wx = wrow - wy * g.WRL;
+            const int x = x0 + wx - g.hxw, y = y0 + wy - g.hyw;
+            sl_y[i] = y;
+            if ((unsigned)x < (unsigned)W) sl_off[i] = (tf * H + y) * W + x;
+        }
+    }
+    const int src_chunk = (gt & 3) ^ ((gt >> 4) & 3);            // 0,1: hi k0-7 / k8-15;  2,3: lo k0-7 / k8-15
+    const int src_plane = src_chunk >> 1, src_k8 = (src_chunk & 1) * 8;
+
+    // every descriptor field the loop needs, fetched once (a descriptor load inside the loop would make the compiler drain
+    // vmcnt, i.e. the A-fragment prefetch, at every window switch)
+    const bf16_t* const sp0 = (const bf16_t*)(src_plane ? p.seg[0].lo : p.seg[0].hi);
+    const bf16_t* const sp1 = (const bf16_t*)(src_plane ? p.seg[p.nseg - 1].lo : p.seg[p.nseg - 1].hi);
+    const int ld0 = p.seg[0].ld, ld1 = p.seg[p.nseg - 1].ld;
+    const int kh_ = p.kh;
+    const char* zpage = (const char*)g_zero_page5;
+    asm volatile("" : "+s"(zpage));                               // keep the address in registers (else: one GOT load per DMA piece)
+    auto dma_b = [&](int win, int buf) {                          // win = rowstep * nchunk + chunk
+        const int rowstep = win / g.nchunk, chunk = win - rowstep * g.nchunk;
+        int dy = 0, dt;
+        if (g.rdy) {
+            const int ky = rowstep % kh_;
+            dy = ky - hy;
+            dt = rowstep / kh_ - ht;
+        } else {
+            dt = rowstep - ht;
+        }
+        const int sg = (chunk >= g.n0) ? 1 : 0;
+        const int c0 = (chunk - (sg ? g.n0 : 0)) * 16 + src_k8;
+        const bf16_t* sp = sg ? sp1 : sp0;
+        const int ld = sg ? ld1 : ld0;
+        const bool tok = (unsigned)(tf + dt + p.t_halo) < (unsigned)(T + 2 * p.t_halo);
+        const int shift = (dt * H + dy) * W;
+        char* d = wbase + buf * wbytes + gwave * 1024;
+#pragma unroll
+        for (int i = 0; i < MAXS5; ++i) {
+            if (i < g.npieces) {                                  // uniform: every wave issues every piece (lanes past the window
+                                                                  // read the zero page into the buffer's padding), so all waves count alike
+                const bool ok = tok && sl_off[i] >= 0 && (unsigned)(sl_y[i] + dy) < (unsigned)H;
+                const void* ps = ok ? (const void*)(sp + (int64_t)(sl_off[i] + shift) * ld + c0) : (const void*)zpage;
+                dma16_5(ps, d + i * GT * 16);
+            }
+        }
+    };
+
+    // ---- A fragments: packed [k16-step][M/64][4 frags: mb0 hi, mb0 lo, mb1 hi, mb1 lo][64 lanes][16 B] -----------------------
+    const int mblocks = p.M >> 6;
+    const char* abase = (const char*)p.w;                                       // wave-uniform part kept scalar
+    const unsigned avoff = (unsigned)(wm * 4096 + lane * 16);
+    const int64_t astep = (int64_t)mblocks * 4096;
+    u32x4 areg[DEPTH5][4];
+    auto load_a = [&](u32x4 (&st)[4], int ks) {
+        const char* sb = abase + (int64_t)ks * astep;
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(st[0]) : "v"(avoff), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(st[1]) : "v"(avoff), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(st[2]) : "v"(avoff), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(st[3]) : "v"(avoff), "s"(sb) : "memory");
+    };
+
+    // ---- B-operand rows of this lane's pixel blocks (at sweep tap 0) ---------------------------------------------------------
+    int brow[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+        const int pid = (blk0 + (nb < nbw ? nb : 0)) * 32 + r;   // (a 3-block wave never reads its 4th entry)
+        brow[nb] = (pid >> g.logC) * g.WRL + (pid & (g.C - 1));
+    }
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
+
+    // temporal taps outside the readable frames contribute zeros: skip them (contiguous kz range)
+    const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
+    const int kz1 = (ht + T + p.t_halo - 1 - tf) < (p.kt - 1) ? (ht + T + p.t_halo - 1 - tf) : (p.kt - 1);
+    const int rows_per_kz = g.rdy ? p.kh : 1;
+    const int win0 = kz0 * rows_per_kz * g.nchunk + kg;                 // this K-group's first window; it takes every kgroups-th one
+    const int nwin = (kz1 + 1 - kz0) * rows_per_kz * g.nchunk / g.kgroups;
+    const int wstride = g.kgroups;
+    const int nsteps = nwin * g.nsweep;
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)wbase;
+    // B fragments of one tap from a window buffer: cpos 0 = hi chunks, 2 = lo chunks (inline asm: the LDS counter is managed
+    // by hand, see conv_gemm4.hip)
+#define CONV5_READ_B(DST, NBW, BUF, TROW, CPOS)                                                                                \
+    _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) {                                                                      \
+        const int row = brow[nb] + (TROW);                                                                                     \
+        const unsigned addr = lds0 + (BUF) * wbytes + row * 64 + ((((CPOS) + h) ^ ((row >> 2) & 3)) << 4);                     \
+        asm volatile("ds_read_b128 %0, %1" : "=v"(DST[nb]) : "v"(addr) : "memory");                                            \
+    }
+    // one k16-step with static A stage U and static block count NBW (see conv_gemm4.hip for the pipeline and the vmcnt arithmetic)
+#define CONV5_STEP(U, NBW, JJ)                                                                                                 \
+    {                                                                                                                          \
+        const int jj = (JJ);                                                                                                   \
+        const int ahead = nsteps - 1 - jj;                                                                                     \
+        if (ahead >= DEPTH5 - 1) {                                                                                             \
+            load_a(areg[((U) + DEPTH5 - 1) % DEPTH5], la_ks);                                                                  \
+            ++la_ks;                                                                                                           \
+            if (++la_s == g.nsweep) la_s = 0, la_ks += (wstride - 1) * g.nsweep; /* next window of this K-group */             \
+        }                                                                                                                      \
+        CONV5_READ_B(bl, NBW, w & 1, trow, 2)                                                                                  \
+        vm_wait5(4 * (ahead < DEPTH5 - 1 ? ahead : DEPTH5 - 1) + ((sw < DEPTH5 - 1 && w + 1 < nwin) ? g.npieces : 0));         \
+        if ((NBW) == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                     \
+        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        const bf16x8 ah0 = __builtin_bit_cast(bf16x8, areg[U][0]), al0 = __builtin_bit_cast(bf16x8, areg[U][1]);               \
+        const bf16x8 ah1 = __builtin_bit_cast(bf16x8, areg[U][2]), al1 = __builtin_bit_cast(bf16x8, areg[U][3]);               \
+        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[nb], acc[0][nb], 0, 0, 0); \
+        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[nb], acc[1][nb], 0, 0, 0); \
+        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[nb], acc[0][nb], 0, 0, 0); \
+        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[nb], acc[1][nb], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        if (++sw == g.nsweep) {                                                                                                \
+            sw = swx = trow = 0;                                                                                               \
+            if (ahead > 0) {                                                                                                   \
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                               \
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
+                __builtin_amdgcn_s_barrier();                                                                                  \
+                if (w + 2 < nwin) dma_b(win0 + wstride * (w + 2), w & 1);                                                      \
+            }                                                                                                                  \
+            ++w;                                                                                                               \
+        } else {                                                                                                               \
+            ++trow;                                                                                                            \
+            if (++swx == g.swx_n) {                                                                                            \
+                swx = 0;                                                                                                       \
+                trow += g.row_jump;                                                                                            \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        if (ahead > 0) {                                                                                                       \
+            CONV5_READ_B(bh, NBW, w & 1, trow, 0)                                                                              \
+            if ((NBW) == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                 \
+            else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                                                            \
+        } else {                                                                                                               \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+        }                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[nb], acc[0][nb], 0, 0, 0); \
+        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[nb], acc[1][nb], 0, 0, 0); \
+    }
+    // the whole K loop for a static block count
+#define CONV5_LOOP(NBW)                                                                                                        \
+    {                                                                                                                          \
+        dma_b(win0, 0);                                                                                                        \
+        load_a(areg[0], win0 * g.nsweep);                                                                                      \
+        load_a(areg[1], win0 * g.nsweep + 1);                                                                                  \
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* window 0 landed (everything but the 8 A loads) */                  \
+        __builtin_amdgcn_s_barrier();                                                                                          \
+        if (nwin > 1) dma_b(win0 + wstride, 1);                                                                                \
+        int sw = 0, swx = 0, trow = 0, w = 0;                                                                                  \
+        int la_s = DEPTH5 - 1, la_ks = win0 * g.nsweep + DEPTH5 - 1; /* tap / packed k16-step of the next A load (nsweep >= 3) */ \
+        bf16x8 bh[4], bl[4];                                                                                                   \
+        CONV5_READ_B(bh, NBW, 0, 0, 0)                                                                                         \
+        for (int j = 0; j < nsteps; j += DEPTH5) {                                                                             \
+            CONV5_STEP(0, NBW, j)                                                                                              \
+            if (j + 1 < nsteps) CONV5_STEP(1, NBW, j + 1)                                                                      \
+            if (j + 2 < nsteps) CONV5_STEP(2, NBW, j + 2)                                                                      \
+        }                                                                                                                      \
+    }
+    static_assert(DEPTH5 == 3, "the switch waits are vmcnt(4 * (DEPTH5 - 1)); the step loop is unrolled DEPTH5 times");
+    if (nbw == 4) CONV5_LOOP(4) else CONV5_LOOP(3)
+#undef CONV5_LOOP
+#undef CONV5_STEP
+#undef CONV5_READ_B
+    __syncthreads();                               // the window buffers become the reduction / epilogue staging areas
+
+    // ---- M = 128: sum the two K-groups' partial tiles (fixed order: group 0 + group 1) through LDS ---------------------------
+    if (g.kgroups == 2) {
+        float* red = (float*)smem + (wm * 2 + wn) * (128 * 64);              // one 32 KiB slot per (wm, wn): 128 registers x 64 lanes
+        if (kg == 1) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v4 = {acc[mb][nb][4 * q4], acc[mb][nb][4 * q4 + 1], acc[mb][nb][4 * q4 + 2], acc[mb][nb][4 * q4 + 3]};
+                        *(f32x4*)(red + (((mb * 4 + nb) * 4 + q4) * 64 + lane) * 4) = v4;
+                    }
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const f32x4 v4 = *(const f32x4*)(red + (((mb * 4 + nb) * 4 + q4) * 64 + lane) * 4);
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) acc[mb][nb][4 * q4 + e2] += v4[e2];
+                    }
+        }
+        __syncthreads();                           // the exchange area is reused as the epilogue's staging patches
+        if (kg == 1) return;
+    }
+
+    // ---- epilogue: accumulators -> wave-private LDS patch [32 px][64 couts] -> 8 couts of one pixel per lane -------
+    const int cblock = wm * 64;
+    const int half = (cblock >= p.m_split) ? 1 : 0;
+    const ppms_epilogue& e = p.epi[half];
+    const int cbase = cblock - (half ? p.m_split : 0);
+    float* stg = (float*)(smem + wave * STG_WAVE);
+    const int q = lane & 7;
+    float b8[8];
+    {
+        const f32x4 b0 = *(const f32x4*)(p.bias + cblock + q * 8), b1 = *(const f32x4*)(p.bias + cblock + q * 8 + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b8[j] = b0[j];
+            b8[4 + j] = b1[j];
+        }
+    }
+#pragma unroll 1
+    for (int nb = 0; nb < nbw; ++nb) {             // (not unrolled: code size; the selects keep every accumulator index static)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                f32x4 a4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[mb][0][4 * gq + j];
+#pragma unroll
+                    for (int k = 1; k < 4; ++k) x = (nb == k) ? acc[mb][k][4 * gq + j] : x;
+                    a4[j] = x;
+                }
+                if (e.out_vt != nullptr) {                           // pixel-major V^T straight from the accumulator layout
+                    const int pid = (blk0 + nb) * 32 + r;
+                    const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+                    const int c4 = mb * 32 + 8 * gq + 4 * h;
+                    const f32x4 bb = *(const f32x4*)(p.bias + cblock + c4);
+                    float v4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
+                    if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+                }
+                stage_write32(stg, r, h, mb, gq, a4);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int prow = it * 8 + (lane >> 3);
+            float v[8];
+            stage_read8(stg, prow, q, v);
+            const int pid = (blk0 + nb) * 32 + prow;
+            const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+            if (px < W && py < H) {
+                const int64_t pix = (int64_t)(tf * H + py) * W + px;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                epilogue_row8(e, v, pix, cbase + q * 8, HW);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// tile shape / window geometry for a descriptor; picks (NBT, C) with the best chip fill; false when nothing fits
+static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0) {
+    const int mode = (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);      // 0: x sweep, 1: y sweep, 2: 2-D sweep
+    const int hx = mode != 1 ? d->kw - 1 : 0, hy = mode != 0 ? d->kh - 1 : 0;   // window halo (total) in x / y
+    const int kgroups = d->M == 128 ? 2 : 1;
+    const int GT = NT5 / kgroups;
+    int nchunk = 0;
+    for (int s = 0; s < d->nseg; ++s) nchunk += d->seg[s].c / 16;
+    double best = -1.0;
+    int bestC = -1, bestN = 0, bestWr = 0;
+    for (int nbt = 7; nbt <= 8; ++nbt) {
+        if (force_nbt && nbt != force_nbt) continue;
+        for (int C = 16; C <= 128; C *= 2) {
+            if ((32 * nbt) % C) continue;
+            const int R = 32 * nbt / C;
+            const int Wr = ((R + hy) * (C + hx) + 15) / 16 * 16;
+            if (Wr > 384) continue;
+            const int64_t tiles = (int64_t)((d->W + C - 1) / C) * ((d->H + R - 1) / R) * d->T;
+            // useful pixels per CU-slot-round: rounds of 256 workgroups (one per CU), each costing nbt blocks
+            const double eff = (double)d->T * d->H * d->W / ((double)((tiles + 255) / 256) * 256 * 32 * nbt);
+            if (eff > best + 1e-9 || (eff > best - 1e-9 && Wr < bestWr)) best = eff, bestC = C, bestN = nbt, bestWr = Wr;
+        }
+    }
+    if (bestC < 0) return false;
+    g.NBT = bestN;
+    g.C = bestC;
+    g.R = 32 * bestN / bestC;
+    g.logC = 0;
+    while ((1 << g.logC) < g.C) ++g.logC;
+    g.tiles_x = (d->W + g.C - 1) / g.C;
+    g.tiles_y = (d->H + g.R - 1) / g.R;
+    g.WRL = g.C + hx;
+    g.Wr = bestWr;
+    g.hxw = hx >> 1;
+    g.hyw = hy >> 1;
+    if (mode == 0) {
+        g.swx_n = d->kw, g.row_jump = 0, g.nsweep = d->kw, g.rdy = 1;
+    } else if (mode == 1) {
+        g.swx_n = 1, g.row_jump = g.WRL - 1, g.nsweep = d->kh, g.rdy = 0;
+    } else {
+        g.swx_n = d->kw, g.row_jump = g.WRL - d->kw, g.nsweep = d->kh * d->kw, g.rdy = 0;
+    }
+    g.nchunk = nchunk;
+    g.n0 = d->seg[0].c / 16;
+    g.kgroups = kgroups;
+    g.npieces = (g.Wr * 4 + GT - 1) / GT;
+    return g.npieces <= MAXS5 && nchunk % kgroups == 0;
+}
+
+}  // namespace
+
+// returns 1 when this kernel serves the convolution: M == 256 or 128 (all couts in one workgroup), a spatial sweep of >= 3 taps,
+// 16-channel-aligned segments, a halo'd window that fits, and at least ~a workgroup per CU
+extern "C" int ppms_conv_gemm5_applicable(const ppms_conv* d) {
+    if (d == nullptr || (d->M != 256 && d->M != 128) || d->m_split % 64 != 0 || d->nseg < 1 || d->nseg > 2) return 0;
+    if (d->kw == 1 && d->kh == 1) return 0;
+    for (int s = 0; s < d->nseg; ++s)
+        if (d->seg[s].c <= 0 || d->seg[s].c % 16 != 0) return 0;
+    Geo5 g;
+    if (!plan5(d, g)) return 0;
+    return (int64_t)g.tiles_x * g.tiles_y * d->T >= 200 ? 1 : 0;   // fewer workgroups than CUs: conv_gemm2's K slicing fills the chip better
+}
+
+extern "C" int ppms_conv_gemm5(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, void* stream) {
+    PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm5: null descriptor");
+    PPMS_REQUIRE(nbt == 0 || nbt == 7 || nbt == 8, "conv_gemm5: nbt must be 0 (choose), 7 or 8");
+    PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm5: nseg=%d", d->nseg);
+    PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm5: bad volume %dx%dx%d", d->T, d->H, d->W);
+    PPMS_REQUIRE((d->M == 256 || d->M == 128) && d->m_split % 64 == 0, "conv_gemm5: M=%d must be 128 or 256", d->M);
+    PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15 && d->kh <= 15, "conv_gemm5: odd kernel extents <= 15");
+    PPMS_REQUIRE(d->kw > 1 || d->kh > 1, "conv_gemm5: needs a spatial sweep axis (kw > 1 or kh > 1)");
+    PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm5: weights/bias missing");
+    PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm5: t_halo=%d", d->t_halo);
+    PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 31) / 512, "conv_gemm5: volume too large for 32-bit pixel offsets");
+    for (int s = 0; s < d->nseg; ++s) {
+        PPMS_REQUIRE(d->seg[s].hi && d->seg[s].lo && d->seg[s].c > 0 && d->seg[s].c % 16 == 0 && d->seg[s].ld % 8 == 0,
+                     "conv_gemm5: segment %d needs hi/lo planes, c %% 16 == 0 and ld %% 8 == 0", s);
+        PPMS_REQUIRE(((uintptr_t)d->seg[s].hi & 15) == 0 && ((uintptr_t)d->seg[s].lo & 15) == 0, "conv_gemm5: segment %d not 16-B aligned", s);
+    }
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const ppms_epilogue& e = d->epi[hlf];
+        if (hlf == 1 && d->m_split >= d->M) break;
+        PPMS_REQUIRE(e.n_valid > 0, "conv_gemm5: epilogue %d has n_valid=%d", hlf, e.n_valid);
+        PPMS_REQUIRE(e.pre_f32 == nullptr || (e.n_valid % 4 == 0 && e.pre_f32_ld % 4 == 0), "conv_gemm5: pre_f32 needs n_valid and pre_f32_ld to be multiples of 4");
+        {
+            const char* why = epilogue_row8_check(e);
+            PPMS_REQUIRE(why == nullptr, "conv_gemm5: epilogue %d: %s", hlf, why ? why : "");
+        }
+        if (e.out_sp.hi) PPMS_REQUIRE(e.out_sp.lo && e.out_sp.ld % 4 == 0, "conv_gemm5: epilogue %d SP output misaligned", hlf);
+        if (e.kind == PPMS_EPI_RESID || e.kind == PPMS_EPI_RH || e.kind == PPMS_EPI_GRU)
+            PPMS_REQUIRE(e.aux_sp.hi && e.aux_sp.lo && e.aux_sp.ld % 4 == 0, "conv_gemm5: epilogue %d needs aux_sp", hlf);
+        if (e.kind == PPMS_EPI_GRU) PPMS_REQUIRE(e.aux_f32 != nullptr, "conv_gemm5: GRU epilogue needs z");
+    }
+    Geo5 g;
+    PPMS_REQUIRE(plan5(d, g, nbt), "conv_gemm5: no tile shape fits the LDS window");
+    PPMS_REQUIRE(g.nsweep >= 3, "conv_gemm5: the sweep must have at least 3 taps");
+    PPMS_REQUIRE(4 * (DEPTH5 - 1) + g.npieces <= 14 && g.npieces >= 1, "conv_gemm5: window of %d rows needs too many DMA pieces", g.Wr);
+    const int ntiles = g.tiles_x * g.tiles_y * d->T;
+    size_t lds = (size_t)2 * g.kgroups * g.npieces * (NT5 / g.kgroups) * 16;        // the K-groups' pairs of window buffers
+    if (g.kgroups == 2 && lds < (size_t)4 * 128 * 64 * 4) lds = (size_t)4 * 128 * 64 * 4;   // K-group exchange: 4 x 32 KiB
+    if (lds < (size_t)8 * STG_WAVE) lds = (size_t)8 * STG_WAVE;                  // the epilogue's transposition patches
+    PPMS_REQUIRE(lds <= 160 * 1024, "conv_gemm5: LDS budget exceeded (%zu B)", lds);
+    static ppms_device_once once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)conv5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    hipLaunchKernelGGL(conv5_kernel, dim3(ntiles), dim3(NT5), lds, (hipStream_t)stream, dev_desc, g);
+    return ppms_check_launch("conv_gemm5");
+}

@@ -31,6 +31,7 @@ from . import packing as _packing
 TOP_K = 5
 # tuning switches between HIP code paths of the library (A/B measurements on the GPU box; every setting runs HIP kernels only)
 USE_CONV4 = os.environ.get("PPMS_CONV4", "0") != "0"      # barrier-free k-loop kernel (conv_gemm4.hip): measured equal to conv_gemm3 so far, off
+USE_CONV5 = os.environ.get("PPMS_CONV5", "1") != "0"      # one 8-wave workgroup per CU, 7- / 8-block tiles (conv_gemm5.hip) where it applies
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
 _YS = os.environ.get("PPMS_YSWEEP", "1")                  # conv_gemm2 one-window forms: 0 = off, 1 = y-swept (1, kh, 1) convs (default),
@@ -101,7 +102,9 @@ class ConvOp:
             self._launch()
 
     def _launch(self):
-        if self.version == 4:
+        if self.version == 5:
+            L.check(L.load().ppms_conv_gemm5(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
+        elif self.version == 4:
             L.check(L.load().ppms_conv_gemm4(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         elif self.ysweep:
             L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
@@ -172,7 +175,7 @@ class PackedBlock:
                 self.w[name + "_2d"] = pack_conv(sweep, bias, segs, seg_pad, cout_map, m_pad)
             elif w5.shape[3] > 1:
                 sweep = w5.transpose(3, 4).contiguous()                      # y sweep: kh / kw swapped
-            if USE_CONV4 and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
+            if (USE_CONV4 or USE_CONV5) and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
                 rows = (max(cout_map) + 1) if cout_map is not None else w5.shape[0]
                 self.w4[name] = _packing.pack_conv4(sweep, bias, segs, seg_pad, cout_map, (rows + 127) // 128 * 128)
 
@@ -373,14 +376,10 @@ class ScaleEngine:
         if epi1 is not None:
             d.epi[1] = epi1
         version = 2
-        if USE_CONV4 and isinstance(wname, str) and wname in self.pk.w4:
-            packed4, bias4, meta4 = self.pk.w4[wname]
-            d4 = L.Conv.from_buffer_copy(bytes(d))
-            d4.w, d4.bias, d4.M = packed4.data_ptr(), bias4.data_ptr(), meta4["M"]
-            if m_split is None:
-                d4.m_split = meta4["M"]
-            if self.lib.ppms_conv_gemm4_applicable(C.byref(d4)):
-                return ConvOp(d4, [packed4, bias4, *keep], 4, device=self.dev)
+        if isinstance(wname, str):
+            op = self._try_fragment_kernels(wname, d, m_split, keep)
+            if op is not None:
+                return op
         if USE_CONV3 and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
             # the large-map kernel wants its k-steps in sweep order: y-swept convs packed with kh / kw swapped ("_y"),
             # 2-D swept ones (kh, kw > 1) with (ky, kx) flattened into x ("_2d"); without such a pack: conv_gemm2
@@ -399,8 +398,28 @@ class ScaleEngine:
                 return ConvOp(d, [packed_y, bias_y, *keep], 2, ysweep=True, device=self.dev)
         return ConvOp(d, [packed, bias, *keep], version, device=self.dev)
 
+    def _try_fragment_kernels(self, wname: str, d: L.Conv, m_split, keep) -> Optional[ConvOp]:
+        """conv_gemm5 / conv_gemm4 (weights in MFMA-fragment order, pack_conv4, couts padded to 128) when one of them serves the conv."""
+        if not (USE_CONV4 or USE_CONV5) or wname not in self.pk.w4:
+            return None
+        packed4, bias4, meta4 = self.pk.w4[wname]
+        d4 = L.Conv.from_buffer_copy(bytes(d))
+        d4.w, d4.bias, d4.M = packed4.data_ptr(), bias4.data_ptr(), meta4["M"]
+        if m_split is None:
+            d4.m_split = meta4["M"]
+        real = d4.epi[0].n_valid + (d4.epi[1].n_valid if d4.m_split < d4.M else 0)
+        if USE_CONV5 and 2 * real > meta4["M"] and self.lib.ppms_conv_gemm5_applicable(C.byref(d4)):
+            return ConvOp(d4, [packed4, bias4, *keep], 5, device=self.dev)
+        if USE_CONV4 and self.lib.ppms_conv_gemm4_applicable(C.byref(d4)):
+            return ConvOp(d4, [packed4, bias4, *keep], 4, device=self.dev)
+        return None
+
     def _conv_padded(self, wname, *a, **k) -> ConvOp:
         """wname + "_p" (couts padded to a multiple of 128) when the large-map kernel takes it, else the tight pack."""
+        if (USE_CONV4 or USE_CONV5) and wname in self.pk.w4:
+            op = self._conv(wname, *a, **k)
+            if op.version in (4, 5):
+                return op
         if USE_CONV3 and wname + "_p" in self.pk.w:
             op = self._conv(wname + "_p", *a, **k)
             if op.version == 3:

@@ -78,7 +78,9 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     tile_px = 0
     if version in (4, 4128, 4256):                                         # conv_gemm4; 4128 / 4256 force the pixel tile
         tile_px, version = (0 if version == 4 else version - 4000), 4
-    pack_conv = pack_conv4 if version == 4 else pack_conv2
+    if version in (5, 5007, 5008):                                         # conv_gemm5; 5007 / 5008 force the blocks per tile
+        tile_px, version = (0 if version == 5 else version - 5000), 5
+    pack_conv = pack_conv4 if version in (4, 5) else pack_conv2
     P = T * H * W
     segs, keep = [], []
     seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
@@ -88,9 +90,9 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
         segs.append(t.view())
         keep.append(t)
     wpack = weight
-    if (version in (3, 4) or ysweep) and k3[2] == 1 and k3[1] > 1:       # y-swept kernels: pack with kh / kw swapped
+    if (version in (3, 4, 5) or ysweep) and k3[2] == 1 and k3[1] > 1:       # y-swept kernels: pack with kh / kw swapped
         wpack = (weight if weight.dim() == 5 else weight[:, :, None]).transpose(3, 4).contiguous()
-    if (version in (3, 4) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
+    if (version in (3, 4, 5) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
         w5 = weight if weight.dim() == 5 else weight[:, :, None]
         wpack = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, k3[1] * k3[2]).contiguous()
     packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad)
@@ -121,7 +123,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     d.kt, d.kh, d.kw = k3
     d.M = d.m_split = meta["M"]
     d.epi[0] = e
-    ConvOp(d, keep, version, tile_px if version == 4 else wm, nslice=nslice if nslice is not None else 1, ysweep=ysweep)()
+    ConvOp(d, keep, version, tile_px if version in (4, 5) else wm, nslice=nslice if nslice is not None else 1, ysweep=ysweep)()
     torch.cuda.synchronize()
     sp = out.to_f32()[:, :cout].cpu()
     assert (sp - outf[:, :cout].cpu()).abs().max() < 2e-5 * (1 + sp.abs().max()), "SP and fp32 outputs of one launch disagree"
@@ -242,6 +244,44 @@ def test_conv_gemm4_vs_torch(lib, name, T, H, W, segs, cout, k3, tile):
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
+@pytest.mark.parametrize("nbt", [5007, 5008])
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV3_CASES + [("3x3_ragged_m256", 2, 13, 45, [48, 16], 190, (1, 3, 3)), ("x15_w24", 1, 9, 24, [32], 128, (1, 1, 15)),
+                                                   ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3))])
+def test_conv_gemm5_vs_torch(lib, name, T, H, W, segs, cout, k3, nbt):
+    """One 8-wave workgroup per tile of 7 / 8 blocks of 32 pixels (4 + 3 split balanced per SIMD), all couts per workgroup:
+    M = 256 (4 cout blocks x 2 pixel halves) and M = 128 (K loop split over two wave groups, partial tiles summed through LDS) --
+    x / y / 2-D sweeps, temporal taps, two segments, padded couts, ragged maps -- vs torch conv3d, and bit-reproducible."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    seg_pad = [((c + 15) // 16) * 16 for c in segs]
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=nbt, seg_pad=seg_pad)
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    assert torch.equal(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=nbt, seg_pad=seg_pad))
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=nbt, seg_pad=seg_pad, kind=lib.EPI_GRU, aux=aux, z=z)
+    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
+def test_conv_gemm5_full_map(lib):
+    """The shapes the 1/4 scale of BASELINE config 2 really runs (5 x 80 x 128 pixels) through the library's own tile choice
+    (7-block tiles: 240 workgroups): the GRU (1,1,15) conv to 256 couts, a 3x3 conv to 256, and the q-gate conv to 128 couts."""
+    T, H, W = 5, 80, 128
+    P = T * H * W
+    for segs, cout, k3 in (([128, 256], 256, (1, 1, 15)), ([128], 256, (1, 3, 3)), ([128, 256], 128, (1, 1, 5))):
+        xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+        cin = sum(segs)
+        wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+        bs = hash_normal((cout,), 201) * 0.1
+        ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+        got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=5)
+        assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), (segs, k3)
+
+
 def test_conv_gemm4_full_map(lib):
     """The shapes the 1/4 scale of BASELINE config 2 really runs (5 x 80 x 128 pixels): GRU (1,1,15) conv with 384 + 128 input
     channels to 256 couts, and a 3x3 conv, through the library's own tile choice (256-pixel tiles, 400 workgroups)."""
@@ -257,7 +297,7 @@ def test_conv_gemm4_full_map(lib):
         assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), (segs, k3)
 
 
-@pytest.mark.parametrize("version", [4, 3, 2])
+@pytest.mark.parametrize("version", [5, 4, 3, 2])
 def test_conv_gemm_hoisted_input_share(lib, version):
     """conv([h | inp | rest]) == conv_h_rest([h | rest]) + pre, pre = conv_inp(inp) + bias computed by another launch
     (the engine hoists the inp share of the GRU gates out of the iteration loop): every epilogue adds pre_f32 to
