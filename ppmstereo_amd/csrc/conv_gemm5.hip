@@ -21,7 +21,7 @@ namespace {
 
 constexpr int NT5 = 512;
 constexpr int MAXS5 = 6;                      // window 16-B pieces per thread of a K-group
-constexpr int DEPTH5 = 3;                     // A-fragment stages in registers (2 steps of prefetch)
+constexpr int DEPTH5 = 2;                     // A-fragment stages in registers: the next step's are loaded during this step's first MFMA group
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page5[64];     // zero-initialised: source of padded rows
 
@@ -57,6 +57,8 @@ __device__ __forceinline__ void vm_wait5(int n) {
 #undef PPMS_VMW
 }
 
+#include "conv5_asm.h"
+
 __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restrict__ pd, const Geo5 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ppms_conv& p = *pd;
@@ -87,20 +89,19 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
     // ---- window slots: LDS piece q = gt + i*GT (lane-linear destination); row = q >> 2, position q & 3 ------------------------
     // a 64-B row holds [hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15] of one pixel's 16-channel chunk, chunk c stored at position
     // c ^ ((row >> 2) & 3); GT is a multiple of 256, so ((row >> 2) & 3) = (gt >> 4) & 3 for every piece of a thread
-    int sl_off[MAXS5];          // pixel offset at (dt, dy) = 0, -1: column outside the image / slot unused
-    int sl_y[MAXS5];
+    // per slot ONE register: pixel offset at (dt, dy) = 0 in the low 22 bits (the volume has < 2^22 pixels), y + 512 in the high 10
+    // (the halo puts y in [-7, H + 7]); -1: column outside the image / slot unused
+    int sl[MAXS5];
     const int nq = g.Wr * 4;
 #pragma unroll
     for (int i = 0; i < MAXS5; ++i) {
         const int q = gt + i * GT;
-        sl_off[i] = -1;
-        sl_y[i] = 0;
+        sl[i] = -1;
         if (q < nq) {
             const int wrow = q >> 2;
             const int wy = wrow / g.WRL, wx = wrow - wy * g.WRL;
             const int x = x0 + wx - g.hxw, y = y0 + wy - g.hyw;
-            sl_y[i] = y;
-            if ((unsigned)x < (unsigned)W) sl_off[i] = (tf * H + y) * W + x;
+            if ((unsigned)x < (unsigned)W && (tf * H + y) * W + x >= 0) sl[i] = ((tf * H + y) * W + x) | ((y + 512) << 22);
         }
     }
     const int src_chunk = (gt & 3) ^ ((gt >> 4) & 3);            // 0,1: hi k0-7 / k8-15;  2,3: lo k0-7 / k8-15
@@ -135,8 +136,9 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
         for (int i = 0; i < MAXS5; ++i) {
             if (i < g.npieces) {                                  // uniform: every wave issues every piece (lanes past the window
                                                                   // read the zero page into the buffer's padding), so all waves count alike
-                const bool ok = tok && sl_off[i] >= 0 && (unsigned)(sl_y[i] + dy) < (unsigned)H;
-                const void* ps = ok ? (const void*)(sp + (int64_t)(sl_off[i] + shift) * ld + c0) : (const void*)zpage;
+                const int so = sl[i] & 0x3fffff, sy = ((unsigned)sl[i] >> 22) - 512;
+                const bool ok = tok && sl[i] != -1 && (unsigned)(sy + dy) < (unsigned)H;   // (a valid slot has y + 512 < 1023)
+                const void* ps = ok ? (const void*)(sp + (int64_t)(so + shift) * ld + c0) : (const void*)zpage;
                 dma16_5(ps, d + i * GT * 16);
             }
         }
@@ -147,13 +149,13 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
     const char* abase = (const char*)p.w;                                       // wave-uniform part kept scalar
     const unsigned avoff = (unsigned)(wm * 4096 + lane * 16);
     const int64_t astep = (int64_t)mblocks * 4096;
-    u32x4 areg[DEPTH5][4];
+    u32x4 areg[DEPTH5][4];   // (read-write asm operands below: the first 'read' is of an undefined value, on purpose -- see conv5_asm.h)
     auto load_a = [&](u32x4 (&st)[4], int ks) {
         const char* sb = abase + (int64_t)ks * astep;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(st[0]) : "v"(avoff), "s"(sb) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=v"(st[1]) : "v"(avoff), "s"(sb) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=v"(st[2]) : "v"(avoff), "s"(sb) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=v"(st[3]) : "v"(avoff), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(st[0]) : "v"(avoff), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "+v"(st[1]) : "v"(avoff), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "+v"(st[2]) : "v"(avoff), "s"(sb) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "+v"(st[3]) : "v"(avoff), "s"(sb) : "memory");
     };
 
     // ---- B-operand rows of this lane's pixel blocks (at sweep tap 0) ---------------------------------------------------------
@@ -164,11 +166,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
         brow[nb] = (pid >> g.logC) * g.WRL + (pid & (g.C - 1));
     }
 
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x16){0};
+    f32x16 acc[2][4];                              // (zeroed per path below: a 3-block wave must not carry two dead zero tuples)
 
     // temporal taps outside the readable frames contribute zeros: skip them (contiguous kz range)
     const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
@@ -180,40 +178,44 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
     const int nsteps = nwin * g.nsweep;
 
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)wbase;
-    // B fragments of one tap from a window buffer: cpos 0 = hi chunks, 2 = lo chunks (inline asm: the LDS counter is managed
-    // by hand, see conv_gemm4.hip)
-#define CONV5_READ_B(DST, NBW, BUF, TROW, CPOS)                                                                                \
+    // LDS byte address of the hi fragment (chunk h) of pixel block nb at window-row offset TROW of buffer BUF; the lo fragment
+    // (chunk 2 + h) of the same row is that address ^ 32
+#define CONV5_ADDR(DST, NBW, BUF, TROW)                                                                                        \
     _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) {                                                                      \
         const int row = brow[nb] + (TROW);                                                                                     \
-        const unsigned addr = lds0 + (BUF) * wbytes + row * 64 + ((((CPOS) + h) ^ ((row >> 2) & 3)) << 4);                     \
-        asm volatile("ds_read_b128 %0, %1" : "=v"(DST[nb]) : "v"(addr) : "memory");                                            \
+        DST[nb] = lds0 + (BUF) * wbytes + row * 64 + ((h ^ ((row >> 2) & 3)) << 4);                                            \
     }
-    // one k16-step with static A stage U and static block count NBW (see conv_gemm4.hip for the pipeline and the vmcnt arithmetic)
-#define CONV5_STEP(U, NBW, JJ)                                                                                                 \
+    // One k16-step with static A stage U and static block count NBW.  Pipeline:
+    //   top:     wait for A(jj) (requested during the previous step's group 1) and for the hi fragments (previous step's group 3)
+    //   group 1: a_lo x b_hi MFMAs || A loads of step jj + 1 (into the other register stage)
+    //   group 2: a_hi x b_hi MFMAs || requests for this step's lo fragments
+    //   tap state -> next step; at the end of a window: wait for the next window's pieces, barrier, request the window after next
+    //   group 3: requests for the next step's hi fragments, wait for the lo fragments, a_hi x b_lo MFMAs
+    // vmcnt: at the top nothing but a window's pieces can be younger than A(jj) -- when the previous step switched windows (tap
+    // index 0); at a switch only A(jj + 1) is younger than the awaited window's pieces.
+#define CONV5_STEP(U, NBW, JJ, MORE)                                                                                               \
     {                                                                                                                          \
         const int jj = (JJ);                                                                                                   \
         const int ahead = nsteps - 1 - jj;                                                                                     \
-        if (ahead >= DEPTH5 - 1) {                                                                                             \
-            load_a(areg[((U) + DEPTH5 - 1) % DEPTH5], la_ks);                                                                  \
+        vm_wait5((sw == 0 && w > 0 && w + 1 < nwin) ? g.npieces : ((jj == 0 && nwin > 1) ? g.npieces : 0));                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        /* (every MFMA group is unconditional straight-line code: an if / else around asm groups that redefine the eight      */ \
+        /*  accumulator tuples makes the register allocator copy and spill them; the last step simply re-requests data)        */ \
+        mfma_group1<NBW, MORE>(acc, areg[U][1], areg[U][3], bh, areg[(U) ^ 1], avoff, abase + (int64_t)la_ks * astep);         \
+        if (ahead >= 2) {                                                                                                      \
             ++la_ks;                                                                                                           \
             if (++la_s == g.nsweep) la_s = 0, la_ks += (wstride - 1) * g.nsweep; /* next window of this K-group */             \
         }                                                                                                                      \
-        CONV5_READ_B(bl, NBW, w & 1, trow, 2)                                                                                  \
-        vm_wait5(4 * (ahead < DEPTH5 - 1 ? ahead : DEPTH5 - 1) + ((sw < DEPTH5 - 1 && w + 1 < nwin) ? g.npieces : 0));         \
-        if ((NBW) == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                     \
-        else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                                     \
-        const bf16x8 ah0 = __builtin_bit_cast(bf16x8, areg[U][0]), al0 = __builtin_bit_cast(bf16x8, areg[U][1]);               \
-        const bf16x8 ah1 = __builtin_bit_cast(bf16x8, areg[U][2]), al1 = __builtin_bit_cast(bf16x8, areg[U][3]);               \
-        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al0, bh[nb], acc[0][nb], 0, 0, 0); \
-        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al1, bh[nb], acc[1][nb], 0, 0, 0); \
-        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bh[nb], acc[0][nb], 0, 0, 0); \
-        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bh[nb], acc[1][nb], 0, 0, 0); \
-        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        {                                                                                                                      \
+            unsigned adr_lo[4];                                                                                                \
+            _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) adr_lo[nb] = adr_hi[nb] ^ 32u;                                \
+            mfma_group2<NBW>(acc, areg[U][0], areg[U][2], bh, areg[U][1], areg[U][3], bx, adr_lo);                                                   \
+        }                                                                                                                      \
         if (++sw == g.nsweep) {                                                                                                \
             sw = swx = trow = 0;                                                                                               \
             if (ahead > 0) {                                                                                                   \
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                               \
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                               \
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
                 __builtin_amdgcn_s_barrier();                                                                                  \
                 if (w + 2 < nwin) dma_b(win0 + wstride * (w + 2), w & 1);                                                      \
@@ -226,41 +228,48 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
                 trow += g.row_jump;                                                                                            \
             }                                                                                                                  \
         }                                                                                                                      \
-        if (ahead > 0) {                                                                                                       \
-            CONV5_READ_B(bh, NBW, w & 1, trow, 0)                                                                              \
-            if ((NBW) == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");                                                 \
-            else asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");                                                            \
-        } else {                                                                                                               \
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
-        }                                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                                     \
-        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[0][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah0, bl[nb], acc[0][nb], 0, 0, 0); \
-        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) acc[1][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah1, bl[nb], acc[1][nb], 0, 0, 0); \
+        if (ahead > 0) { CONV5_ADDR(adr_hi, NBW, w & 1, trow) }                                                                \
+        mfma_group3<NBW, MORE>(acc, areg[U][0], areg[U][2], bh, areg[U][1], areg[U][3], bx, adr_hi);                                                 \
     }
     // the whole K loop for a static block count
 #define CONV5_LOOP(NBW)                                                                                                        \
     {                                                                                                                          \
+        _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < (NBW); ++b) {                      \
+            acc[a][b] = (f32x16){0};                                                                                           \
+            /* materialise the zeros HERE: the MFMAs of the loop are inline asm, so the compiler pads no VALU-write ->       */ \
+            /* MFMA-read wait states in front of them; left alone it sinks these moves right in front of the first MFMA      */ \
+            asm volatile("" : "+v"(acc[a][b]));                                                                                \
+        }                                                                                                                      \
         dma_b(win0, 0);                                                                                                        \
         load_a(areg[0], win0 * g.nsweep);                                                                                      \
-        load_a(areg[1], win0 * g.nsweep + 1);                                                                                  \
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); /* window 0 landed (everything but the 8 A loads) */                  \
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); /* window 0 landed (everything but the 4 A loads) */                  \
         __builtin_amdgcn_s_barrier();                                                                                          \
         if (nwin > 1) dma_b(win0 + wstride, 1);                                                                                \
         int sw = 0, swx = 0, trow = 0, w = 0;                                                                                  \
-        int la_s = DEPTH5 - 1, la_ks = win0 * g.nsweep + DEPTH5 - 1; /* tap / packed k16-step of the next A load (nsweep >= 3) */ \
-        bf16x8 bh[4], bl[4];                                                                                                   \
-        CONV5_READ_B(bh, NBW, 0, 0, 0)                                                                                         \
-        for (int j = 0; j < nsteps; j += DEPTH5) {                                                                             \
-            CONV5_STEP(0, NBW, j)                                                                                              \
-            if (j + 1 < nsteps) CONV5_STEP(1, NBW, j + 1)                                                                      \
-            if (j + 2 < nsteps) CONV5_STEP(2, NBW, j + 2)                                                                      \
+        int la_s = 1, la_ks = win0 * g.nsweep + 1; /* tap / packed k16-step of the next A load (nsweep >= 3); stops at the last step */ \
+        bf16x8 bh[4], bx[2];                                                                                                  \
+        unsigned adr_hi[4];                                                                                                    \
+        CONV5_ADDR(adr_hi, NBW, 0, 0)                                                                                          \
+        _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb)                                                                    \
+            asm volatile("ds_read_b128 %0, %1" : "+v"(bh[nb]) : "v"(adr_hi[nb]) : "memory");                                   \
+        int j = 0;                                                                                                             \
+        for (; j + 1 < nsteps; j += DEPTH5) {                                                                                  \
+            CONV5_STEP(0, NBW, j, true)                                                                                        \
+            CONV5_STEP(1, NBW, j + 1, true)                                                                                     \
         }                                                                                                                      \
+        if (j < nsteps) CONV5_STEP(0, NBW, j, false) /* odd step count */                                                      \
+        /* the last step's re-requests land in dead registers: drain them before the registers are reused; the last MFMAs' */  \
+        /* results need 12+ wait states before any non-MFMA reader */                                                          \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");                                    \
+        /* every register a load of the loop targets stays allocated up to here: a load whose result is dead would have its   */ \
+        /* destination handed to the next value while the data is still in flight                                            */ \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(areg[0][k]), "v"(areg[1][k]), "v"(bh[k]));         \
     }
-    static_assert(DEPTH5 == 3, "the switch waits are vmcnt(4 * (DEPTH5 - 1)); the step loop is unrolled DEPTH5 times");
+    static_assert(DEPTH5 == 2, "two A stages: U and U ^ 1; the step loop is unrolled twice");
     if (nbw == 4) CONV5_LOOP(4) else CONV5_LOOP(3)
 #undef CONV5_LOOP
 #undef CONV5_STEP
-#undef CONV5_READ_B
+#undef CONV5_ADDR
     __syncthreads();                               // the window buffers become the reduction / epilogue staging areas
 
     // ---- M = 128: sum the two K-groups' partial tiles (fixed order: group 0 + group 1) through LDS ---------------------------
@@ -428,7 +437,7 @@ extern "C" int ppms_conv_gemm5(const ppms_conv* d, const ppms_conv* dev_desc, in
     PPMS_REQUIRE(d->kw > 1 || d->kh > 1, "conv_gemm5: needs a spatial sweep axis (kw > 1 or kh > 1)");
     PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm5: weights/bias missing");
     PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm5: t_halo=%d", d->t_halo);
-    PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 31) / 512, "conv_gemm5: volume too large for 32-bit pixel offsets");
+    PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 22) && d->H < 480, "conv_gemm5: volume too large for the packed window slots (< 2^22 pixels, H < 480)");
     for (int s = 0; s < d->nseg; ++s) {
         PPMS_REQUIRE(d->seg[s].hi && d->seg[s].lo && d->seg[s].c > 0 && d->seg[s].c % 16 == 0 && d->seg[s].ld % 8 == 0,
                      "conv_gemm5: segment %d needs hi/lo planes, c %% 16 == 0 and ld %% 8 == 0", s);
@@ -451,7 +460,7 @@ extern "C" int ppms_conv_gemm5(const ppms_conv* d, const ppms_conv* dev_desc, in
     Geo5 g;
     PPMS_REQUIRE(plan5(d, g, nbt), "conv_gemm5: no tile shape fits the LDS window");
     PPMS_REQUIRE(g.nsweep >= 3, "conv_gemm5: the sweep must have at least 3 taps");
-    PPMS_REQUIRE(4 * (DEPTH5 - 1) + g.npieces <= 14 && g.npieces >= 1, "conv_gemm5: window of %d rows needs too many DMA pieces", g.Wr);
+    PPMS_REQUIRE(g.npieces <= 14 && g.npieces >= 1, "conv_gemm5: window of %d rows needs too many DMA pieces", g.Wr);
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
     size_t lds = (size_t)2 * g.kgroups * g.npieces * (NT5 / g.kgroups) * 16;        // the K-groups' pairs of window buffers
     if (g.kgroups == 2 && lds < (size_t)4 * 128 * 64 * 4) lds = (size_t)4 * 128 * 64 * 4;   // K-group exchange: 4 x 32 KiB
