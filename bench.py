@@ -104,8 +104,8 @@ def main():
     torch.cuda.synchronize()
     assert torch.isfinite(disp).all()
 
-    # HIP events around EVERY launch of the two dominant kernel families (memory attention; conv3_kernel = the large-map
-    # implicit-GEMM convolution), on the stream each is launched on
+    # HIP events around EVERY launch of the two dominant kernel families (memory attention; the large-map implicit-GEMM
+    # convolution kernels conv5_kernel / conv3_kernel -- whichever the engine picked per conv), on the stream each is launched on
     Tl = T // world if sharded else T
     engs = [(model.update_block16.engine(Tl, H // 16, W // 16, dev, shard), iters // 2), (model.update_block08.engine(Tl, H // 8, W // 8, dev, shard), iters // 2),
             (model.update_block04.engine(Tl, H // 4, W // 4, dev, shard), iters)]
@@ -113,9 +113,10 @@ def main():
     if not args.no_kernel_timing:
         for (e, n_it), sc in zip(engs, (16, 8, 4)):
             e.enable_attn_timing(args.steps * n_it)
-            for name, op in e.conv_ops(3).items():
-                op.events = []
-                conv3[(sc, name)] = op
+            for name, op in e.conv_ops().items():
+                if op.version in (3, 4, 5):
+                    op.events = []
+                    conv3[(sc, name)] = op
 
     step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     D.barrier()
@@ -156,7 +157,7 @@ def main():
                           traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                           launches=n_launch, avg_ms=round(tot_ms / n_launch, 4), total_ms_per_step=round(tot_ms / args.steps, 3),
                           flop_per_launch=tot_flop / n_launch, per_scale=per_scale))
-        # ---- conv3_kernel: algorithmic FLOPs of a launch = 2 * pixels * couts * cin * taps from its descriptor
+        # ---- large-map conv kernels: algorithmic FLOPs of a launch = 2 * pixels * couts * cin * taps from its descriptor
         if conv3:
             torch.cuda.synchronize()
             c_flop = c_ms = 0.0
@@ -168,19 +169,20 @@ def main():
                 c_flop += op.flops() * len(ms)
                 c_ms += sum(ms)
                 c_n += len(ms)
-                per_op[f"1/{sc}:{name}"] = dict(launches=len(ms), avg_ms=round(sum(ms) / len(ms), 4), gflop=round(op.flops() / 1e9, 2),
+                per_op[f"1/{sc}:{name}"] = dict(kernel=f"conv{op.version}_kernel", launches=len(ms), avg_ms=round(sum(ms) / len(ms), 4), gflop=round(op.flops() / 1e9, 2),
                                                 tflops=round(op.flops() / (sum(ms) / len(ms) * 1e-3) / 1e12, 1))
             if c_n:
                 cach = c_flop / (c_ms * 1e-3) / 1e12
                 ctraffic = None
-                tfile = os.path.join(ROOT, "profiles", "conv3_traffic.json")
+                tfile = os.path.join(ROOT, "profiles", "conv_traffic.json")
                 if os.path.exists(tfile) and (T, H, W) == (5, 320, 512):
                     ctraffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-                roofs.append(dict(bound="mfma", kernel="conv3_kernel (large-map implicit-GEMM convolution, bf16x3 split MFMA), every launch of the timed region; "
+                roofs.append(dict(bound="mfma", kernel="conv5_kernel / conv3_kernel (large-map implicit-GEMM convolutions, bf16x3 split MFMA; per_op names the kernel), "
+                                                       "every launch of the timed region; "
                                                        "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / 3 (three MFMAs per product)",
                                   achieved=round(cach, 2), peak=round(CONV_BOUND_TFLOPS, 1), unit="TFLOP/s", frac=round(cach / CONV_BOUND_TFLOPS, 4),
                                   frac_of_bf16_dense=round(cach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=ctraffic,
-                                  traffic_note="HBM bytes of ONE zr1_0 launch at the 1/4 scale, profiles/conv3_traffic.json",
+                                  traffic_note="HBM bytes of ONE zr1_0 launch at the 1/4 scale, profiles/conv_traffic.json",
                                   launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / args.steps, 3),
                                   flop_per_launch=c_flop / c_n, per_op=per_op))
         roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first

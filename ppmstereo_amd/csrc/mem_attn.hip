@@ -331,6 +331,8 @@ __device__ __forceinline__ void att_dma16(const void* src, char* lds_wave_base) 
     __builtin_amdgcn_global_load_lds((const PPMS_GLOBAL void*)(uintptr_t)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+#include "attn64_asm.h"
+
 __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
                                                             const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
                                                             float scale_log2, int n, float* __restrict__ part_o, float* __restrict__ part_ml,
@@ -380,15 +382,12 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int b = 0; b < QB; ++b) o[i][b] = (f32x16){0};
-    float neg_m[QB], l_run[QB];
-    bool bail = false;
-
     // K rows enter the MFMA with bits 2 and 3 of the row index swapped: S^T register g of lane half h then belongs to key
     // 16 (g >> 3) + 8 h + (g & 7) of the sub-tile, i.e. a lane's 8 P values per PV step are 8 consecutive keys
     const int rk_row = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
-    auto s_steps = [&](const char* ks, int kblk, f32x16 (&st)[QB], int s0, int s1) __attribute__((always_inline)) {
+    auto s_steps = [&](const char* ks, int kblk, f32x16 (&st)[QB]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = s0; s < s1; ++s) {
+        for (int s = 0; s < 8; ++s) {
             const int row = kblk * 32 + rk_row;
             const bf16x8 kf = *(const bf16x8*)(ks + row * 256 + (((2 * s + h) ^ (row & 15)) << 4));
 #pragma unroll
@@ -398,44 +397,17 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
             }
         }
     };
-    // one sub-step, ONE basic block: S of the next sub-tile (matrix pipe) || exp / sum / bf16 of the current one (VALU),
-    // then O += V P
-    auto substep = [&](const char* ks_next, int kblk_next, const char* vs, int kblk, f32x16 (&cur)[QB],
-                       f32x16 (&nxt)[QB]) __attribute__((always_inline)) {
-        s_steps(ks_next, kblk_next, nxt, 0, 8);
+    // LDS addresses of this lane's fragments in stage 0 (attn64_asm.h moves them from stage to stage):
+    //  K, k-step s: row rk_row (+ 32 rows = 8192 B for the tile's second sub-tile), chunk (2 s + h) ^ (row & 15)
+    //  V^T, 16-key group c4 of the tile: row d = r (+ 32 rows = 4096 B per d block), chunk (2 c4 + h) ^ ((d >> 1) & 7)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    unsigned kaddr[8], vaddr[4];
 #pragma unroll
-        for (int b = 0; b < QB; ++b) {
-            float psum = 0.0f;
+    for (int s = 0; s < 8; ++s) kaddr[s] = lds0 + rk_row * 256 + (((2 * s + h) ^ (rk_row & 15)) << 4);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                // raw v_exp_f32; values below 2^-126 flush to 0 (irrelevant for P)
-                const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(cur[b][g], scale_log2, neg_m[b]));
-                cur[b][g] = pe;
-                psum += pe;
-            }
-            l_run[b] += psum;
-            bail = bail || !(psum <= 0x1p60f);          // some score > reference + 60, or NaN: the fix-up pass redoes this tile
-        }
-        // O^T[d][query] += V^T P^T: one V^T fragment read feeds both query blocks
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 pf[QB];
-#pragma unroll
-            for (int b = 0; b < QB; ++b)
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) pf[b][jj] = (bf16_t)cur[b][8 * s2 + jj];
-            const int chunk = (kblk * 2 + s2) * 2 + h;            // keys kblk*32 + 16 s2 + 8 h .. + 7
-#pragma unroll
-            for (int dblk = 0; dblk < 4; ++dblk) {
-                const int d = dblk * 32 + r;
-                const bf16x8 vf = *(const bf16x8*)(vs + d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4));
-#pragma unroll
-                for (int b = 0; b < QB; ++b) o[dblk][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b], o[dblk][b], 0, 0, 0);
-            }
-        }
-    };
+    for (int c4 = 0; c4 < 4; ++c4) vaddr[c4] = lds0 + K_TILE + r * 128 + (((2 * c4 + h) ^ ((r >> 1) & 7)) << 4);
 
-    // ring: iteration j requests tile j+3 (into the stage tile j-1 just left), computes with K_j, K_{j+1}, V_j, and ends
+    // ring: iteration j requests tile j+3 (into the stage tile j-1 left at the barrier), computes with K_j, K_{j+1}, V_j, and ends
     // with "tiles <= j+2 have landed" (counted vmcnt: only tile j+3's 8 DMAs of this thread may still be in flight) + barrier
     issue_tile(0);
     if (nt > 1) issue_tile(1);
@@ -446,7 +418,8 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     f32x16 sa[QB], sb[QB];
-    s_steps(smem, 0, sa, 0, 8);
+    s_steps(smem, 0, sa);
+    float neg_m[QB], lsum[QB] = {0.0f, 0.0f};
 #pragma unroll
     for (int b = 0; b < QB; ++b) {                // softmax reference: maximum over the first 32 keys of the frame
         float mx = sa[b][0];
@@ -454,22 +427,36 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         for (int g = 1; g < 16; ++g) mx = fmaxf(mx, sa[b][g]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         neg_m[b] = -(mx * scale_log2);
-        l_run[b] = 0.0f;
+        asm volatile("" : "+v"(sa[b]));           // the loop keeps the S^T tiles in the VGPR half of the register file (its VALU reads them)
     }
+    // the hand-scheduled loop (attn64_asm.h, generated by tools/gen_attn_asm.py): 2 substeps = one 64-key tile.  The O += V P group
+    // of a sub-tile's second key half runs one substep late, so the first substep multiplies zeros by zeros
+    u32x4 ring[4], vh1[4] = {}, pf0[2] = {}, pf1[2] = {};
+    float pt[4] = {0.0f, 0.0f, 0.0f, 0.0f}, tt[2];
+    attn64_prime(sa, ring, pt, tt, neg_m, scale_log2, kaddr);
     for (int j = 0; j < nt; ++j) {
         const bool more3 = j + 3 < nt;
         if (more3) issue_tile(j + 3);
-        const char* kc = smem + (j & (ATT_NS - 1)) * ATT_STAGE;             // K_j, V_j
-        const char* kn = smem + ((j + 1) & (ATT_NS - 1)) * ATT_STAGE;       // K_{j+1} (stale on the last tile: result unused)
-        const char* vs = kc + K_TILE;
-        substep(kc, 1, vs, 0, sa, sb);
-        substep(kn, 0, vs, 1, sb, sa);
+        const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
+        attn64_substep<0>(sa, sb, qf, o, ring, vh1, pf0, pf1, pt, tt, lsum, neg_m, scale_log2, kaddr, vaddr, delta);
+        attn64_substep<1>(sb, sa, qf, o, ring, vh1, pf0, pf1, pt, tt, lsum, neg_m, scale_log2, kaddr, vaddr, delta);
         if (more3)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();
+        // the loop's MFMAs are inline asm: the compiler pads no MFMA-write -> VALU-read wait states behind them, and after the loop it
+        // copies accumulators around.  Drain the matrix pipe inside the last iteration, in front of anything it may place at the exit
+        if (j + 1 == nt) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
+    attn64_tail(pf1, pt);
+#pragma unroll
+    for (int dblk = 0; dblk < 4; ++dblk)          // O += V P for keys 16..31 of the last sub-tile
+#pragma unroll
+        for (int b = 0; b < QB; ++b)
+            o[dblk][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vh1[dblk]), __builtin_bit_cast(bf16x8, pf1[b]), o[dblk][b], 0, 0, 0);
+    // a score more than 2^60 above the reference (or a NaN) anywhere shows in the sum: the fix-up pass redoes the tile
+    const bool bail = !(lsum[0] <= 0x1p60f) || !(lsum[1] <= 0x1p60f);
 
     // ---- (O, m, l) -> this workgroup's partial slot; attn_combine_kernel finishes the softmax and the aggregation ------
     {                                             // both 128-query halves of this workgroup are redone by the fix-up pass when any
@@ -483,7 +470,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         const int qi = q0 + b * 32 + r;
-        const float l_tot = l_run[b] + __shfl_xor(l_run[b], 32);
+        const float l_tot = lsum[b] + __shfl_xor(lsum[b], 32);
         if (qi >= n) continue;
         const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
         float* po = part_o + row * D;
