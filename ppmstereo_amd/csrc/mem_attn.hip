@@ -341,10 +341,22 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     constexpr int QB = 2;                         // 32-query blocks per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int clip = blockIdx.y;
+    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by dispatch index, and each XCD has its own L2.  The 40-odd
+    // workgroups that stream the same (clip, picked frame) K / V^T should therefore sit on ONE XCD (they then advance through the
+    // tiles together and share every line); dealt the plain way each XCD reads all of K / V^T: 8x the fetch traffic.
     const int nsplit = gridDim.z;                 // one picked frame per workgroup (gridDim.z == ksel)
-    const int slot0 = (int)blockIdx.z;
-    const int q0 = blockIdx.x * (64 * NW) + wave * 64;
+    int qblk, clip, slot0;
+    {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = lin & 7, k = lin >> 3, q = nwg >> 3, rem = nwg & 7;
+        const int w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;      // a bijection of [0, nwg)
+        qblk = w % (int)gridDim.x;
+        const int pair = w / (int)gridDim.x;
+        clip = pair % (int)gridDim.y;
+        slot0 = pair / (int)gridDim.y;
+    }
+    const int q0 = qblk * (64 * NW) + wave * 64;
     const int nt = n / KT;
 
     bf16x8 qf[QB][8];
@@ -419,7 +431,8 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     __syncthreads();
     f32x16 sa[QB], sb[QB];
     s_steps(smem, 0, sa);
-    float neg_m[QB], lsum[QB] = {0.0f, 0.0f};
+    float neg_m[QB];
+    f32x2 negm2[QB], lsum2[QB] = {{0.0f, 0.0f}, {0.0f, 0.0f}};   // (the loop works on pairs of scores)
 #pragma unroll
     for (int b = 0; b < QB; ++b) {                // softmax reference: maximum over the first 32 keys of the frame
         float mx = sa[b][0];
@@ -427,19 +440,21 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         for (int g = 1; g < 16; ++g) mx = fmaxf(mx, sa[b][g]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         neg_m[b] = -(mx * scale_log2);
+        negm2[b] = (f32x2){neg_m[b], neg_m[b]};
         asm volatile("" : "+v"(sa[b]));           // the loop keeps the S^T tiles in the VGPR half of the register file (its VALU reads them)
     }
     // the hand-scheduled loop (attn64_asm.h, generated by tools/gen_attn_asm.py): 2 substeps = one 64-key tile.  The O += V P group
     // of a sub-tile's second key half runs one substep late, so the first substep multiplies zeros by zeros
     u32x4 ring[4], vh1[4] = {}, pf0[2] = {}, pf1[2] = {};
-    float pt[4] = {0.0f, 0.0f, 0.0f, 0.0f}, tt[2];
-    attn64_prime(sa, ring, pt, tt, neg_m, scale_log2, kaddr);
+    f32x2 pt2[2], tt2[2];
+    const f32x2 scale2 = {scale_log2, scale_log2};
+    attn64_prime(sa, ring, pt2, tt2, negm2, scale2, kaddr);
     for (int j = 0; j < nt; ++j) {
         const bool more3 = j + 3 < nt;
         if (more3) issue_tile(j + 3);
         const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
-        attn64_substep<0>(sa, sb, qf, o, ring, vh1, pf0, pf1, pt, tt, lsum, neg_m, scale_log2, kaddr, vaddr, delta);
-        attn64_substep<1>(sb, sa, qf, o, ring, vh1, pf0, pf1, pt, tt, lsum, neg_m, scale_log2, kaddr, vaddr, delta);
+        attn64_substep<0>(sa, sb, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, negm2, scale2, kaddr, vaddr, delta);
+        attn64_substep<1>(sb, sa, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, negm2, scale2, kaddr, vaddr, delta);
         if (more3)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
@@ -449,7 +464,8 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         // copies accumulators around.  Drain the matrix pipe inside the last iteration, in front of anything it may place at the exit
         if (j + 1 == nt) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
-    attn64_tail(pf1, pt);
+    attn64_tail();
+    const float lsum[QB] = {lsum2[0][0] + lsum2[0][1], lsum2[1][0] + lsum2[1][1]};
 #pragma unroll
     for (int dblk = 0; dblk < 4; ++dblk)          // O += V P for keys 16..31 of the last sub-tile
 #pragma unroll
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     {                                             // both 128-query halves of this workgroup are redone by the fix-up pass when any
         const int flag = __syncthreads_or(bail);  // of its queries bailed; written either way (no memset of the flags per call)
         if (tid == 0) {
-            int32_t* f = redo + ((int64_t)(clip * nsplit + slot0) * gridDim.x + blockIdx.x) * 2;
+            int32_t* f = redo + ((int64_t)(clip * nsplit + slot0) * gridDim.x + qblk) * 2;
             f[0] = flag ? 1 : 0;
             f[1] = flag ? 1 : 0;
         }

@@ -2,7 +2,8 @@
 """Generates ppmstereo_amd/csrc/attn64_asm.h: the hand-scheduled inner loop of mem_attn64_kernel (mem_attn.hip).
 
 One "substep" = one 32-key sub-tile of the 64-key KV tile, for the wave's two 32-query blocks: 32 MFMAs (32 cycles of the matrix pipe
-each), and in their shadow the softmax VALU work of 32 scores per lane (fma, exp2, add, bf16 pack) plus 16 LDS fragment reads.
+each), and behind them the softmax VALU work of 32 scores per lane (16 pairs: one packed fma, two exp2, one packed add, one bf16
+pack each) plus 16 LDS fragment reads.
 Every instruction is its own `asm volatile` statement (never reordered among themselves): the lists below ARE the issue order, the
 compiler only allocates registers.  Schedule of substep k (slot = one MFMA and what issues behind it):
 
@@ -21,6 +22,10 @@ import os
 MF = "v_mfma_f32_32x32x16_bf16"
 
 
+# 1: packed fp32 VALU ops (v_pk_fma_f32 / v_pk_add_f32) for the softmax pairs -- measured SLOWER on gfx950 (1/4-scale call 1.52 ms
+# against 1.25 ms with scalar ops: the packed fp32 ops do not hide behind the MFMAs); needs __attribute__((target("packed-fp32-ops")))
+# on the kernel, the library being built without packed-fp32 code generation
+PK = int(os.environ.get("PPMS_ATTN_PK", "0"))
 ABL = int(os.environ.get("PPMS_ATTN_ABL", "0"))     # timing experiments only (wrong results): 1 drops the softmax VALU work, 2 the LDS
                                                     # requests and waits, 4 the MFMAs, 8 the address upkeep
 
@@ -31,12 +36,12 @@ class Emit:
 
     def asm(self, text, outs=(), ins=()):
         op = text.split()[0]
-        if ((ABL & 1 and op in ("v_exp_f32", "v_fma_f32", "v_add_f32", "v_cvt_pk_bf16_f32")) or (ABL & 2 and (op == "ds_read_b128" or "lgkmcnt" in text)) or
+        if ((ABL & 1 and op in ("v_exp_f32", "v_fma_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_cvt_pk_bf16_f32")) or (ABL & 2 and (op == "ds_read_b128" or "lgkmcnt" in text)) or
                 (ABL & 4 and op == MF) or (ABL & 8 and op == "v_add_u32")):
             return
         if ABL & 16 and op == "v_exp_f32":
             text = text.replace("v_exp_f32", "v_mov_b32")
-        if ABL & 32 and op in ("v_fma_f32", "v_add_f32", "v_cvt_pk_bf16_f32"):
+        if ABL & 32 and op in ("v_fma_f32", "v_add_f32", "v_pk_fma_f32", "v_pk_add_f32", "v_cvt_pk_bf16_f32"):
             return
         ops = list(outs) + list(ins)
         for i, (nm, _, _) in enumerate(ops):
@@ -98,23 +103,34 @@ def substep(par):
             dblk = (s - 17) >> 1
             E.asm(f"ds_read_b128 {{d}}, {{a}} offset:{dblk * 4096}", [("d", "+v", f"vh1[{dblk}]")], [("a", "v", f"vaddr[{par * 2 + 1}]")])
             queue.append(f"h{dblk}")
-        # ---- VALU: exp of element s + 1 (its argument was formed one slot earlier: an fma feeding the exp directly costs a wait
-        #      state), argument of element s + 2, sum of element s, pack of the pair before ---------------------------------------
-        E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt[{(s + 1) & 3}]")], [("t", "v", f"tt[{(s + 1) & 1}]")])
-        if s < 30:
-            _, lb, lg = elem(s + 2)
-            src = f"cur[{lb}][{lg}]"
+        # ---- VALU, in PAIRS of scores (registers 2p, 2p + 1 of a tile are two consecutive keys of one query): pair p owns slots 2p
+        #      and 2p + 1.  even slot: exp of pair p + 1's first score, sum of pair p.  odd slot: arguments of pair p + 2 (first: an fma
+        #      feeding an exp within two instructions costs a wait state), exp of pair p + 1's second score, bf16 pack of pair p.
+        p = s >> 1
+        half, pb, g = elem(2 * p)
+        if s % 2 == 0:
+            E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[{(p + 1) & 1}][0]")], [("t", "v", f"tt2[{(p + 1) & 1}][0]")])
+            if PK:
+                E.asm("v_pk_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum2[{pb}]")], [("p", "v", f"pt2[{p & 1}]")])
+            else:
+                for j in range(2):
+                    E.asm("v_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum2[{pb}][{j}]")], [("p", "v", f"pt2[{p & 1}][{j}]")])
         else:
-            lb, src = 0, f"nxt[0][{s - 30}]"
-        E.asm("v_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt[{s & 1}]")], [("x", "v", src), ("sc", "s", "scale"), ("m", "v", f"negm[{lb}]")])
-        _, cb, _ = elem(s)
-        E.asm("v_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum[{cb}]")], [("p", "v", f"pt[{s & 3}]")])
-        if s % 2 == 0:                # pack the pair (s - 2, s - 1); slot 0: the previous substep's last pair
-            e1 = (s - 1) % 32
-            half, pb, g = elem(e1)
-            w = (g & 7) >> 1
-            E.asm("v_cvt_pk_bf16_f32 {d}, {p0}, {p1}", [("d", "+v" if True else "=v", f"pf{half}[{pb}][{w}]")],
-                  [("p0", "v", f"pt[{(s - 2) & 3}]"), ("p1", "v", f"pt[{(s - 1) & 3}]")])
+            if p < 14:
+                _, lb, lg = elem(2 * (p + 2))
+                tile = f"cur[{lb}]"
+            else:
+                lb, lg, tile = 0, 2 * (p - 14), "nxt[0]"
+            if PK:
+                E.asm("v_pk_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt2[{p & 1}]")],
+                      [("x", "v", f"__builtin_shufflevector({tile}, {tile}, {lg}, {lg + 1})"), ("sc", "v", "scale2"), ("m", "v", f"negm2[{lb}]")])
+            else:
+                for j in range(2):
+                    E.asm("v_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt2[{p & 1}][{j}]")],
+                          [("x", "v", f"{tile}[{lg + j}]"), ("sc", "v", "scale2[0]"), ("m", "v", f"negm2[{lb}][0]")])
+            E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[{(p + 1) & 1}][1]")], [("t", "v", f"tt2[{(p + 1) & 1}][1]")])
+            E.asm("v_cvt_pk_bf16_f32 {d}, {p0}, {p1}", [("d", "+v", f"pf{half}[{pb}][{(g & 7) >> 1}]")],
+                  [("p0", "v", f"pt2[{p & 1}][0]"), ("p1", "v", f"pt2[{p & 1}][1]")])
         # ---- address upkeep: K addresses move to the next stage once this sub-tile's own K requests are out (even substeps);
         #      V addresses after the tile's last V request (odd substeps) ---------------------------------------------------------
         if par == 0 and 18 <= s < 26:
@@ -126,7 +142,7 @@ def substep(par):
 
 
 SIG = ("f32x16 (&cur)[2], f32x16 (&nxt)[2], const bf16x8 (&qf)[2][8], f32x16 (&o)[4][2], u32x4 (&ring)[4], u32x4 (&vh1)[4],\n"
-       "        u32x4 (&pf0)[2], u32x4 (&pf1)[2], float (&pt)[4], float (&tt)[2], float (&lsum)[2], const float (&negm)[2], float scale,\n"
+       "        u32x4 (&pf0)[2], u32x4 (&pf1)[2], f32x2 (&pt2)[2], f32x2 (&tt2)[2], f32x2 (&lsum2)[2], const f32x2 (&negm2)[2], f32x2 scale2,\n"
        "        unsigned (&kaddr)[8], unsigned (&vaddr)[4], int delta")
 
 
@@ -136,23 +152,24 @@ def gen():
 ''']
     out.append(f"template <int PAR>\n__device__ __forceinline__ void attn64_substep({SIG}) {{")
     out.append("    if constexpr (PAR == 0) {\n" + substep(0) + "\n    } else {\n" + substep(1) + "\n    }\n}\n")
-    # prime: ring units 0..2 of substep 0 (S of sub-tile 1: tile 0, keys 32..63), the look-ahead exp of element 0 and argument of element 1
+    # prime: ring units 0..2 of substep 0 (S of sub-tile 1: tile 0, keys 32..63), arguments of pairs 0 and 1, exps of pair 0
     E = Emit()
     for u in range(3):
         E.asm("ds_read_b128 {d}, {a} offset:8192", [("d", "+v", f"ring[{u}]")], [("a", "v", f"kaddr[{u}]")])
-    E.asm("v_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", "tt[0]")], [("x", "v", "cur[0][0]"), ("sc", "s", "scale"), ("m", "v", "negm[0]")])
-    E.asm("v_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", "tt[1]")], [("x", "v", "cur[0][1]"), ("sc", "s", "scale"), ("m", "v", "negm[0]")])
-    E.asm("v_exp_f32 {p}, {t}", [("p", "=v", "pt[0]")], [("t", "v", "tt[0]")])
-    out.append("__device__ __forceinline__ void attn64_prime(f32x16 (&cur)[2], u32x4 (&ring)[4], float (&pt)[4], float (&tt)[2], const float (&negm)[2], float scale,\n"
+    for pr in range(2):
+        for j in range(2):
+            E.asm("v_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt2[{pr}][{j}]")], [("x", "v", f"cur[0][{2 * pr + j}]"), ("sc", "v", "scale2[0]"), ("m", "v", "negm2[0][0]")])
+    for j in range(2):
+        E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[0][{j}]")], [("t", "v", f"tt2[0][{j}]")])
+    out.append("__device__ __forceinline__ void attn64_prime(f32x16 (&cur)[2], u32x4 (&ring)[4], f32x2 (&pt2)[2], f32x2 (&tt2)[2], const f32x2 (&negm2)[2], f32x2 scale2,\n"
                "                                             unsigned (&kaddr)[8]) {\n" + "\n".join(E.lines) + "\n}\n")
-    # tail: the last pair's pack; drains the LDS queue.  (The O += V P group of the last sub-tile's keys 16..31 that follows is
-    # written with MFMA builtins in mem_attn.hip: outside the loop the register allocator moves accumulator tuples around with
-    # v_accvgpr_* copies, and it pads wait states only around MFMAs it can see.)
+    # tail: drains the LDS queue.  (The O += V P group of the last sub-tile's keys 16..31 that follows is written with MFMA builtins
+    # in mem_attn.hip: outside the loop the register allocator moves accumulator tuples around with v_accvgpr_* copies, and it pads
+    # wait states only around MFMAs it can see.)
     E = Emit()
-    E.asm("v_cvt_pk_bf16_f32 {d}, {p0}, {p1}", [("d", "+v", "pf1[1][3]")], [("p0", "v", "pt[2]"), ("p1", "v", "pt[3]")])
     E.asm("s_waitcnt lgkmcnt(0)")
     E.asm("s_nop 1")
-    out.append("__device__ __forceinline__ void attn64_tail(u32x4 (&pf1)[2], float (&pt)[4]) {\n" + "\n".join(E.lines) + "\n}\n")
+    out.append("__device__ __forceinline__ void attn64_tail() {\n" + "\n".join(E.lines) + "\n}\n")
     return "\n".join(out)
 
 

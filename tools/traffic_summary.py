@@ -1,0 +1,45 @@
+"""Turns the four rocprofv3 --pmc passes of tools/traffic_pmc.sh into attn_traffic.json / conv_traffic.json (HBM-side bytes per launch).
+FETCH_SIZE / WRITE_SIZE are reported in KB per dispatch; on gfx950 FETCH_SIZE tallies the 128-B requests of 16-B/lane streams at 64 B,
+so it is doubled (MI355X_MICROARCH.md, HBM); WRITE_SIZE is exact."""
+import csv, glob, json, os, sys, collections
+
+out = sys.argv[1]
+
+
+def per_kernel(prefix, counter):
+    files = glob.glob(os.path.join(out, f"{prefix}_{counter}", "**", "*counter_collection.csv"), recursive=True)
+    assert files, (prefix, counter)
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(files[0])):
+        if r["Counter_Name"] == counter:
+            acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def summarise(prefix, want, note, algorithmic):
+    res, total = {}, 0.0
+    for counter, corr in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+        for k, vals in per_kernel(prefix, counter).items():
+            key = next((w for w in want if w in k), None)
+            if key is None:
+                continue
+            calls = vals[-want[key]:] if want[key] else vals        # the last launches (steady state)
+            kb = sum(calls) / len(calls)
+            res.setdefault(key, {})[counter + "_KB_raw"] = round(kb, 1)
+            total += kb * 1024 * corr
+    return dict(kernels=res, correction="gfx950: FETCH_SIZE x2 (128-B requests of 16-B/lane streams counted at 64 B); WRITE_SIZE exact",
+                hbm_bytes_per_launch=int(total), algorithmic_bytes_per_launch=algorithmic, ratio=round(total / algorithmic, 2), note=note,
+                source="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/traffic_pmc.sh)")
+
+
+attn = summarise("attn", {"mem_attn64_kernel": 3, "mem_attn_kernel": 3, "attn_combine_kernel": 3},
+                 "one ppms_mem_attn call at the 1/4 scale (T=5, n=10240, 5 picked frames): attention kernel + fix-up pass + combine kernel, mean of the last 3 calls",
+                 157286400)
+json.dump(attn, open(os.path.join(out, "attn_traffic.json"), "w"), indent=1)
+# zr1_0 at the 1/4 scale: activations [h | x] 512 ch + output 256 ch as split bf16 planes (4 B per value), weights 256x512x15 x 4 B, aux reads
+P = 5 * 80 * 128
+conv_alg = P * (512 + 256) * 4 + 256 * 512 * 15 * 4
+conv = summarise("conv", {"conv5_kernel": 3, "conv3_kernel": 3}, "one zr1_0 launch (1,1,15), 512 -> 256 channels, 5x80x128 pixels; mean of the last 3 launches", conv_alg)
+json.dump(conv, open(os.path.join(out, "conv_traffic.json"), "w"), indent=1)
+print(json.dumps(attn)[:600])
+print(json.dumps(conv)[:600])
