@@ -33,6 +33,13 @@ BASELINE_CONFIGS = {(5, 320, 512, 10): "BASELINE config 2", (5, 736, 1280, 20): 
                     (40, 320, 512, 20): "BASELINE config 4 (one T=40 window)", (40, 736, 1280, 20): "BASELINE config 5 (one T=40 window)"}
 
 
+def _latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round (committed PMC summaries, tools/traffic_pmc.sh), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return files[-1] if files else None
+
+
 def cpu_baseline(T, H, W, iters, threads):
     """The oracle (a CPU restatement of the reference path) timed on a bounded sample of the same workload: ONE
     iteration of forward_update_block at each of the three scales plus the three pyramid builds, extrapolated with the
@@ -148,13 +155,13 @@ def main():
                                         tflops=round(fl / (sum(ms) / len(ms) * 1e-3) / 1e12, 1))
         ach = tot_flop / (tot_ms * 1e-3) / 1e12
         traffic = None            # HBM bytes per 1/4-scale launch from the committed PMC passes (same kernel, same shape), if present
-        tfile = os.path.join(ROOT, "profiles", "attn_traffic.json")
-        if os.path.exists(tfile) and (T, H, W) == (5, 320, 512):
+        tfile = _latest_profile("attn_traffic.json")
+        if tfile and (T, H, W) == (5, 320, 512):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
         roofs.append(dict(bound="mfma", kernel="memory attention = one ppms_mem_attn call (attention kernel + combine), every call of the timed region "
                                                "(3 scales: 1/16, 1/8, 1/4); algorithmic FLOPs = sum over launches of 4*n*(k*n)*128*T",
                           achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
-                          traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
+                          traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/rNN_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
                           launches=n_launch, avg_ms=round(tot_ms / n_launch, 4), total_ms_per_step=round(tot_ms / args.steps, 3),
                           flop_per_launch=tot_flop / n_launch, per_scale=per_scale))
         # ---- large-map conv kernels: algorithmic FLOPs of a launch = 2 * pixels * couts * cin * taps from its descriptor
@@ -174,15 +181,15 @@ def main():
             if c_n:
                 cach = c_flop / (c_ms * 1e-3) / 1e12
                 ctraffic = None
-                tfile = os.path.join(ROOT, "profiles", "conv_traffic.json")
-                if os.path.exists(tfile) and (T, H, W) == (5, 320, 512):
+                tfile = _latest_profile("conv_traffic.json")
+                if tfile and (T, H, W) == (5, 320, 512):
                     ctraffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
                 roofs.append(dict(bound="mfma", kernel="conv5_kernel / conv3_kernel (large-map implicit-GEMM convolutions, bf16x3 split MFMA; per_op names the kernel), "
                                                        "every launch of the timed region; "
                                                        "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / 3 (three MFMAs per product)",
                                   achieved=round(cach, 2), peak=round(CONV_BOUND_TFLOPS, 1), unit="TFLOP/s", frac=round(cach / CONV_BOUND_TFLOPS, 4),
                                   frac_of_bf16_dense=round(cach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=ctraffic,
-                                  traffic_note="HBM bytes of ONE zr1_0 launch at the 1/4 scale, profiles/conv_traffic.json",
+                                  traffic_note="HBM bytes of ONE zr1_0 launch at the 1/4 scale, profiles/rNN_conv_traffic.json",
                                   launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / args.steps, 3),
                                   flop_per_launch=c_flop / c_n, per_op=per_op))
         roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first
