@@ -245,6 +245,21 @@ def test_full_config_properties(model):
     assert d1.abs().max() < 4 * Wd
 
 
+def test_cascade_is_bit_stable_over_many_runs(model):
+    """25 back-to-back config-2 cascades (two-stream branches of every iteration, the once-per-scale hoist stream overlapping the
+    first iteration, 200+ launches per iteration queued far ahead of the GPU) give ONE result: guards against any
+    ordering / hazard dependence between concurrent kernels (the packed-fp32 finding of round 1 showed up only this way)."""
+    T, H, Wd = 5, 320, 512
+    feats = {k: v.to(DEV) for k, v in synth_cascade_feats(T, H, Wd).items()}
+    d0, c0 = model.cascade(feats, 10, T, test_mode=True)
+    d0, c0 = d0.clone(), c0.clone()
+    bad = 0
+    for _ in range(25):
+        d, c = model.cascade(feats, 10, T, test_mode=True)
+        bad += int(not (torch.equal(d, d0) and torch.equal(c, c0)))
+    assert bad == 0, f"{bad} of 25 runs differ"
+
+
 def test_attention_is_a_convex_combination(model):
     """Softmax-weighted aggregation property at full 1/4-scale size (n = 10240, 5 frames): with V == const vector c per
     channel the output must equal bf16(c) whatever Q, K are."""

@@ -1,7 +1,8 @@
 """GPU robustness: the small kernels must give bit-identical results whether or not another stream keeps the CUs busy with a
 conv kernel (the engine runs independent branches of an iteration on two HIP streams).  Regression test for the packed-fp32
 issue described in ppmstereo_amd/build.py: built with v_pk_*_f32, ppms_bilinear dropped one tap in lanes 48-63 of some waves
-under exactly this load."""
+under exactly this load.  The library is now built without packed fp32 code generation in every source; this test keeps
+watch (200 repetitions per small kernel: the original failure showed in a few percent of the launches)."""
 import pytest
 import torch
 
@@ -23,7 +24,7 @@ def eng():
     return e
 
 
-def _mismatches(eng, fn, heavy=("m1", "m2"), n=25):
+def _mismatches(eng, fn, heavy=("m1", "m2"), n=200):
     side = torch.cuda.Stream()
     ref = fn().clone()
     torch.cuda.synchronize()
@@ -73,7 +74,7 @@ def test_small_kernels_are_unaffected_by_a_concurrent_conv(eng):
         L.check(lib.ppms_layernorm(x.data_ptr(), 384, wgt.data_ptr(), bias.data_ptr(), L.SP(None, None, 0, 0), out.view(), eng.P, 384, L.stream_ptr()))
         return out.to_f32()
 
-    # the memory attention keeps packed fp32 ops (build.py): same stress
+    # the memory attention kernels (hand-scheduled loop; scalar fp32 ops): same stress
     n = eng.n
     qb = hash_normal((T, n, 128), 950).to(torch.bfloat16).to(DEV)
     kb = hash_normal((T, 5, n, 128), 951).to(torch.bfloat16).to(DEV)
@@ -97,6 +98,6 @@ def test_small_kernels_are_unaffected_by_a_concurrent_conv(eng):
              "bilinear(align_corners)": lambda: bilinear(rnd, (4 * h, 4 * w), True), "convex_upsample": cvx, "nhwc_to_nchw": to_nchw,
              "dwconv_gelu": dw, "layernorm": ln, "conv q1 (other conv concurrent)": lambda: (eng.op["q1"](), eng.Hb[1].to_f32())[1]}
     bad = {name: _mismatches(eng, fn) for name, fn in cases.items()}
-    bad["mem_attn 64-query + combine"] = _mismatches(eng, attn(True), heavy=("zr1_0", "m1", "zr2"), n=8)
-    bad["mem_attn 32-query fused"] = _mismatches(eng, attn(False), heavy=("zr1_0", "m1", "zr2"), n=6)
+    bad["mem_attn 64-query + combine"] = _mismatches(eng, attn(True), heavy=("zr1_0", "m1", "zr2"), n=30)
+    bad["mem_attn 32-query fused"] = _mismatches(eng, attn(False), heavy=("zr1_0", "m1", "zr2"), n=12)
     assert all(v == 0 for v in bad.values()), f"results change under a concurrent conv kernel: {bad}"
