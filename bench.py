@@ -135,7 +135,7 @@ def main():
         b.record()
     torch.cuda.synchronize()
     D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
     step_ms = [a.elapsed_time(b) for a, b in step_ev]
 
     px = T * H * W

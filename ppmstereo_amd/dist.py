@@ -48,8 +48,8 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:          # RCCL on GPUs; PPMS_DIST_BACKEND=gloo rehearses the multi-rank paths on a box with fewer GPUs than ranks
+            backend = os.environ.get("PPMS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
