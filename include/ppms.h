@@ -191,6 +191,23 @@ int ppms_avgpool(const float* src, float* dst, int planes, int H, int W, int k, 
 int ppms_axpby(const float* x, const float* y, float* out, float a, float b, int64_t period, int64_t n, void* stream);
 int ppms_ctx_mix(const float* fmap, const float* ctx, float* net, float* inp, int N, int HW, void* stream);
 
+/* ---------------------------------------------------------------- feature encoder (fnet) pieces
+ * BasicEncoder(output_dim=256, norm_fn="instance"), extractor.py:302-423.  Its convolutions run on
+ * ppms_conv_gemm2 / ppms_conv_gemm5; the stride-2 layers (extractor.py:306-308, 341-343, 366) as stride-1 convolutions over a
+ * 2x2 space-to-depth copy of their input: dst[(n, i, j)][(2 dy + dx) * C + c] = src[(n, 2 i + dy, 2 j + dx)][c].
+ * ppms_img_s2d: src = the NCHW fp32 image batch (N, C, H, W) handed to fnet (extractor.py:400-405); channels >= 4 C of dst are
+ * zeroed.  ppms_sp_s2d: src, dst split-plane views, dst.c == 4 * src.c.  H, W even. */
+int ppms_img_s2d(const float* img_nchw, ppms_sp dst, int N, int C, int H, int W, void* stream);
+int ppms_sp_s2d(ppms_sp src, ppms_sp dst, int N, int H, int W, void* stream);
+/* nn.InstanceNorm2d(affine=False) (extractor.py:326-329, 364): per (sample, channel) mean and 1 / sqrt(biased var + eps) over the
+ * HW pixels of x (channel-last fp32 [N * HW][ld], a convolution's fp32 output) -> stats[N][C][2] (pixel slices merged in fixed
+ * order: deterministic; caller-owned workspace of ppms_instnorm_workspace_bytes); then
+ * out = relu?( (x - mean) * rstd + res? ) as split planes (res: optional residual view, e.g. relu(x + y) of extractor.py:345;
+ * channels >= C of out are zeroed). */
+int64_t ppms_instnorm_workspace_bytes(int N, int HW, int C);       /* per-slice partial statistics of ppms_instnorm_stats */
+int ppms_instnorm_stats(const float* x, int ld, int N, int HW, int C, float eps, float* stats, void* workspace, void* stream);
+int ppms_instnorm_apply(const float* x, int ld, const float* stats, ppms_sp res, int relu, ppms_sp out, int N, int HW, int C, void* stream);
+
 /* ---------------------------------------------------------------- pick-and-play memory attention */
 /* PPMStereo.compute_qk_similarity, ppmstereo.py:397-423.  q,k: fp32 [T][H*W][ld] channel-last (128 channels);
  * pooled: workspace fp32 [2][T][(H/4)*(W/4)]; sim: fp32 [T][T], sim[i][j] = cos(kbar_i, qbar_j). */

@@ -477,6 +477,38 @@ def pre_loop_glue(fmap1: Tensor, fmap2: Tensor, c4: Tensor, c8: Tensor, c16: Ten
     return feats
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# fnet: BasicEncoder(output_dim=256, norm_fn="instance") -- the producer of fmap1 / fmap2
+def _instance_norm(x: Tensor) -> Tensor:
+    """nn.InstanceNorm2d(planes, affine=False): per (sample, channel) over H x W, biased variance, eps 1e-5 (models/core/extractor.py:326-329, 364)."""
+    return F.instance_norm(x, eps=1e-5)
+
+
+def residual_block(W: Dict[str, Tensor], pre: str, x: Tensor, stride: int) -> Tensor:
+    """ResidualBlock.forward, models/core/extractor.py:337-345: the 1x1 projection + norm on the skip is applied ALWAYS (also at
+    stride 1 with equal planes), its norm is norm3 (:339-341)."""
+    y = F.relu(_instance_norm(F.conv2d(x, W[pre + "conv1.weight"], W[pre + "conv1.bias"], stride=stride, padding=1)))
+    y = F.relu(_instance_norm(F.conv2d(y, W[pre + "conv2.weight"], W[pre + "conv2.bias"], padding=1)))
+    x = _instance_norm(F.conv2d(x, W[pre + "downsample.0.weight"], W[pre + "downsample.0.bias"], stride=stride))
+    return F.relu(x + y)
+
+
+def basic_encoder(W: Dict[str, Tensor], x):
+    """BasicEncoder.forward, models/core/extractor.py:391-423 with the ctor of :349-389 (conv1 7x7 s2 p3, layer1 64 s1, layer2 96 s2,
+    layer3 128 s1, conv2 1x1 -> 256; dropout 0).  x: (N, 3, H, W) or a pair of such (batch concatenation :398-401, split back :419-420)."""
+    is_list = isinstance(x, (tuple, list))
+    if is_list:
+        x = torch.cat(list(x), dim=0)
+    x = F.relu(_instance_norm(F.conv2d(x, W["conv1.weight"], W["conv1.bias"], stride=2, padding=3)))
+    for layer, stride in ((1, 1), (2, 2), (3, 1)):
+        x = residual_block(W, f"layer{layer}.0.", x, stride)
+        x = residual_block(W, f"layer{layer}.1.", x, 1)
+    x = F.conv2d(x, W["conv2.weight"], W["conv2.bias"])
+    if is_list:
+        return torch.split(x, x.shape[0] // 2, dim=0)
+    return x
+
+
 class InputPadder:
     """models/core/utils/utils.py:19-44 (mode "sintel"): replicate-pad H, W up to multiples of divis_by, split evenly."""
 

@@ -25,7 +25,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppms.so")
 STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
-SOURCES = ["corr.hip", "conv_gemm2.hip", "conv_gemm3.hip", "conv_gemm4.hip", "conv_gemm5.hip", "small_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
+SOURCES = ["corr.hip", "conv_gemm2.hip", "conv_gemm3.hip", "conv_gemm4.hip", "conv_gemm5.hip", "small_ops.hip", "encoder_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
 HEADERS = ["common.h", "conv_epilogue.h", "conv5_asm.h", "attn64_asm.h", os.path.join("..", "..", "include", "ppms.h")]
 # Packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32) are disabled (NO_PK): a wave of the bilinear resize kernel returned
 # wrong values in lanes 48-63 when an MFMA-heavy kernel of another stream shared its SIMD (DESIGN.md section 5,

@@ -235,15 +235,19 @@ class InputPadder:
 
 class PPMStereo(PPMStereoHotPath):
     """``models/core/ppmstereo.py:PPMStereo`` from the encoder outputs on: same constructor arguments, ``forward`` (:601-804)
-    and ``forward_batch_test`` (:238-320).  The encoders are outside the hot path: ``fnet`` /
-    ``cnet`` are modules the caller plugs in (the reference's ``BasicEncoder`` / ``Feature``, or any callable with the same
+    and ``forward_batch_test`` (:238-320).  The encoders are outside the hot path: ``fnet``
+    defaults to this package's HIP ``BasicEncoder`` (``ppmstereo_amd/encoder.py``, row f3; ``fnet=False`` leaves it unset),
+    ``cnet`` is a module the caller plugs in (the reference's ``Feature``, or any callable with the same
     contract: ``fnet([im1, im2]) -> (fmap1, fmap2)`` (BT,256,H/4,W/4), ``cnet(im1) -> (c4, c8, c16)`` with 256 channels);
     ``sst`` stands for ``forward_sst_block`` (:322-395) and defaults to its ``attention_type=None`` behaviour (positional
     encoding only).  Everything between the encoders and the returned disparity runs on the gfx950 kernels."""
 
     def __init__(self, *args, fnet=None, cnet=None, sst=None, **kwargs):
         super().__init__(*args, **kwargs)
-        self.fnet, self.cnet, self.sst = fnet, cnet, sst
+        if fnet is None:                                       # the reference builds it in its ctor (ppmstereo.py:64)
+            from .encoder import BasicEncoder
+            fnet = BasicEncoder(output_dim=256, norm_fn="instance")
+        self.fnet, self.cnet, self.sst = (None if fnet is False else fnet), cnet, sst
         self.dim = 256
         self._pe_cache: Dict[tuple, torch.Tensor] = {}
 

@@ -96,6 +96,28 @@ def att_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
     return OrderedDict([("to_qk.weight", (256, 128, 1, 1))])
 
 
+def fnet_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict of the reference's fnet, BasicEncoder(output_dim=256, norm_fn="instance"), in its registration order
+    (/root/reference/models/core/extractor.py:349-389 and :303-341; InstanceNorm2d(affine=False) has no entries; the skip's
+    1x1 conv is downsample.0)."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["conv1.weight"], s["conv1.bias"] = (64, 3, 7, 7), (64,)
+    cin = 64
+    for layer, dim in ((1, 64), (2, 96), (3, 128)):
+        for blk in range(2):
+            pre = f"layer{layer}.{blk}."
+            s[pre + "conv1.weight"], s[pre + "conv1.bias"] = (dim, cin, 3, 3), (dim,)
+            s[pre + "conv2.weight"], s[pre + "conv2.bias"] = (dim, dim, 3, 3), (dim,)
+            s[pre + "downsample.0.weight"], s[pre + "downsample.0.bias"] = (dim, cin, 1, 1), (dim,)
+            cin = dim
+    s["conv2.weight"], s["conv2.bias"] = (256, 128, 1, 1), (256,)
+    return s
+
+
+def fnet_weights(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    return procedural_state_dict(fnet_param_shapes(), "fnet.", seed)
+
+
 def _gen(name: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
     rng = np.random.Generator(np.random.PCG64([zlib.crc32(name.encode()), seed]))
     x = rng.standard_normal(size=shape, dtype=np.float64)

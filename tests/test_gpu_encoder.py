@@ -1,0 +1,69 @@
+"""the HIP fnet (ppmstereo_amd/encoder.py) against the reference's own BasicEncoder outputs
+(tests/golden/fnet_*.npz, written by tools/gen_golden.py from /root/reference/models/core/extractor.py:348-423) and against the CPU oracle at
+the benchmark's image size."""
+import time
+
+import pytest
+import torch
+
+from golden_util import Golden
+from ppmstereo_amd import weights as Wm
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def fnet():
+    assert torch.cuda.is_available()
+    from ppmstereo_amd.encoder import BasicEncoder
+    m = BasicEncoder(output_dim=256, norm_fn="instance")
+    m.load_state_dict(Wm.fnet_weights(), strict=True)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("name,n,hh,ww", [("fnet_small", 2, 64, 96), ("fnet_odd", 1, 40, 72)])
+def test_fnet_vs_reference_golden(fnet, name, n, hh, ww):
+    g = Golden(name)
+    i1, i2 = Wm.hash_uniform((n, 3, hh, ww), 600 + hh).to(DEV), Wm.hash_uniform((n, 3, hh, ww), 700 + hh).to(DEV)
+    f1, f2 = fnet([i1, i2])
+    assert f1.shape == (n, 256, hh // 4, ww // 4) and f2.shape == f1.shape
+    # fp32-accurate convolutions (bf16x3 split) through 14 conv + InstanceNorm layers: a few 1e-5 of the feature range
+    g.check("fmap1", f1, 2e-4, 2e-4)
+    g.check("fmap2", f2, 2e-4, 2e-4)
+    # single-tensor call (extractor.py:396-397: no list) == first half of the pair call; and bit-reproducible
+    assert torch.equal(fnet(i1), fnet(i1))
+    assert (fnet(i1) - f1).abs().max() < 1e-6
+
+
+def test_fnet_full_size_vs_oracle(fnet):
+    """BASELINE config 2 images: T = 5 frames of 320 x 512, left + right = 10 images in one call (ppmstereo.py:618)."""
+    from oracle import ppm_oracle as O
+    T, H, W = 5, 320, 512
+    i1, i2 = Wm.hash_uniform((T, 3, H, W), 611), Wm.hash_uniform((T, 3, H, W), 612)
+    torch.set_num_threads(16)
+    r1, r2 = O.basic_encoder(Wm.fnet_weights(), [i1, i2])
+    d1, d2 = i1.to(DEV), i2.to(DEV)
+    f1, f2 = fnet([d1, d2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        f1, f2 = fnet([d1, d2])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    print(f"fnet, 10 images of 320x512 (326 GFLOP): {ms:.2f} ms per call")
+    for f, r in ((f1, r1), (f2, r2)):
+        err = (f.cpu() - r).abs()
+        assert torch.isfinite(f).all()
+        assert err.max() < 3e-4 * max(1.0, r.abs().max().item()), (err.max().item(), r.abs().max().item())
+        assert err.mean() < 2e-5 * max(1.0, r.abs().mean().item() * 10), err.mean().item()
+
+
+def test_fnet_rejects_what_it_does_not_support(fnet):
+    from ppmstereo_amd.encoder import BasicEncoder
+    with pytest.raises(NotImplementedError):
+        BasicEncoder(norm_fn="batch")
+    with pytest.raises(RuntimeError):
+        fnet(torch.zeros(1, 3, 64, 64))                       # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        fnet(torch.zeros(1, 3, 66, 64, device=DEV))

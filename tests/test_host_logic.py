@@ -217,3 +217,32 @@ def test_large_map_kernel_applicability():
     assert a(5, 80, 128, 128, (1, 1, 5), [128, 256]) == 0          # 200 workgroups: conv_gemm2 fills the chip better
     assert a(5, 80, 128, 192, (1, 3, 3), [256]) == 0               # M not a multiple of 128 (the engine pads such convs)
     assert a(5, 40, 64, 256, (1, 1, 15), [128, 256]) == 0          # 1/8 scale: too few tiles
+
+
+def test_fnet_state_dict_is_the_reference_layout():
+    """ppmstereo_amd.encoder.BasicEncoder exposes the reference's parameter names, shapes and ORDER (extractor.py:349-389, 303-341;
+    tools/gen_golden.py additionally loads these weights into the reference module with strict=True)."""
+    from ppmstereo_amd import weights as Wm
+    from ppmstereo_amd.encoder import BasicEncoder
+    m = BasicEncoder(output_dim=256, norm_fn="instance")
+    shapes = Wm.fnet_param_shapes()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(shapes.keys())
+    assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+    assert abs(sum(v.numel() for v in sd.values()) - 1.10e6) < 0.01e6      # SURVEY.md appendix: fnet 1.10 M parameters
+    m.load_state_dict(Wm.fnet_weights(), strict=True)
+
+
+@pytest.mark.parametrize("k,pad,cin,cout,h,w", [(7, 3, 3, 8, 20, 28), (3, 1, 16, 12, 12, 16), (1, 0, 8, 8, 10, 14)])
+def test_stride2_conv_as_space_to_depth_conv(k, pad, cin, cout, h, w):
+    """The host-side weight re-layout behind the HIP fnet's stride-2 layers: conv(x, w, stride 2, padding p) == a stride-1 'same'
+    conv of the re-laid kernel over the 2x2 space-to-depth input (channel (2 dy + dx) * cin + c), exactly (same products, fp32)."""
+    import torch.nn.functional as F
+    from ppmstereo_amd.encoder import _s2d_weight
+    from ppmstereo_amd.weights import hash_normal
+    x, wt = hash_normal((2, cin, h, w), 5).double(), hash_normal((cout, cin, k, k), 6).double()
+    ref = F.conv2d(x, wt, stride=2, padding=pad)
+    xs = x.reshape(2, cin, h // 2, 2, w // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(2, 4 * cin, h // 2, w // 2)     # (dy, dx, c) major
+    w2 = _s2d_weight(wt, pad)
+    got = F.conv2d(xs, w2, padding=w2.shape[-1] // 2)
+    assert got.shape == ref.shape and (got - ref).abs().max() < 1e-12

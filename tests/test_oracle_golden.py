@@ -175,3 +175,15 @@ def test_window_plan():
     assert keep(25, 20) == [(0, 14), (15, 24)]
     assert keep(150, 20)[0] == (0, 14) and keep(150, 20)[-1] == (145, 149)
     assert keep(40, 10)[:3] == [(0, 6), (7, 11), (12, 16)] and keep(40, 10)[-1] == (37, 39)
+
+
+@pytest.mark.parametrize("name,n,hh,ww", [("fnet_small", 2, 64, 96), ("fnet_odd", 1, 40, 72)])
+def test_fnet_basic_encoder(name, n, hh, ww):
+    """the oracle's BasicEncoder restatement against the reference's own fnet (extractor.py:348-423), a pair of
+    image batches through the batch-concatenated call (:398-401); 40 x 72 gives odd 1/2-resolution maps (20 x 36 -> 10 x 18)."""
+    g = Golden(name)
+    i1, i2 = Wm.hash_uniform((n, 3, hh, ww), 600 + hh), Wm.hash_uniform((n, 3, hh, ww), 700 + hh)
+    f1, f2 = O.basic_encoder(Wm.fnet_weights(), [i1, i2])
+    assert f1.shape == (n, 256, hh // 4, ww // 4)
+    g.check("fmap1", f1, 2e-5, 1e-5)
+    g.check("fmap2", f2, 2e-5, 1e-5)

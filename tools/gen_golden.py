@@ -66,10 +66,11 @@ sys.modules.update({"timm": _timm, "timm.models": _tm, "timm.models.layers": _tl
 from models.core import corr as rcorr                      # noqa: E402
 from models.core import ppmtereo_update as rupd            # noqa: E402
 from models.core import ppmstereo as rppm                  # noqa: E402
+from models.core import extractor as rext                  # noqa: E402
 
 from ppmstereo_amd import weights as Wm                    # noqa: E402
 from ppmstereo_amd.synth import T40_CASES, synth_scale_inputs   # noqa: E402
-from ppmstereo_amd.weights import hash_normal              # noqa: E402
+from ppmstereo_amd.weights import hash_normal, hash_uniform  # noqa: E402
 
 ATTN_LOG = []
 
@@ -272,6 +273,16 @@ def main():
         fo, net, mhs = m3.forward_update_block(None, getattr(m3, tag), cb, d["flow"], d["net"], d["inp"], d["mhs"], m3.att[ai],
                                                preds, uncs, iters, isc, T)
         save(name, flow_out=fo, net=net, mhs=mhs, preds=torch.stack(preds), uncs=torch.stack(uncs))
+
+    # ---- G10: fnet = BasicEncoder(output_dim=256, norm_fn="instance") (extractor.py:348-423), as PPMStereo builds it (ppmstereo.py:64) ---
+    fnet = rext.BasicEncoder(output_dim=256, norm_fn="instance", dropout=0.0)
+    fnet.load_state_dict(Wm.fnet_weights(), strict=True)          # also proves key names / shapes / order == reference
+    assert list(fnet.state_dict().keys()) == list(Wm.fnet_param_shapes().keys())
+    fnet.eval()
+    for name, n, hh, ww in (("fnet_small", 2, 64, 96), ("fnet_odd", 1, 40, 72)):
+        i1, i2 = hash_uniform((n, 3, hh, ww), 600 + hh), hash_uniform((n, 3, hh, ww), 700 + hh)   # normalised images: [-1, 1]
+        f1, f2 = fnet([i1, i2])
+        save(name, fmap1=f1, fmap2=f2)
 
     # ---- G7: T == 1 -> NaN known answer (SURVEY.md hazard 1) ------------------------------------
     d = synth_scale_inputs(1, 8, 32, seed=81)
