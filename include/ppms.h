@@ -248,9 +248,10 @@ int ppms_pwchain_param_bytes(void);
 
 /* ---------------------------------------------------------------- update_block16 time / space attention pieces */
 /* TimeAttnBlock core (ppmtereo_update.py:603-606 with Attention.forward :409-417): per pixel, tokens = its T frames;
- * y = LayerNorm(x); out_t = sum_t2 softmax(y_t . y_t2 / sqrt(48)) y_t2 per head (q = k = v = y).  x, out: SP, 384 channels. */
+ * y = LayerNorm(x); out_t = sum_t2 softmax(y_t . y_t2 / sqrt(48)) y_t2 per head (q = k = v = y).  x, out: SP, 384 channels
+ * (update_block16) or 256 (the SST block's TimeAttnBlock, ppmstereo.py:392-393). */
 int ppms_time_attn(ppms_sp x, const float* ln_w, const float* ln_b, ppms_sp out, int T, int n, int heads, void* stream);
-/* out = resid + LayerNorm(x) (resid.hi == NULL: no residual); x fp32 [pixel][ld]; C = 384 (attention.py:186-190) */
+/* out = resid + LayerNorm(x) (resid.hi == NULL: no residual); x fp32 [pixel][ld]; C = 384 or 256 (attention.py:186-190) */
 int ppms_layernorm(const float* x, int ld, const float* w, const float* b, ppms_sp resid, ppms_sp out, int64_t pixels, int C, void* stream);
 /* LinearAttention.forward (attention.py:73-100) per frame and head: Q, K already elu()+1, V already / n;
  * kv_ws: fp32 workspace of 4*T*heads*dh*(dh+1) floats; out (SP) = (Q KV) / (Q . sum K + 1e-6) * n */

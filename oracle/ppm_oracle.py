@@ -450,6 +450,34 @@ def position_encoding_sine(d_model: int, h: int, w: int) -> Tensor:
     return pe
 
 
+def sst_block(W: Dict[str, Tensor], f1: Tensor, f2: Tensor, T: int, depth: int = 4, num_frames: int = 5):
+    """PPMStereo.forward_sst_block with attention_type "self_stereo_temporal_update_time_update_space", ppmstereo.py:322-395, on the 1/16
+    features (BT, 256, h, w) of both views: + PositionEncodingSine, + time_embed (nearest-interpolated along T when T != num_frames,
+    :347-352), then depth x { "self" LoFTR layer on each view, "cross" layer (the second call sees the UPDATED first view,
+    attention.py:230-232), TimeAttnBlock(256) on each view }.  W: keys of ppmstereo_amd.weights.sst_param_shapes()."""
+    BT, C, h, w = f1.shape
+    pe = position_encoding_sine(C, h, w)
+    te = W["time_embed"]
+    if T != num_frames:
+        te = F.interpolate(te.transpose(1, 2), size=T, mode="nearest").transpose(1, 2).contiguous()
+    b = BT // T
+    add_te = lambda x: (x.reshape(b, T, C, h, w) + te[0][None, :, :, None, None]).reshape(BT, C, h, w)
+    x0, x1 = add_te(f1 + pe), add_te(f2 + pe)
+    tok = lambda x: x.reshape(BT, C, h * w).transpose(1, 2)
+    img = lambda t: t.transpose(1, 2).reshape(BT, C, h, w)
+    for i in range(depth):
+        p = f"self_attn_blocks.{i}.layers.0."
+        t0, t1 = tok(x0), tok(x1)
+        t0, t1 = loftr_layer(W, p, t0, t0), loftr_layer(W, p, t1, t1)
+        p = f"cross_attn_blocks.{i}.layers.0."
+        t0 = loftr_layer(W, p, t0, t1)
+        t1 = loftr_layer(W, p, t1, t0)
+        x0, x1 = img(t0), img(t1)
+        p = f"time_attn_blocks.{i}."
+        x0, x1 = time_attn(W, x0, T, p), time_attn(W, x1, T, p)
+    return x0, x1
+
+
 def pre_loop_glue(fmap1: Tensor, fmap2: Tensor, c4: Tensor, c8: Tensor, c16: Tensor, sst_fn=None, hdim: int = 128):
     """PPMStereo.forward between the encoders and the loop, ppmstereo.py:620-682.
     sst_fn(f1_16, f2_16) stands for forward_sst_block (:322-395); None = positional encoding only

@@ -1,6 +1,7 @@
 // update_block16's TimeAttnBlock / SpaceAttnBlock pieces that are not plain GEMMs
 // (/root/reference/models/core/ppmtereo_update.py:593-631 with Attention :400-420, and the LoFTR linear attention of
-// /root/reference/models/core/attention.py:73-100,164-190).  The Linear layers run on the implicit-GEMM kernel; these
+// /root/reference/models/core/attention.py:73-100,164-190) -- C = 384 there; the same kernels with C = 256 serve the SST block
+// of the 1/16 features (ppmstereo.py:322-395: LoFTR self / cross layers and TimeAttnBlock(256)).  The Linear layers run on the implicit-GEMM kernel; these
 // kernels are the LayerNorms, the per-pixel T x T temporal attention and the per-(frame, head) linear-attention sums.
 #include "common.h"
 
@@ -80,12 +81,17 @@ __global__ __launch_bounds__(64) void time_attn_kernel(ppms_sp x, const float* _
 
 extern "C" int ppms_time_attn(ppms_sp x, const float* ln_w, const float* ln_b, ppms_sp out, int T, int n, int heads, void* stream) {
     PPMS_REQUIRE(x.hi && x.lo && out.hi && out.lo && ln_w && ln_b, "time_attn: null operand");
-    PPMS_REQUIRE(x.c == 384 && out.c == 384 && heads == 8, "time_attn: C = 384, 8 heads (update_block16) expected, got C=%d heads=%d", x.c, heads);
+    PPMS_REQUIRE((x.c == 384 || x.c == 256) && out.c == x.c && heads == 8,
+                 "time_attn: C = 384 (update_block16) or 256 (SST block), 8 heads expected, got C=%d heads=%d", x.c, heads);
     PPMS_REQUIRE(T >= 1 && T <= 64 && n >= 1, "time_attn: bad T=%d n=%d", T, n);
     const int lanes_per_head = 64 / heads;
     const float scale = 1.0f / sqrtf((float)(x.c / heads));
-    hipLaunchKernelGGL(time_attn_kernel<6>, dim3(n), dim3(64), (size_t)T * 384 * 4, (hipStream_t)stream, x, ln_w, ln_b, out, T, n, lanes_per_head,
-                       scale);
+    if (x.c == 384)
+        hipLaunchKernelGGL(time_attn_kernel<6>, dim3(n), dim3(64), (size_t)T * 384 * 4, (hipStream_t)stream, x, ln_w, ln_b, out, T, n, lanes_per_head,
+                           scale);
+    else
+        hipLaunchKernelGGL(time_attn_kernel<4>, dim3(n), dim3(64), (size_t)T * 256 * 4, (hipStream_t)stream, x, ln_w, ln_b, out, T, n, lanes_per_head,
+                           scale);
     return ppms_check_launch("time_attn");
 }
 
@@ -125,24 +131,32 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 extern "C" int ppms_layernorm(const float* x, int ld, const float* w, const float* b, ppms_sp resid, ppms_sp out, int64_t pixels, int C,
                               void* stream) {
-    PPMS_REQUIRE(x && w && b && out.hi && out.lo && C == 384 && ld >= C, "layernorm: C = 384 expected (got %d)", C);
-    hipLaunchKernelGGL(layernorm_kernel<6>, dim3(ceil_div(pixels, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, w, b, resid, out, pixels);
+    PPMS_REQUIRE(x && w && b && out.hi && out.lo && (C == 384 || C == 256) && ld >= C, "layernorm: C = 384 or 256 expected (got %d)", C);
+    if (C == 384)
+        hipLaunchKernelGGL(layernorm_kernel<6>, dim3(ceil_div(pixels, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, w, b, resid, out, pixels);
+    else
+        hipLaunchKernelGGL(layernorm_kernel<4>, dim3(ceil_div(pixels, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, w, b, resid, out, pixels);
     return ppms_check_launch("layernorm");
 }
 
 // ------------------------------------------------------------------------------------------------ linear attention
 // kv[f][hd][d][v] = sum_s K[f,s,hd,d] V[f,s,hd,v];  ksum[f][hd][d] = sum_s K[f,s,hd,d].
 // Grid (head, frame, pixel split): each workgroup reduces n/NSPLIT pixels into its own partial (fixed order: deterministic),
-// each thread owns a 3 x 3 block of the 48 x 48 outer product (6 LDS reads per 9 FMAs).
+// each thread owns a B x B block of the DH x DH outer product, B = DH / 16 (DH = 48: 6 LDS reads per 9 FMAs; DH = 32: 4 per 4).
 constexpr int LA_NSPLIT = 4;
+template <int DH>
 __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
                                                          float* __restrict__ kv, float* __restrict__ ksum, int n, int heads) {
-    constexpr int DH = 48, CH = 32;                    // pixels staged per pass
+    constexpr int CH = 32, B = DH / 16;                // pixels staged per pass; block edge per thread
     __shared__ float ks[CH][DH + 1], vs[CH][DH + 1];
     const int hd = blockIdx.x, f = blockIdx.y, sp_id = blockIdx.z;
     const int tid = threadIdx.x;
-    const int d0 = (tid >> 4) * 3, v0 = (tid & 15) * 3;
-    float acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    const int d0 = (tid >> 4) * B, v0 = (tid & 15) * B;
+    float acc[B][B];
+#pragma unroll
+    for (int i = 0; i < B; ++i)
+#pragma unroll
+        for (int j = 0; j < B; ++j) acc[i][j] = 0.0f;
     float ksacc = 0.0f;                                // threads 0..47
     const int per = (n + LA_NSPLIT - 1) / LA_NSPLIT;
     const int s_begin = sp_id * per, s_end = (s_begin + per < n) ? s_begin + per : n;
@@ -156,11 +170,16 @@ __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict
         }
         __syncthreads();
         for (int sp = 0; sp < CH; ++sp) {
-            const float k0 = ks[sp][d0], k1 = ks[sp][d0 + 1], k2 = ks[sp][d0 + 2];
-            const float a0 = vs[sp][v0], a1 = vs[sp][v0 + 1], a2 = vs[sp][v0 + 2];
-            acc[0][0] += k0 * a0; acc[0][1] += k0 * a1; acc[0][2] += k0 * a2;
-            acc[1][0] += k1 * a0; acc[1][1] += k1 * a1; acc[1][2] += k1 * a2;
-            acc[2][0] += k2 * a0; acc[2][1] += k2 * a1; acc[2][2] += k2 * a2;
+            float kk[B], aa[B];
+#pragma unroll
+            for (int i = 0; i < B; ++i) {
+                kk[i] = ks[sp][d0 + i];
+                aa[i] = vs[sp][v0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < B; ++i)
+#pragma unroll
+                for (int j = 0; j < B; ++j) acc[i][j] += kk[i] * aa[j];
         }
         if (tid < DH)
             for (int sp = 0; sp < CH; ++sp) ksacc += ks[sp][tid];
@@ -168,16 +187,17 @@ __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict
     }
     float* o = kv + (((int64_t)sp_id * gridDim.y + f) * heads + hd) * DH * DH;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < B; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) o[(d0 + i) * DH + v0 + j] = acc[i][j];
+        for (int j = 0; j < B; ++j) o[(d0 + i) * DH + v0 + j] = acc[i][j];
     if (tid < DH) ksum[(((int64_t)sp_id * gridDim.y + f) * heads + hd) * DH + tid] = ksacc;
 }
 
 // msg[f,l,hd,v] = (sum_d Q[f,l,hd,d] kv[f,hd,d,v]) * (1 / (Q . ksum + eps)) * n   (one workgroup = 32 pixels of one frame x head)
+template <int DH>
 __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ kv,
                                                             const float* __restrict__ ksum, ppms_sp out, int n, int heads, float eps) {
-    constexpr int DH = 48, PX = 32;
+    constexpr int PX = 32;
     __shared__ float kvs[DH][DH + 1], kss[DH], qs[PX][DH];
     const int hd = blockIdx.y, f = blockIdx.z, p0 = blockIdx.x * PX;
     const int tid = threadIdx.x;
@@ -217,11 +237,18 @@ __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restr
 
 extern "C" int ppms_linear_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* kv_ws, ppms_sp out,
                                      int T, int n, int heads, int dh, void* stream) {
-    PPMS_REQUIRE(Q && K && V && kv_ws && out.hi && out.lo && heads == 8 && dh == 48, "linear_attention: 8 heads x 48 channels expected");
+    PPMS_REQUIRE(Q && K && V && kv_ws && out.hi && out.lo && heads == 8 && (dh == 48 || dh == 32),
+                 "linear_attention: 8 heads x 48 (update_block16) or x 32 (SST block) channels expected");
     float* kv = kv_ws;
     float* ksum = kv_ws + (size_t)LA_NSPLIT * T * heads * dh * dh;
-    hipLaunchKernelGGL(linattn_kv_kernel, dim3(heads, T, LA_NSPLIT), dim3(256), 0, (hipStream_t)stream, K, ldk, V, ldv, kv, ksum, n, heads);
-    hipLaunchKernelGGL(linattn_apply_kernel, dim3(ceil_div(n, 32), heads, T), dim3(256), 0, (hipStream_t)stream, Q, ldq, kv, ksum, out, n, heads,
-                       1e-6f);
+    if (dh == 48) {
+        hipLaunchKernelGGL(linattn_kv_kernel<48>, dim3(heads, T, LA_NSPLIT), dim3(256), 0, (hipStream_t)stream, K, ldk, V, ldv, kv, ksum, n, heads);
+        hipLaunchKernelGGL(linattn_apply_kernel<48>, dim3(ceil_div(n, 32), heads, T), dim3(256), 0, (hipStream_t)stream, Q, ldq, kv, ksum, out, n, heads,
+                           1e-6f);
+    } else {
+        hipLaunchKernelGGL(linattn_kv_kernel<32>, dim3(heads, T, LA_NSPLIT), dim3(256), 0, (hipStream_t)stream, K, ldk, V, ldv, kv, ksum, n, heads);
+        hipLaunchKernelGGL(linattn_apply_kernel<32>, dim3(ceil_div(n, 32), heads, T), dim3(256), 0, (hipStream_t)stream, Q, ldq, kv, ksum, out, n, heads,
+                           1e-6f);
+    }
     return ppms_check_launch("linear_attention");
 }

@@ -239,17 +239,40 @@ class PPMStereo(PPMStereoHotPath):
     defaults to this package's HIP ``BasicEncoder`` (``ppmstereo_amd/encoder.py``, row f3; ``fnet=False`` leaves it unset),
     ``cnet`` is a module the caller plugs in (the reference's ``Feature``, or any callable with the same
     contract: ``fnet([im1, im2]) -> (fmap1, fmap2)`` (BT,256,H/4,W/4), ``cnet(im1) -> (c4, c8, c16)`` with 256 channels);
-    ``sst`` stands for ``forward_sst_block`` (:322-395) and defaults to its ``attention_type=None`` behaviour (positional
-    encoding only).  Everything between the encoders and the returned disparity runs on the gfx950 kernels."""
+    ``sst`` stands for ``forward_sst_block`` (:322-395): "auto" (default) follows the reference's ctor (:139-171) -- the HIP
+    ``SSTBlock`` (``ppmstereo_amd/sst.py``, row f4) when ``attention_type`` names "self_stereo" / "temporal", its parameters
+    registered under the reference's names (``time_embed``, ``time_attn_blocks``, ``self_attn_blocks``, ``cross_attn_blocks``);
+    ``None`` = the ``attention_type=None`` behaviour (positional encoding only); or any callable ``(f1_16, f2_16, T)``.
+    Everything between the images (minus cnet) and the returned disparity runs on the gfx950 kernels."""
 
-    def __init__(self, *args, fnet=None, cnet=None, sst=None, **kwargs):
+    def __init__(self, *args, fnet=None, cnet=None, sst="auto", **kwargs):
         super().__init__(*args, **kwargs)
+        at = kwargs.get("attention_type", args[3] if len(args) > 3 else "self_stereo_temporal_update_time_update_space")
+        if isinstance(sst, str) and sst == "auto":
+            sst = None
+            if at is not None and ("self_stereo" in at or "temporal" in at):
+                if not ("self_stereo" in at and "temporal" in at):
+                    raise NotImplementedError("SST block: attention types with both 'self_stereo' and 'temporal' (the shipped model) or neither")
+                from .sst import SSTBlock
+                blk = SSTBlock(dim=256, num_frames=self.num_frames)
+                self.time_embed = blk.time_embed                       # same objects, registered under the reference's names
+                self.time_attn_blocks, self.self_attn_blocks, self.cross_attn_blocks = blk.time_attn_blocks, blk.self_attn_blocks, blk.cross_attn_blocks
+                object.__setattr__(self, "_sst_impl", blk)           # (not a second registration of the same parameters)
+                sst = blk
         if fnet is None:                                       # the reference builds it in its ctor (ppmstereo.py:64)
             from .encoder import BasicEncoder
             fnet = BasicEncoder(output_dim=256, norm_fn="instance")
-        self.fnet, self.cnet, self.sst = (None if fnet is False else fnet), cnet, sst
+        self.fnet, self.cnet = (None if fnet is False else fnet), cnet
+        object.__setattr__(self, "sst", sst)
         self.dim = 256
         self._pe_cache: Dict[tuple, torch.Tensor] = {}
+
+    def load_state_dict(self, sd, strict: bool = True, **kw):
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        for m in (self.fnet, getattr(self, "_sst_impl", None)):       # packed weight copies are cached per module
+            if hasattr(m, "invalidate"):
+                m.invalidate()
+        return r
 
     # ------------------------------------------------------------------ pre-loop glue (ppmstereo.py:620-682)
     def _pe(self, h: int, w: int, device) -> torch.Tensor:

@@ -96,6 +96,34 @@ def att_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
     return OrderedDict([("to_qk.weight", (256, 128, 1, 1))])
 
 
+def sst_param_shapes(depth: int = 4, dim: int = 256, num_frames: int = 5) -> "OrderedDict[str, Tuple[int, ...]]":
+    """The SST block's parameters as they sit on the reference's PPMStereo (attention_type "self_stereo_temporal_..."), in
+    state_dict order: the module's own parameter first, then its children in registration order
+    (/root/reference/models/core/ppmstereo.py:139-171; TimeAttnBlock ppmtereo_update.py:593-601, LoFTREncoderLayer attention.py:140-162)."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    s["time_embed"] = (1, num_frames, dim)
+    for i in range(depth):
+        p = f"time_attn_blocks.{i}."
+        s[p + "temporal_attn.qkv.weight"] = (3 * dim, dim)      # dead parameter (never applied)
+        s[p + "temporal_attn.proj.weight"], s[p + "temporal_attn.proj.bias"] = (dim, dim), (dim,)
+        s[p + "temporal_fc.weight"], s[p + "temporal_fc.bias"] = (dim, dim), (dim,)
+        s[p + "temporal_norm1.weight"], s[p + "temporal_norm1.bias"] = (dim,), (dim,)
+    for kind in ("self_attn_blocks", "cross_attn_blocks"):
+        for i in range(depth):
+            p = f"{kind}.{i}.layers.0."
+            for n in ("q_proj", "k_proj", "v_proj", "merge"):
+                s[p + n + ".weight"] = (dim, dim)
+            s[p + "mlp.0.weight"] = (2 * dim, 2 * dim)
+            s[p + "mlp.2.weight"] = (dim, 2 * dim)
+            for n in ("norm1", "norm2"):
+                s[p + n + ".weight"], s[p + n + ".bias"] = (dim,), (dim,)
+    return s
+
+
+def sst_weights(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    return procedural_state_dict(sst_param_shapes(), "sst.", seed)
+
+
 def fnet_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
     """state_dict of the reference's fnet, BasicEncoder(output_dim=256, norm_fn="instance"), in its registration order
     (/root/reference/models/core/extractor.py:349-389 and :303-341; InstanceNorm2d(affine=False) has no entries; the skip's
@@ -130,6 +158,8 @@ def _gen(name: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
         return (0.02 * x).astype(np.float32)
     fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
     gain = 1.0
+    if name.endswith("time_embed"):
+        return (0.5 * x).astype(np.float32)                   # zero-init in the reference (ppmstereo.py:141): would mute the term
     if "temporal_fc" in name:
         gain = 0.3                                            # zero-init in the reference (ppmtereo_update.py:600)
     return (gain * x / np.sqrt(fan_in)).astype(np.float32)

@@ -187,3 +187,14 @@ def test_fnet_basic_encoder(name, n, hh, ww):
     assert f1.shape == (n, 256, hh // 4, ww // 4)
     g.check("fmap1", f1, 2e-5, 1e-5)
     g.check("fmap2", f2, 2e-5, 1e-5)
+
+
+@pytest.mark.parametrize("name,T,h,w", [("sst_T5", 5, 8, 12), ("sst_T3", 3, 6, 10)])
+def test_sst_block(name, T, h, w):
+    """the oracle's forward_sst_block restatement against the reference's own (ppmstereo.py:322-395 with its
+    LocalFeatureTransformer / TimeAttnBlock modules); T = 3 takes the time_embed interpolation branch."""
+    g = Golden(name)
+    a, b = hash_normal((T, 256, h, w), 810 + T), hash_normal((T, 256, h, w), 820 + T)
+    o1, o2 = O.sst_block(Wm.sst_weights(), a, b, T)
+    g.check("f1", o1, 5e-5, 1e-5)
+    g.check("f2", o2, 5e-5, 1e-5)

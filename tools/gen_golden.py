@@ -67,6 +67,7 @@ from models.core import corr as rcorr                      # noqa: E402
 from models.core import ppmtereo_update as rupd            # noqa: E402
 from models.core import ppmstereo as rppm                  # noqa: E402
 from models.core import extractor as rext                  # noqa: E402
+from models.core import attention as ratt                  # noqa: E402
 
 from ppmstereo_amd import weights as Wm                    # noqa: E402
 from ppmstereo_amd.synth import T40_CASES, synth_scale_inputs   # noqa: E402
@@ -283,6 +284,24 @@ def main():
         i1, i2 = hash_uniform((n, 3, hh, ww), 600 + hh), hash_uniform((n, 3, hh, ww), 700 + hh)   # normalised images: [-1, 1]
         f1, f2 = fnet([i1, i2])
         save(name, fmap1=f1, fmap2=f2)
+
+    # ---- G11: the SST block (forward_sst_block, ppmstereo.py:322-395) with the reference's own modules (ctor :139-171) ---------------
+    at = "self_stereo_temporal_update_time_update_space"
+    ms = bare_model(attention_type=at)
+    Ws = Wm.sst_weights()
+    ms.time_embed = nn.Parameter(torch.zeros(1, 5, 256))
+    ms.time_attn_blocks = nn.ModuleList([rupd.TimeAttnBlock(dim=256, num_heads=8) for _ in range(4)])
+    ms.self_attn_blocks = nn.ModuleList([ratt.LocalFeatureTransformer(d_model=256, nhead=8, layer_names=["self"], attention="linear") for _ in range(4)])
+    ms.cross_attn_blocks = nn.ModuleList([ratt.LocalFeatureTransformer(d_model=256, nhead=8, layer_names=["cross"], attention="linear") for _ in range(4)])
+    sst_keys = [k for k in ms.state_dict().keys() if k.split(".")[0] in ("time_embed", "time_attn_blocks", "self_attn_blocks", "cross_attn_blocks")]
+    assert sst_keys == list(Wm.sst_param_shapes().keys()), "SST state_dict order"
+    missing, unexpected = ms.load_state_dict(Ws, strict=False)
+    assert not unexpected and all(k.split(".")[0] not in ("time_embed", "time_attn_blocks", "self_attn_blocks", "cross_attn_blocks") for k in missing)
+    ms.eval()
+    for name, T, h, w in (("sst_T5", 5, 8, 12), ("sst_T3", 3, 6, 10)):          # T = 3: time_embed interpolation branch (:347-352)
+        a, b = hash_normal((T, 256, h, w), 810 + T), hash_normal((T, 256, h, w), 820 + T)
+        o1, o2 = ms.forward_sst_block(a, b, T)
+        save(name, f1=o1, f2=o2)
 
     # ---- G7: T == 1 -> NaN known answer (SURVEY.md hazard 1) ------------------------------------
     d = synth_scale_inputs(1, 8, 32, seed=81)
