@@ -195,9 +195,10 @@ int ppms_ctx_mix(const float* fmap, const float* ctx, float* net, float* inp, in
  * BasicEncoder(output_dim=256, norm_fn="instance"), extractor.py:302-423.  Its convolutions run on
  * ppms_conv_gemm2 / ppms_conv_gemm5; the stride-2 layers (extractor.py:306-308, 341-343, 366) as stride-1 convolutions over a
  * 2x2 space-to-depth copy of their input: dst[(n, i, j)][(2 dy + dx) * C + c] = src[(n, 2 i + dy, 2 j + dx)][c].
- * ppms_img_s2d: src = the NCHW fp32 image batch (N, C, H, W) handed to fnet (extractor.py:400-405); channels >= 4 C of dst are
- * zeroed.  ppms_sp_s2d: src, dst split-plane views, dst.c == 4 * src.c.  H, W even. */
-int ppms_img_s2d(const float* img_nchw, ppms_sp dst, int N, int C, int H, int W, void* stream);
+ * ppms_img_s2d: src = the NCHW fp32 image batch (N, C, H, W) handed to the encoders (extractor.py:400-405, convnext.py:257),
+ * factor k (phase = k dy + dx); channels >= k*k*C of dst are zeroed.  ppms_sp_s2d: src, dst split-plane views, factor 2,
+ * dst.c == 4 * src.c.  H, W multiples of the factor. */
+int ppms_img_s2d(const float* img_nchw, ppms_sp dst, int N, int C, int H, int W, int k, void* stream);   /* k = 2 (fnet), 4 (cnet stem) */
 int ppms_sp_s2d(ppms_sp src, ppms_sp dst, int N, int H, int W, void* stream);
 /* nn.InstanceNorm2d(affine=False) (extractor.py:326-329, 364): per (sample, channel) mean and 1 / sqrt(biased var + eps) over the
  * HW pixels of x (channel-last fp32 [N * HW][ld], a convolution's fp32 output) -> stats[N][C][2] (pixel slices merged in fixed
@@ -207,6 +208,22 @@ int ppms_sp_s2d(ppms_sp src, ppms_sp dst, int N, int H, int W, void* stream);
 int64_t ppms_instnorm_workspace_bytes(int N, int HW, int C);       /* per-slice partial statistics of ppms_instnorm_stats */
 int ppms_instnorm_stats(const float* x, int ld, int N, int HW, int C, float eps, float* stats, void* workspace, void* stream);
 int ppms_instnorm_apply(const float* x, int ld, const float* stats, ppms_sp res, int relu, ppms_sp out, int N, int HW, int C, void* stream);
+
+/* ---------------------------------------------------------------- context encoder (cnet) pieces
+ * Feature("tiny", 256) = frozen ConvNeXt-V2-tiny + FPN decoder, convnext.py:50-264.  Its Linear / conv layers
+ * run on ppms_conv_gemm2 (1x1 over channel-last data; the patchify stem 4x4 s4 and the 2x2 s2 downsamplers over space-to-depth
+ * copies); these are the rest:
+ * ppms_dwconv: depthwise k x k conv + bias (Block.dwconv :60), weights [C][k*k]; x split planes -> y fp32 [pixel][ldy].
+ * ppms_layernorm_any: LayerNorm over the C channels of a pixel, eps given (:11-35, both data formats; 1e-6), fp32 -> split planes.
+ * ppms_grn: GRN (:37-48): out = gamma * (x * Nx) + beta + x, Nx = ||x||_2 over a sample's pixels / (its mean over channels + 1e-6);
+ *   x fp32 [N * HW][ld] (the GELU output), caller-owned workspace of ppms_grn_workspace_bytes; deterministic.
+ * ppms_sp_upsample2: nn.Upsample(scale_factor=2) (nearest, :226-238) of a split-plane view into another (e.g. a channel range of the
+ *   concatenation buffer of :259-261). */
+int ppms_dwconv(ppms_sp x, float* y, int ldy, const float* w, const float* b, int k, int N, int H, int W, void* stream);
+int ppms_layernorm_any(const float* x, int ld, const float* w, const float* b, float eps, ppms_sp out, int64_t pixels, int C, void* stream);
+int64_t ppms_grn_workspace_bytes(int N, int HW, int C);
+int ppms_grn(const float* x, int ld, const float* gamma, const float* beta, ppms_sp out, int N, int HW, int C, void* workspace, void* stream);
+int ppms_sp_upsample2(ppms_sp src, ppms_sp dst, int N, int H, int W, void* stream);
 
 /* ---------------------------------------------------------------- pick-and-play memory attention */
 /* PPMStereo.compute_qk_similarity, ppmstereo.py:397-423.  q,k: fp32 [T][H*W][ld] channel-last (128 channels);

@@ -537,6 +537,61 @@ def basic_encoder(W: Dict[str, Tensor], x):
     return x
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# cnet: Feature("tiny", 256) = frozen ConvNeXt-V2-tiny + FPN decoder
+CNET_DIMS, CNET_DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
+
+
+def _ln_cf(x: Tensor, w: Tensor, b: Tensor) -> Tensor:
+    """LayerNorm(data_format="channels_first", eps=1e-6), models/core/convnext.py:29-34 (normalises over C of an NCHW tensor)."""
+    u = x.mean(1, keepdim=True)
+    s = (x - u).pow(2).mean(1, keepdim=True)
+    return w[:, None, None] * ((x - u) / torch.sqrt(s + 1e-6)) + b[:, None, None]
+
+
+def convnext_block(W: Dict[str, Tensor], p: str, x: Tensor) -> Tensor:
+    """Block.forward, models/core/convnext.py:67-79 (drop_path = identity): dw7x7 -> LN (channels_last, eps 1e-6) -> Linear 4x ->
+    GELU (exact) -> GRN (:44-47) -> Linear -> + input."""
+    C = x.shape[1]
+    y = F.conv2d(x, W[p + "dwconv.weight"], W[p + "dwconv.bias"], padding=3, groups=C).permute(0, 2, 3, 1)
+    y = F.layer_norm(y, (C,), W[p + "norm.weight"], W[p + "norm.bias"], 1e-6)
+    y = F.gelu(F.linear(y, W[p + "pwconv1.weight"], W[p + "pwconv1.bias"]))
+    gx = torch.norm(y, p=2, dim=(1, 2), keepdim=True)
+    nx = gx / (gx.mean(dim=-1, keepdim=True) + 1e-6)
+    y = W[p + "grn.gamma"] * (y * nx) + W[p + "grn.beta"] + y
+    y = F.linear(y, W[p + "pwconv2.weight"], W[p + "pwconv2.bias"])
+    return x + y.permute(0, 3, 1, 2)
+
+
+def feature_cnet(W: Dict[str, Tensor], x: Tensor):
+    """Feature.forward, models/core/convnext.py:256-264, with ConvNeXtV2.forward_features (:133-139): stem conv 4x4 s4 + LN, three
+    LN + conv 2x2 s2 downsamplers, stages of 3/3/9/3 blocks -> x4, x8, x16, x32; decoder (:225-253): up* = nearest x2 -> conv3x3 ->
+    InstanceNorm -> ReLU, decode* = conv1x1 -> InstanceNorm -> ReLU -> conv3x3 on cat[skip, up].  x: (N, 3, H, W), H, W multiples of 32."""
+    d = "convnext.downsample_layers."
+    feats = []
+    y = _ln_cf(F.conv2d(x, W[d + "0.0.weight"], W[d + "0.0.bias"], stride=4), W[d + "0.1.weight"], W[d + "0.1.bias"])
+    for i in range(4):
+        if i > 0:
+            y = F.conv2d(_ln_cf(y, W[d + f"{i}.0.weight"], W[d + f"{i}.0.bias"]), W[d + f"{i}.1.weight"], W[d + f"{i}.1.bias"], stride=2)
+        for j in range(CNET_DEPTHS[i]):
+            y = convnext_block(W, f"convnext.stages.{i}.{j}.", y)
+        feats.append(y)
+    x4, x8, x16, x32 = feats
+
+    def up(tag, t):
+        t = F.interpolate(t, scale_factor=2.0, mode="nearest")
+        return F.relu(_instance_norm(F.conv2d(t, W[tag + ".1.weight"], W[tag + ".1.bias"], padding=1)))
+
+    def dec(tag, t):
+        t = F.relu(_instance_norm(F.conv2d(t, W[tag + ".0.weight"], W[tag + ".0.bias"])))
+        return F.conv2d(t, W[tag + ".3.weight"], W[tag + ".3.bias"], padding=1)
+
+    x16 = dec("decode_16x", torch.cat([x16, up("upconv_16", x32)], 1))
+    x8 = dec("decode_8x", torch.cat([x8, up("upconv_8", x16)], 1))
+    x4 = dec("decode_4x", torch.cat([x4, up("upconv_4", x8)], 1))
+    return x4, x8, x16
+
+
 class InputPadder:
     """models/core/utils/utils.py:19-44 (mode "sintel"): replicate-pad H, W up to multiples of divis_by, split evenly."""
 

@@ -82,7 +82,12 @@ _SIGS = {
     "ppms_avgpool": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_axpby": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int64, c_int64, c_void_p]),
     "ppms_ctx_mix": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "ppms_img_s2d": (c_int, [c_void_p, SP, c_int, c_int, c_int, c_int, c_void_p]),
+    "ppms_img_s2d": (c_int, [c_void_p, SP, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ppms_dwconv": (c_int, [SP, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ppms_layernorm_any": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, SP, c_int64, c_int, c_void_p]),
+    "ppms_grn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "ppms_grn": (c_int, [c_void_p, c_int, c_void_p, c_void_p, SP, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ppms_sp_upsample2": (c_int, [SP, SP, c_int, c_int, c_int, c_void_p]),
     "ppms_sp_s2d": (c_int, [SP, SP, c_int, c_int, c_int, c_void_p]),
     "ppms_instnorm_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "ppms_instnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, C.c_float, c_void_p, c_void_p, c_void_p]),

@@ -6,15 +6,15 @@
 
 namespace {
 
-// ---- space to depth, factor 2: dst[(n, i, j)][phase * C + c] = src[(n, 2i + dy, 2j + dx)][c], phase = 2 dy + dx -------------
-// image form: src is the NCHW fp32 image batch the reference hands to fnet (3 channels); channels >= 4 C of dst are zeroed
-__global__ __launch_bounds__(256) void img_s2d_kernel(const float* __restrict__ img, ppms_sp dst, int C, int H, int W, int64_t npix) {
+// ---- space to depth, factor k: dst[(n, i, j)][phase * C + c] = src[(n, k i + dy, k j + dx)][c], phase = k dy + dx -------------
+// image form: src is the NCHW fp32 image batch the reference hands to its encoders (3 channels); channels >= k*k*C of dst are zeroed
+__global__ __launch_bounds__(256) void img_s2d_kernel(const float* __restrict__ img, ppms_sp dst, int C, int H, int W, int k, int64_t npix) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread = one output pixel x 8 channels
     const int groups = dst.c >> 3;
     if (idx >= npix * groups) return;
     const int g8 = (int)(idx % groups);
     const int64_t p = idx / groups;
-    const int OW = W >> 1, OH = H >> 1;
+    const int OW = W / k, OH = H / k;
     const int j = (int)(p % OW), i = (int)((p / OW) % OH);
     const int64_t n = p / ((int64_t)OW * OH);
     bf16x8 oh, ol;
@@ -22,9 +22,9 @@ __global__ __launch_bounds__(256) void img_s2d_kernel(const float* __restrict__ 
     for (int e = 0; e < 8; ++e) {
         const int ch = g8 * 8 + e;
         float v = 0.0f;
-        if (ch < 4 * C) {
+        if (ch < k * k * C) {
             const int ph = ch / C, c = ch - ph * C;
-            v = img[((n * C + c) * H + 2 * i + (ph >> 1)) * W + 2 * j + (ph & 1)];
+            v = img[((n * C + c) * H + k * i + ph / k) * W + k * j + ph % k];
         }
         bf16_t hh, ll;
         split_bf16(v, hh, ll);
@@ -163,15 +163,201 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
     *(bf16x8*)((bf16_t*)out.lo + od) = ol;
 }
 
+// ================================================================================================ cnet (ConvNeXt-V2 + FPN) pieces
+// (/root/reference/models/core/convnext.py: SURVEY.md section 8 row f5)
+// nn.Upsample(scale_factor=2), nearest (:226-238): dst[(n, y, x)] = src[(n, y / 2, x / 2)]; split planes, 16-B channel groups
+__global__ __launch_bounds__(256) void sp_upsample2_kernel(ppms_sp src, ppms_sp dst, int H, int W, int64_t npix) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread = one OUTPUT pixel x 8 channels
+    const int groups = src.c >> 3;
+    if (idx >= npix * groups) return;
+    const int g8 = (int)(idx % groups);
+    const int64_t p = idx / groups;
+    const int OW = 2 * W, OH = 2 * H;
+    const int x = (int)(p % OW), y = (int)((p / OW) % OH);
+    const int64_t n = p / ((int64_t)OW * OH);
+    const int64_t sp = ((n * H + (y >> 1)) * W + (x >> 1)) * src.ld + g8 * 8;
+    const int64_t od = p * dst.ld + g8 * 8;
+    *(bf16x8*)((bf16_t*)dst.hi + od) = *(const bf16x8*)((const bf16_t*)src.hi + sp);
+    *(bf16x8*)((bf16_t*)dst.lo + od) = *(const bf16x8*)((const bf16_t*)src.lo + sp);
+}
+
+// depthwise k x k convolution + bias (Block.dwconv, :60): split planes in, fp32 channel-last out.  One thread = one pixel x 8
+// channels; weights [C][k*k] as in the state_dict.
+__global__ __launch_bounds__(256) void dwconv_plain_kernel(ppms_sp x, float* __restrict__ y, int ldy, const float* __restrict__ w, const float* __restrict__ b,
+                                                           int H, int W, int K, int64_t npix) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int groups = x.c >> 3;
+    if (idx >= npix * groups) return;
+    const int c0 = (int)(idx % groups) * 8;
+    const int64_t p = idx / groups;
+    const int px = (int)(p % W), py = (int)((p / W) % H);
+    const int R = K >> 1;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = b[c0 + e];
+    for (int ky = 0; ky < K; ++ky) {
+        const int yy = py + ky - R;
+        if ((unsigned)yy >= (unsigned)H) continue;
+        for (int kx = 0; kx < K; ++kx) {
+            const int xx = px + kx - R;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const int64_t q = (p + (int64_t)(ky - R) * W + (kx - R)) * x.ld + c0;
+            const bf16x8 h8 = *(const bf16x8*)((const bf16_t*)x.hi + q), l8 = *(const bf16x8*)((const bf16_t*)x.lo + q);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += join_bf16(h8[e], l8[e]) * w[(c0 + e) * K * K + ky * K + kx];
+        }
+    }
+    float* o = y + p * ldy + c0;
+    *(f32x4*)o = (f32x4){acc[0], acc[1], acc[2], acc[3]};
+    *(f32x4*)(o + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+}
+
+// LayerNorm over the channels of a pixel, any C (convnext.py:11-35, eps 1e-6: both data formats are this per-pixel op on
+// channel-last data): x fp32 [pixel][ld] -> split planes.  One wave per pixel, lanes stride the channels.
+__global__ __launch_bounds__(256) void layernorm_any_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w, const float* __restrict__ b,
+                                                            float eps, ppms_sp out, int64_t pixels, int C) {
+    const int lane = threadIdx.x & 63;
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= pixels) return;
+    const float* xp = x + pix * ld;
+    float s = 0.0f;
+    for (int c = lane; c < C; c += 64) s += xp[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.0f;
+    for (int c = lane; c < C; c += 64) q += (xp[c] - mean) * (xp[c] - mean);
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + eps);
+    for (int c = lane; c < out.c; c += 64) {
+        const float y = c < C ? (xp[c] - mean) * rstd * w[c] + b[c] : 0.0f;
+        bf16_t hi, lo;
+        split_bf16(y, hi, lo);
+        ((bf16_t*)out.hi)[pix * out.ld + c] = hi;
+        ((bf16_t*)out.lo)[pix * out.ld + c] = lo;
+    }
+}
+
+// GRN (convnext.py:37-48) on channel-last fp32 h [N*HW][ld]: Gx[n][c] = ||h[n, :, c]||_2 over the pixels; Nx = Gx / (mean_c Gx + 1e-6);
+// out = gamma * (h * Nx) + beta + h.  Squares summed per pixel slice (part kernel), slices merged in order + the channel mean
+// (one workgroup per sample), then the apply kernel.  Deterministic.
+__global__ __launch_bounds__(256) void grn_part_kernel(const float* __restrict__ x, int ld, int HW, int C, int S, float* __restrict__ part) {
+    __shared__ float red[8][32];
+    const int n = blockIdx.y, c0 = blockIdx.x * 32, s = blockIdx.z;
+    const int lane = threadIdx.x & 31, row = threadIdx.x >> 5;
+    const int c = c0 + lane;
+    const int chunk = (HW + S - 1) / S;
+    const int p0 = s * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
+    const float* xp = x + (int64_t)n * HW * ld;
+    float acc = 0.0f;
+    if (c < C)
+        for (int p = p0 + row; p < p1; p += 8) {
+            const float v = xp[(int64_t)p * ld + c];
+            acc += v * v;
+        }
+    red[row][lane] = acc;
+    __syncthreads();
+    if (row == 0 && c < C) {
+        float t = 0.0f;
+        for (int r = 0; r < 8; ++r) t += red[r][lane];
+        part[((int64_t)n * S + s) * C + c] = t;
+    }
+}
+__global__ __launch_bounds__(256) void grn_merge_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ nx) {
+    __shared__ float red[256];
+    const int n = blockIdx.x;
+    float local = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.0f;
+        for (int s = 0; s < S; ++s) t += part[((int64_t)n * S + s) * C + c];
+        const float g = sqrtf(t);
+        nx[(int64_t)n * C + c] = g;
+        local += g;
+    }
+    red[threadIdx.x] = local;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    const float inv = 1.0f / (red[0] / (float)C + 1e-6f);
+    for (int c = threadIdx.x; c < C; c += 256) nx[(int64_t)n * C + c] *= inv;
+}
+__global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict__ x, int ld, const float* __restrict__ nx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, ppms_sp out, int HW, int C, int64_t npix) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one thread = one pixel x 8 channels
+    const int groups = C >> 3;
+    if (idx >= npix * groups) return;
+    const int c0 = (int)(idx % groups) * 8;
+    const int64_t p = idx / groups;
+    const int64_t n = p / HW;
+    bf16x8 oh, ol;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        const float v = x[p * ld + c];
+        const float y = gamma[c] * (v * nx[n * C + c]) + beta[c] + v;
+        bf16_t hh, ll;
+        split_bf16(y, hh, ll);
+        oh[e] = hh;
+        ol[e] = ll;
+    }
+    const int64_t od = p * out.ld + c0;
+    *(bf16x8*)((bf16_t*)out.hi + od) = oh;
+    *(bf16x8*)((bf16_t*)out.lo + od) = ol;
+}
+
 }  // namespace
 
-extern "C" int ppms_img_s2d(const float* img, ppms_sp dst, int N, int C, int H, int W, void* stream) {
-    PPMS_REQUIRE(img && dst.hi && dst.lo && N > 0 && C > 0 && H > 0 && W > 0, "img_s2d: bad arguments");
-    PPMS_REQUIRE(H % 2 == 0 && W % 2 == 0, "img_s2d: H = %d, W = %d must be even", H, W);
-    PPMS_REQUIRE(dst.c >= 4 * C && dst.c % 8 == 0 && dst.ld % 8 == 0 && (((uintptr_t)dst.hi | (uintptr_t)dst.lo) & 15) == 0,
-                 "img_s2d: destination view needs >= %d channels, multiples of 8, 16-B aligned", 4 * C);
-    const int64_t npix = (int64_t)N * (H / 2) * (W / 2);
-    hipLaunchKernelGGL(img_s2d_kernel, dim3(ceil_div(npix * (dst.c / 8), 256)), dim3(256), 0, (hipStream_t)stream, img, dst, C, H, W, npix);
+extern "C" int ppms_sp_upsample2(ppms_sp src, ppms_sp dst, int N, int H, int W, void* stream) {
+    PPMS_REQUIRE(src.hi && src.lo && dst.hi && dst.lo && N > 0 && H > 0 && W > 0, "sp_upsample2: bad arguments");
+    PPMS_REQUIRE(src.c % 8 == 0 && dst.c == src.c && src.ld % 8 == 0 && dst.ld % 8 == 0, "sp_upsample2: equal channel counts, multiples of 8");
+    PPMS_REQUIRE((((uintptr_t)src.hi | (uintptr_t)src.lo | (uintptr_t)dst.hi | (uintptr_t)dst.lo) & 15) == 0, "sp_upsample2: views must be 16-B aligned");
+    const int64_t npix = (int64_t)N * 4 * H * W;
+    hipLaunchKernelGGL(sp_upsample2_kernel, dim3(ceil_div(npix * (src.c / 8), 256)), dim3(256), 0, (hipStream_t)stream, src, dst, H, W, npix);
+    return ppms_check_launch("sp_upsample2");
+}
+
+extern "C" int ppms_dwconv(ppms_sp x, float* y, int ldy, const float* w, const float* b, int k, int N, int H, int W, void* stream) {
+    PPMS_REQUIRE(x.hi && x.lo && y && w && b && N > 0 && H > 0 && W > 0 && k % 2 == 1 && k >= 1 && k <= 15, "dwconv: bad arguments");
+    PPMS_REQUIRE(x.c % 8 == 0 && x.ld % 8 == 0 && ldy >= x.c && ldy % 4 == 0 && (((uintptr_t)x.hi | (uintptr_t)x.lo | (uintptr_t)y) & 15) == 0,
+                 "dwconv: channel counts multiples of 8, 16-B aligned operands");
+    const int64_t npix = (int64_t)N * H * W;
+    hipLaunchKernelGGL(dwconv_plain_kernel, dim3(ceil_div(npix * (x.c / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, y, ldy, w, b, H, W, k, npix);
+    return ppms_check_launch("dwconv");
+}
+
+extern "C" int ppms_layernorm_any(const float* x, int ld, const float* w, const float* b, float eps, ppms_sp out, int64_t pixels, int C, void* stream) {
+    PPMS_REQUIRE(x && w && b && out.hi && out.lo && pixels > 0 && C > 0 && ld >= C && out.c >= C && eps > 0.0f, "layernorm_any: bad arguments");
+    hipLaunchKernelGGL(layernorm_any_kernel, dim3(ceil_div(pixels, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, w, b, eps, out, pixels, C);
+    return ppms_check_launch("layernorm_any");
+}
+
+extern "C" int64_t ppms_grn_workspace_bytes(int N, int HW, int C) {
+    if (N <= 0 || HW <= 0 || C <= 0) return 0;
+    return ((int64_t)N * in_slices_host(N, HW, C) * C + (int64_t)N * C) * 4;
+}
+
+extern "C" int ppms_grn(const float* x, int ld, const float* gamma, const float* beta, ppms_sp out, int N, int HW, int C, void* workspace, void* stream) {
+    PPMS_REQUIRE(x && gamma && beta && out.hi && out.lo && workspace && N > 0 && HW > 0 && C > 0 && C % 8 == 0 && ld >= C, "grn: bad arguments");
+    PPMS_REQUIRE(out.c >= C && out.ld % 8 == 0 && (((uintptr_t)out.hi | (uintptr_t)out.lo) & 15) == 0, "grn: output view must cover C channels, 16-B aligned");
+    const int S = in_slices_host(N, HW, C);
+    float* part = (float*)workspace;
+    float* nx = part + (size_t)N * S * C;
+    hipLaunchKernelGGL(grn_part_kernel, dim3(ceil_div(C, 32), N, S), dim3(256), 0, (hipStream_t)stream, x, ld, HW, C, S, part);
+    hipLaunchKernelGGL(grn_merge_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const float*)part, C, S, nx);
+    const int64_t npix = (int64_t)N * HW;
+    hipLaunchKernelGGL(grn_apply_kernel, dim3(ceil_div(npix * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, ld, (const float*)nx, gamma, beta, out, HW,
+                       C, npix);
+    return ppms_check_launch("grn");
+}
+
+extern "C" int ppms_img_s2d(const float* img, ppms_sp dst, int N, int C, int H, int W, int k, void* stream) {
+    PPMS_REQUIRE(img && dst.hi && dst.lo && N > 0 && C > 0 && H > 0 && W > 0 && (k == 2 || k == 4), "img_s2d: bad arguments (k = 2 or 4)");
+    PPMS_REQUIRE(H % k == 0 && W % k == 0, "img_s2d: H = %d, W = %d must be multiples of %d", H, W, k);
+    PPMS_REQUIRE(dst.c >= k * k * C && dst.c % 8 == 0 && dst.ld % 8 == 0 && (((uintptr_t)dst.hi | (uintptr_t)dst.lo) & 15) == 0,
+                 "img_s2d: destination view needs >= %d channels, multiples of 8, 16-B aligned", k * k * C);
+    const int64_t npix = (int64_t)N * (H / k) * (W / k);
+    hipLaunchKernelGGL(img_s2d_kernel, dim3(ceil_div(npix * (dst.c / 8), 256)), dim3(256), 0, (hipStream_t)stream, img, dst, C, H, W, k, npix);
     return ppms_check_launch("img_s2d");
 }
 

@@ -143,13 +143,22 @@ class _FnetEngine:
         H2, W2, H4, W4 = H // 2, W // 2, H // 4, W // 4
         P2, P4 = N * H2 * W2, N * H4 * W4
         self.P2, self.P4 = P2, P4
-        sp = lambda p, c: L.SPTensor(p, c, device)
-        f32 = lambda p, c: torch.empty(p, c, device=device, dtype=torch.float32)
+        keep: List = []                 # EVERY buffer of the plan: the launch descriptors hold raw pointers only
+
+        def sp(p, c):
+            t = L.SPTensor(p, c, device)
+            keep.append(t)
+            return t
+
+        def f32(p, c):
+            t = torch.empty(p, c, device=device, dtype=torch.float32)
+            keep.append(t)
+            return t
+
         self.stats = torch.empty(N * 256 * 2, device=device, dtype=torch.float32)
         ws_bytes = max(int(self.lib.ppms_instnorm_workspace_bytes(N, hw, c)) for hw, c in ((H2 * W2, 64), (H4 * W4, 96), (H4 * W4, 128)))
         self.ws = torch.empty(ws_bytes, device=device, dtype=torch.uint8)
         self.ops: List[tuple] = []                                   # ("conv", ConvOp) | ("call", fn)
-        keep: List = []
 
         def conv(name, src: L.SPTensor, dst_f32: torch.Tensor, n, h, w):
             packed, bias, meta, k2 = pk[name]
@@ -215,7 +224,7 @@ class _FnetEngine:
         self.keep = keep
 
     def run(self, img: torch.Tensor) -> torch.Tensor:
-        L.check(self.lib.ppms_img_s2d(img.data_ptr(), self.s0.view(), self.N, 3, self.H, self.W, L.stream_ptr()))
+        L.check(self.lib.ppms_img_s2d(img.data_ptr(), self.s0.view(), self.N, 3, self.H, self.W, 2, L.stream_ptr()))
         for kind, op in self.ops:
             op()
         out = torch.empty_like(self.out)

@@ -236,9 +236,9 @@ class InputPadder:
 class PPMStereo(PPMStereoHotPath):
     """``models/core/ppmstereo.py:PPMStereo`` from the encoder outputs on: same constructor arguments, ``forward`` (:601-804)
     and ``forward_batch_test`` (:238-320).  The encoders are outside the hot path: ``fnet``
-    defaults to this package's HIP ``BasicEncoder`` (``ppmstereo_amd/encoder.py``, row f3; ``fnet=False`` leaves it unset),
-    ``cnet`` is a module the caller plugs in (the reference's ``Feature``, or any callable with the same
-    contract: ``fnet([im1, im2]) -> (fmap1, fmap2)`` (BT,256,H/4,W/4), ``cnet(im1) -> (c4, c8, c16)`` with 256 channels);
+    and ``cnet`` default to this package's HIP ``BasicEncoder`` / ``Feature("tiny", 256)`` (``ppmstereo_amd/encoder.py``, ``cnet.py``:
+    rows f3, f5; ``False`` leaves one unset), or take any callable with the same contract:
+    ``fnet([im1, im2]) -> (fmap1, fmap2)`` (BT,256,H/4,W/4), ``cnet(im1) -> (c4, c8, c16)`` with 256 channels;
     ``sst`` stands for ``forward_sst_block`` (:322-395): "auto" (default) follows the reference's ctor (:139-171) -- the HIP
     ``SSTBlock`` (``ppmstereo_amd/sst.py``, row f4) when ``attention_type`` names "self_stereo" / "temporal", its parameters
     registered under the reference's names (``time_embed``, ``time_attn_blocks``, ``self_attn_blocks``, ``cross_attn_blocks``);
@@ -262,14 +262,22 @@ class PPMStereo(PPMStereoHotPath):
         if fnet is None:                                       # the reference builds it in its ctor (ppmstereo.py:64)
             from .encoder import BasicEncoder
             fnet = BasicEncoder(output_dim=256, norm_fn="instance")
-        self.fnet, self.cnet = (None if fnet is False else fnet), cnet
+        if cnet is None:                                       # (ppmstereo.py:69; no checkpoint is read here: load_state_dict supplies it)
+            from .cnet import Feature
+            cnet = Feature(model_name="tiny", output_dim=256)
+        self.fnet, self.cnet = (None if fnet is False else fnet), (None if cnet is False else cnet)
         object.__setattr__(self, "sst", sst)
+        # state_dict in the reference's registration order (ppmstereo.py:64-171): fnet, cnet, att, the update blocks, the SST modules
+        ref_order = ["fnet", "cnet", "att", "update_block08", "update_block16", "update_block04", "time_attn_blocks", "self_attn_blocks", "cross_attn_blocks"]
+        mods = self._modules
+        for k in [k for k in ref_order if k in mods] + [k for k in list(mods) if k not in ref_order]:
+            mods[k] = mods.pop(k)                              # (re-insertion moves the key to the end)
         self.dim = 256
         self._pe_cache: Dict[tuple, torch.Tensor] = {}
 
     def load_state_dict(self, sd, strict: bool = True, **kw):
         r = super().load_state_dict(sd, strict=strict, **kw)
-        for m in (self.fnet, getattr(self, "_sst_impl", None)):       # packed weight copies are cached per module
+        for m in (self.fnet, self.cnet, getattr(self, "_sst_impl", None)):       # packed weight copies are cached per module
             if hasattr(m, "invalidate"):
                 m.invalidate()
         return r

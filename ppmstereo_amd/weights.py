@@ -124,6 +124,45 @@ def sst_weights(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
     return procedural_state_dict(sst_param_shapes(), "sst.", seed)
 
 
+CNET_DIMS, CNET_DEPTHS = (96, 192, 384, 768), (3, 3, 9, 3)
+
+
+def cnet_param_shapes(output_dim: int = 256) -> "OrderedDict[str, Tuple[int, ...]]":
+    """state_dict of the reference's cnet, Feature("tiny", 256) (/root/reference/models/core/convnext.py:202-253): the ConvNeXt-V2-tiny
+    backbone (:81-125; its unused final norm / classifier head included, as in the checkpoint it loads at :221-222) and the FPN
+    decoder, in registration order.  InstanceNorm2d(affine=False) and nn.Upsample have no entries."""
+    s: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    d = CNET_DIMS
+    p = "convnext.downsample_layers."
+    s[p + "0.0.weight"], s[p + "0.0.bias"] = (d[0], 3, 4, 4), (d[0],)
+    s[p + "0.1.weight"], s[p + "0.1.bias"] = (d[0],), (d[0],)
+    for i in range(3):
+        s[p + f"{i + 1}.0.weight"], s[p + f"{i + 1}.0.bias"] = (d[i],), (d[i],)
+        s[p + f"{i + 1}.1.weight"], s[p + f"{i + 1}.1.bias"] = (d[i + 1], d[i], 2, 2), (d[i + 1],)
+    for i in range(4):
+        for j in range(CNET_DEPTHS[i]):
+            q = f"convnext.stages.{i}.{j}."
+            s[q + "dwconv.weight"], s[q + "dwconv.bias"] = (d[i], 1, 7, 7), (d[i],)
+            s[q + "norm.weight"], s[q + "norm.bias"] = (d[i],), (d[i],)
+            s[q + "pwconv1.weight"], s[q + "pwconv1.bias"] = (4 * d[i], d[i]), (4 * d[i],)
+            s[q + "grn.gamma"], s[q + "grn.beta"] = (1, 1, 1, 4 * d[i]), (1, 1, 1, 4 * d[i])
+            s[q + "pwconv2.weight"], s[q + "pwconv2.bias"] = (d[i], 4 * d[i]), (d[i],)
+    s["convnext.norm.weight"], s["convnext.norm.bias"] = (d[3],), (d[3],)
+    s["convnext.head.weight"], s["convnext.head.bias"] = (1000, d[3]), (1000,)
+    o = output_dim
+    s["upconv_16.1.weight"], s["upconv_16.1.bias"] = (o, d[3], 3, 3), (o,)
+    s["upconv_8.1.weight"], s["upconv_8.1.bias"] = (o, o, 3, 3), (o,)
+    s["upconv_4.1.weight"], s["upconv_4.1.bias"] = (o, o, 3, 3), (o,)
+    for tag, c in (("decode_16x", d[2]), ("decode_8x", d[1]), ("decode_4x", d[0])):
+        s[tag + ".0.weight"], s[tag + ".0.bias"] = (o, c + o, 1, 1), (o,)
+        s[tag + ".3.weight"], s[tag + ".3.bias"] = (o, o, 3, 3), (o,)
+    return s
+
+
+def cnet_weights(seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    return procedural_state_dict(cnet_param_shapes(), "cnet.", seed)
+
+
 def fnet_param_shapes() -> "OrderedDict[str, Tuple[int, ...]]":
     """state_dict of the reference's fnet, BasicEncoder(output_dim=256, norm_fn="instance"), in its registration order
     (/root/reference/models/core/extractor.py:349-389 and :303-341; InstanceNorm2d(affine=False) has no entries; the skip's
@@ -152,8 +191,12 @@ def _gen(name: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
     leaf = name.rsplit(".", 1)[-1]
     if name.endswith("aggregator.beta"):
         return np.full(shape, 0.5, np.float32)               # zero-init in the reference: would mute attention
-    if "norm" in name and leaf == "weight":
-        return (1.0 + 0.1 * x).astype(np.float32)
+    if ("norm" in name and leaf == "weight") or (name.startswith("cnet.") and leaf == "weight" and len(shape) == 1):
+        return (1.0 + 0.1 * x).astype(np.float32)            # (cnet: the LayerNorms inside downsample_layers carry no "norm" in their names)
+    if name.endswith("grn.gamma"):
+        return (0.5 * x).astype(np.float32)                   # zero-init in the reference (convnext.py:42-43): would mute the term
+    if name.endswith("grn.beta"):
+        return (0.1 * x).astype(np.float32)
     if leaf == "bias":
         return (0.02 * x).astype(np.float32)
     fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]

@@ -177,22 +177,27 @@ def test_forward_batch_test_vs_reference():
     assert tuple(preds.shape) == (8, 1, 3, 1, 64, 256) and torch.equal(preds[-1], last)
 
 
-def test_forward_with_hip_fnet_and_sst_vs_oracle():
-    """Rows f3 + f4 in place: PPMStereo.forward from the IMAGES with this package's fnet (encoder.py) and SST block (sst.py), only
-    cnet stubbed, against the oracle's forward with its own BasicEncoder / forward_sst_block restatements (both pinned to the
-    reference by the fnet_* / sst_* fixtures).  Also: the model's state_dict carries the reference's key names for them.
+def test_forward_with_hip_encoders_and_sst_vs_oracle():
+    """Rows f3 + f4 + f5 in place: PPMStereo.forward from the IMAGES with this package's fnet (encoder.py), cnet (cnet.py) and SST block
+    (sst.py) -- the whole model, nothing stubbed -- against the oracle's forward with its own BasicEncoder / Feature / forward_sst_block
+    restatements (all pinned to the reference by the fnet_* / cnet_* / sst_* fixtures).  Also: the model's state_dict IS the
+    reference's: same keys in the same order for every sub-module.
     Tolerance: the loop is ill-conditioned in its inputs -- perturbing the ORACLE's own fnet output by 1e-5 of its range moves the
     oracle's disparity by 7.5e-4 px on average (3.7e-3 max), 1e-4 by 1.2e-3 px (bf16 rounding flips of the attention operands) --
     so the end-to-end check from the images is a sanity bound; the encoders' parity is asserted at feature level
     (tests/test_gpu_encoder.py, tests/test_gpu_sst.py: 2e-4 / 5e-4 of the reference's features)."""
     from ppmstereo_amd.ppmstereo import PPMStereo
     from stub_encoders import StubCNet
-    m = PPMStereo(cnet=StubCNet())
+    m = PPMStereo()
     keys = list(m.state_dict().keys())
-    assert keys[0] == "time_embed" and "fnet.conv1.weight" in keys and "self_attn_blocks.3.layers.0.mlp.2.weight" in keys
-    assert not any(k.startswith(("sst.", "_sst")) for k in keys)
+    assert keys[0] == "time_embed" and not any(k.startswith(("sst.", "_sst")) for k in keys)
+    expect = (["time_embed"] + ["fnet." + k for k in Wm.fnet_param_shapes()] + ["cnet." + k for k in Wm.cnet_param_shapes()] +
+              ["att.%d.%s" % (i, k) for i in range(3) for k in Wm.att_param_shapes()])
+    assert keys[:len(expect)] == expect                     # ctor order of the reference: fnet, cnet, att, update blocks, SST modules
+    assert [k for k in keys if k.split(".")[0].endswith("attn_blocks")] == list(Wm.sst_param_shapes().keys())[1:]
     m.load_hot_path_weights(W)
     m.fnet.load_state_dict(Wm.fnet_weights(), strict=True)
+    m.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
     sd = m.state_dict()
     sd.update(Wm.sst_weights())
     m.load_state_dict(sd, strict=True)
@@ -201,11 +206,10 @@ def test_forward_with_hip_fnet_and_sst_vs_oracle():
     img1 = (torch.sigmoid(hash_normal((1, T, 3, H, Wd), 901)) * 255.0).contiguous()
     img2 = (torch.sigmoid(hash_normal((1, T, 3, H, Wd), 902)) * 255.0).contiguous()
     d, u = m.forward(img1.to(DEV), img2.to(DEV), iters=4, test_mode=True)
-    Wf, Ws = Wm.fnet_weights(), Wm.sst_weights()
-    cn = StubCNet()
-    rd, ru = O.forward(W, lambda x: O.basic_encoder(Wf, x), lambda im: cn(im), img1, img2, 4, sst_fn=lambda a, b: O.sst_block(Ws, a, b, T))
+    Wf, Ws, Wc = Wm.fnet_weights(), Wm.sst_weights(), Wm.cnet_weights()
+    rd, ru = O.forward(W, lambda x: O.basic_encoder(Wf, x), lambda im: O.feature_cnet(Wc, im), img1, img2, 4, sst_fn=lambda a, b: O.sst_block(Ws, a, b, T))
     err = (d.cpu() - rd).abs()
-    print(f"forward with HIP fnet + SST: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px")
+    print(f"forward with HIP fnet + cnet + SST: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px")
     assert tuple(d.shape) == (1, T, 1, H, Wd) and err.mean().item() < 5e-3 and err.max().item() < 5e-2
     assert maxdiff(u, ru) < 1e-2
 

@@ -198,3 +198,13 @@ def test_sst_block(name, T, h, w):
     o1, o2 = O.sst_block(Wm.sst_weights(), a, b, T)
     g.check("f1", o1, 5e-5, 1e-5)
     g.check("f2", o2, 5e-5, 1e-5)
+
+
+@pytest.mark.parametrize("name,n,hh,ww", [("cnet_small", 2, 64, 96), ("cnet_32", 1, 32, 64)])
+def test_cnet_feature(name, n, hh, ww):
+    """the oracle's Feature("tiny", 256) restatement (ConvNeXt-V2-tiny + FPN decoder) against the reference's own
+    module (convnext.py:202-264) with the procedural weights; 32 x 64 is the smallest legal input (1 x 2 pixels at 1/32)."""
+    g = Golden(name)
+    c4, c8, c16 = O.feature_cnet(Wm.cnet_weights(), Wm.hash_uniform((n, 3, hh, ww), 900 + hh))
+    assert c4.shape == (n, 256, hh // 4, ww // 4) and c16.shape == (n, 256, hh // 16, ww // 16)
+    g.check("c4", c4, 5e-5, 2e-5), g.check("c8", c8, 5e-5, 2e-5), g.check("c16", c16, 5e-5, 2e-5)

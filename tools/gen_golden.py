@@ -68,6 +68,7 @@ from models.core import ppmtereo_update as rupd            # noqa: E402
 from models.core import ppmstereo as rppm                  # noqa: E402
 from models.core import extractor as rext                  # noqa: E402
 from models.core import attention as ratt                  # noqa: E402
+from models.core import convnext as rcnx                    # noqa: E402
 
 from ppmstereo_amd import weights as Wm                    # noqa: E402
 from ppmstereo_amd.synth import T40_CASES, synth_scale_inputs   # noqa: E402
@@ -302,6 +303,23 @@ def main():
         a, b = hash_normal((T, 256, h, w), 810 + T), hash_normal((T, 256, h, w), 820 + T)
         o1, o2 = ms.forward_sst_block(a, b, T)
         save(name, f1=o1, f2=o2)
+
+    # ---- G12: cnet = Feature("tiny", 256) (convnext.py:202-264).  Its ctor loads a checkpoint from a path of the authors' machine
+    # (:221-222); torch.load is answered with a freshly initialised backbone's own state_dict for the duration of the call, the
+    # procedural weights are loaded right after (strict) -----------------------------------------------------------------------------
+    real_load = torch.load
+    torch.load = lambda *a, **k: {"model": rcnx.convnextv2_tiny().state_dict()}
+    try:
+        cnet = rcnx.Feature("tiny", 256)
+    finally:
+        torch.load = real_load
+    assert list(cnet.state_dict().keys()) == list(Wm.cnet_param_shapes().keys()), "cnet state_dict order"
+    cnet.load_state_dict(Wm.cnet_weights(), strict=True)
+    cnet.eval()
+    for name, n, hh, ww in (("cnet_small", 2, 64, 96), ("cnet_32", 1, 32, 64)):
+        img = hash_uniform((n, 3, hh, ww), 900 + hh)
+        c4, c8, c16 = cnet(img)
+        save(name, c4=c4, c8=c8, c16=c16)
 
     # ---- G7: T == 1 -> NaN known answer (SURVEY.md hazard 1) ------------------------------------
     d = synth_scale_inputs(1, 8, 32, seed=81)
