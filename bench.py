@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets around the attention / conv3 kernels")
+    ap.add_argument("--with-encoders", action="store_true", help="also time fnet + cnet + SST block (the producers of the path's inputs, once per "
+                    "clip, outside `value`) and report them under `encoders`")
     ap.add_argument("--replicas", action="store_true", help="N > 1: force clip replicas even when T divides over the ranks")
     args = ap.parse_args()
 
@@ -193,6 +195,29 @@ def main():
                                   launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / args.steps, 3),
                                   flop_per_launch=c_flop / c_n, per_op=per_op))
         roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first
+    encoders = None
+    if args.with_encoders and rank == 0 and not sharded:
+        # SURVEY 8 rows f3-f5 on the same clip geometry: fnet on the 2T images, cnet on the T left images, SST on the 1/16 features
+        from ppmstereo_amd.cnet import Feature
+        from ppmstereo_amd.encoder import BasicEncoder
+        from ppmstereo_amd.sst import SSTBlock
+        fnet, cnet, sst = BasicEncoder(256, "instance"), Feature("tiny", 256), SSTBlock()
+        fnet.load_state_dict(Wm.fnet_weights()), cnet.load_state_dict(Wm.cnet_weights()), sst.load_state_dict(Wm.sst_weights())
+        fnet, cnet, sst = fnet.to(dev).eval(), cnet.to(dev).eval(), sst.to(dev).eval()
+        i1, i2 = Wm.hash_uniform((T, 3, H, W), 611).to(dev), Wm.hash_uniform((T, 3, H, W), 612).to(dev)
+        f16a, f16b = feats["f1_16"], feats["f2_16"]
+
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return round((time.perf_counter() - t1) / reps * 1e3, 3)
+
+        encoders = dict(fnet_ms=timed(lambda: fnet([i1, i2])), cnet_ms=timed(lambda: cnet(i1)), sst_ms=timed(lambda: sst(f16a, f16b, T)),
+                        note="once per clip, in front of the timed path; not part of `value`")
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -210,7 +235,7 @@ def main():
                                         "corr pyramid build + lookup, QAM pick, pick-and-play memory attention, ConvGRU3D update, heads, convex upsample, "
                                         "test_mode: only the last prediction is resized)", T=T, H=H, W=W, iters=iters, parallelism=par),
                    roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None, cpu_baseline=cpu,
-                   library=os.path.relpath(L.lib_path(), ROOT))
+                   library=os.path.relpath(L.lib_path(), ROOT), **({"encoders": encoders} if encoders else {}))
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
