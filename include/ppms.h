@@ -213,7 +213,7 @@ int ppms_instnorm_apply(const float* x, int ld, const float* stats, ppms_sp res,
  * Feature("tiny", 256) = frozen ConvNeXt-V2-tiny + FPN decoder, convnext.py:50-264.  Its Linear / conv layers
  * run on ppms_conv_gemm2 (1x1 over channel-last data; the patchify stem 4x4 s4 and the 2x2 s2 downsamplers over space-to-depth
  * copies); these are the rest:
- * ppms_dwconv: depthwise k x k conv + bias (Block.dwconv :60), weights [C][k*k]; x split planes -> y fp32 [pixel][ldy].
+ * ppms_dwconv: depthwise k x k conv + bias (Block.dwconv :60; k = 7), weights [C][k*k]; x split planes -> y fp32 [pixel][ldy].
  * ppms_layernorm_any: LayerNorm over the C channels of a pixel, eps given (:11-35, both data formats; 1e-6), fp32 -> split planes.
  * ppms_grn: GRN (:37-48): out = gamma * (x * Nx) + beta + x, Nx = ||x||_2 over a sample's pixels / (its mean over channels + 1e-6);
  *   x fp32 [N * HW][ld] (the GELU output), caller-owned workspace of ppms_grn_workspace_bytes; deterministic.

@@ -181,35 +181,75 @@ __global__ __launch_bounds__(256) void sp_upsample2_kernel(ppms_sp src, ppms_sp 
     *(bf16x8*)((bf16_t*)dst.lo + od) = *(const bf16x8*)((const bf16_t*)src.lo + sp);
 }
 
-// depthwise k x k convolution + bias (Block.dwconv, :60): split planes in, fp32 channel-last out.  One thread = one pixel x 8
-// channels; weights [C][k*k] as in the state_dict.
+// depthwise 7 x 7 convolution + bias (Block.dwconv, :60): split planes in, fp32 channel-last out.  Same scheme as dwconv_gelu_kernel
+// (small_ops.hip): one thread = a run of 4 pixels along x times 8 channels, per kernel row the 4 + 6 window positions are loaded once
+// (16-byte loads of both planes) and the 7 taps sweep them from registers; a workgroup serves one block of <= 64 channels (blockIdx.y)
+// whose weights sit in LDS transposed to [tap][channel].  Weights [C][49] as in the state_dict.
+constexpr int DWP_PX = 4;
 __global__ __launch_bounds__(256) void dwconv_plain_kernel(ppms_sp x, float* __restrict__ y, int ldy, const float* __restrict__ w, const float* __restrict__ b,
-                                                           int H, int W, int K, int64_t npix) {
+                                                           int H, int W, int64_t rows) {
+    constexpr int K = 7, R = 3, NW = DWP_PX + K - 1;
+    __shared__ __attribute__((aligned(16))) float wl[K * K * 64];
+    const int cb = blockIdx.y * 64;                                        // first channel of this workgroup's block
+    const int cn = (x.c - cb) < 64 ? (x.c - cb) : 64;                      // channels in it (multiple of 8)
+    for (int i = threadIdx.x; i < K * K * cn; i += 256) {
+        const int c = i % cn, tap = i / cn;
+        wl[tap * 64 + c] = w[(cb + c) * K * K + tap];
+    }
+    __syncthreads();
+    const int groups = cn >> 3;
+    const int rpr = (W + DWP_PX - 1) / DWP_PX;                             // runs per image row
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int groups = x.c >> 3;
-    if (idx >= npix * groups) return;
-    const int c0 = (int)(idx % groups) * 8;
-    const int64_t p = idx / groups;
-    const int px = (int)(p % W), py = (int)((p / W) % H);
-    const int R = K >> 1;
-    float acc[8];
+    if (idx >= rows * rpr * groups) return;
+    const int cl = (int)(idx % groups) * 8, c0 = cb + cl;
+    const int64_t run = idx / groups;
+    const int px0 = (int)(run % rpr) * DWP_PX;
+    const int64_t row = run / rpr;                                         // sample * H + y
+    const int py = (int)(row % H);
+    const int64_t pix0 = row * W + px0;
+    const bf16_t* xh = (const bf16_t*)x.hi + c0;
+    const bf16_t* xl = (const bf16_t*)x.lo + c0;
+    float acc[DWP_PX][8];
+    {
+        const f32x4 b0 = *(const f32x4*)(b + c0), b1 = *(const f32x4*)(b + c0 + 4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = b[c0 + e];
+        for (int p = 0; p < DWP_PX; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[p][j] = j < 4 ? b0[j & 3] : b1[j & 3];
+    }
+#pragma unroll
     for (int ky = 0; ky < K; ++ky) {
         const int yy = py + ky - R;
         if ((unsigned)yy >= (unsigned)H) continue;
-        for (int kx = 0; kx < K; ++kx) {
-            const int xx = px + kx - R;
-            if ((unsigned)xx >= (unsigned)W) continue;
-            const int64_t q = (p + (int64_t)(ky - R) * W + (kx - R)) * x.ld + c0;
-            const bf16x8 h8 = *(const bf16x8*)((const bf16_t*)x.hi + q), l8 = *(const bf16x8*)((const bf16_t*)x.lo + q);
+        float win[NW][8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += join_bf16(h8[e], l8[e]) * w[(c0 + e) * K * K + ky * K + kx];
+        for (int i = 0; i < NW; ++i) {
+            const int xx = px0 - R + i;
+            bf16x8 h8 = {0, 0, 0, 0, 0, 0, 0, 0}, l8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            if ((unsigned)xx < (unsigned)W) {
+                const int64_t q = pix0 + (int64_t)(ky - R) * W + (i - R);
+                h8 = *(const bf16x8*)(xh + q * x.ld);
+                l8 = *(const bf16x8*)(xl + q * x.ld);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) win[i][j] = join_bf16(h8[j], l8[j]);
+        }
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const f32x4 w0 = *(const f32x4*)(wl + (ky * K + kx) * 64 + cl), w1 = *(const f32x4*)(wl + (ky * K + kx) * 64 + cl + 4);
+#pragma unroll
+            for (int p = 0; p < DWP_PX; ++p)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[p][j] += win[p + kx][j] * (j < 4 ? w0[j & 3] : w1[j & 3]);
         }
     }
-    float* o = y + p * ldy + c0;
-    *(f32x4*)o = (f32x4){acc[0], acc[1], acc[2], acc[3]};
-    *(f32x4*)(o + 4) = (f32x4){acc[4], acc[5], acc[6], acc[7]};
+#pragma unroll
+    for (int p = 0; p < DWP_PX; ++p) {
+        if (px0 + p >= W) break;
+        float* o = y + (pix0 + p) * ldy + c0;
+        *(f32x4*)o = (f32x4){acc[p][0], acc[p][1], acc[p][2], acc[p][3]};
+        *(f32x4*)(o + 4) = (f32x4){acc[p][4], acc[p][5], acc[p][6], acc[p][7]};
+    }
 }
 
 // LayerNorm over the channels of a pixel, any C (convnext.py:11-35, eps 1e-6: both data formats are this per-pixel op on
@@ -318,11 +358,13 @@ extern "C" int ppms_sp_upsample2(ppms_sp src, ppms_sp dst, int N, int H, int W, 
 }
 
 extern "C" int ppms_dwconv(ppms_sp x, float* y, int ldy, const float* w, const float* b, int k, int N, int H, int W, void* stream) {
-    PPMS_REQUIRE(x.hi && x.lo && y && w && b && N > 0 && H > 0 && W > 0 && k % 2 == 1 && k >= 1 && k <= 15, "dwconv: bad arguments");
+    PPMS_REQUIRE(x.hi && x.lo && y && w && b && N > 0 && H > 0 && W > 0 && k == 7, "dwconv: bad arguments (k = 7: ConvNeXt's depthwise kernel)");
     PPMS_REQUIRE(x.c % 8 == 0 && x.ld % 8 == 0 && ldy >= x.c && ldy % 4 == 0 && (((uintptr_t)x.hi | (uintptr_t)x.lo | (uintptr_t)y) & 15) == 0,
                  "dwconv: channel counts multiples of 8, 16-B aligned operands");
-    const int64_t npix = (int64_t)N * H * W;
-    hipLaunchKernelGGL(dwconv_plain_kernel, dim3(ceil_div(npix * (x.c / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, y, ldy, w, b, H, W, k, npix);
+    const int64_t rows = (int64_t)N * H;
+    const int cblocks = (int)ceil_div(x.c, 64);
+    const int64_t per_block = rows * ((W + DWP_PX - 1) / DWP_PX) * 8;       // threads of a full 64-channel block
+    hipLaunchKernelGGL(dwconv_plain_kernel, dim3(ceil_div(per_block, 256), cblocks), dim3(256), 0, (hipStream_t)stream, x, y, ldy, w, b, H, W, rows);
     return ppms_check_launch("dwconv");
 }
 
