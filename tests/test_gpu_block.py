@@ -214,6 +214,33 @@ def test_forward_with_hip_encoders_and_sst_vs_oracle():
     assert maxdiff(u, ru) < 1e-2
 
 
+def test_forward_batch_test_whole_model():
+    """The reference's evaluation entry point on the whole HIP model (ppmstereo.py:238-320 with nothing stubbed): 7 frames of 60 x 250
+    (padded to 64 x 256 by InputPadder, one window since kernel_size > num_ims), fnet + cnet + SST block + the 3-scale cascade, against the
+    oracle's forward_batch_test with its encoder restatements.  Sanity bound (see the conditioning note above); also deterministic."""
+    from ppmstereo_amd.ppmstereo import PPMStereo
+    m = PPMStereo()
+    m.load_hot_path_weights(W)
+    m.fnet.load_state_dict(Wm.fnet_weights(), strict=True)
+    m.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
+    sd = m.state_dict()
+    sd.update(Wm.sst_weights())
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    N, H0, W0 = 7, 60, 250
+    video = (torch.sigmoid(hash_normal((N, 2, 3, H0, W0), 951)) * 255.0).contiguous()
+    out = m.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=4)
+    out2 = m.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=4)
+    assert tuple(out["disparity"].shape) == (N, 1, H0, W0) and torch.equal(out["disparity"], out2["disparity"])
+    Wf, Ws, Wc = Wm.fnet_weights(), Wm.sst_weights(), Wm.cnet_weights()
+    ref = O.forward_batch_test(W, lambda x: O.basic_encoder(Wf, x), lambda im: O.feature_cnet(Wc, im), video, 20, 4,
+                               sst_fn=lambda a, b: O.sst_block(Ws, a, b, N))
+    err = (out["disparity"] - ref["disparity"]).abs()
+    print(f"forward_batch_test, whole model: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px")
+    assert torch.isfinite(out["disparity"]).all() and err.mean().item() < 5e-3 and err.max().item() < 1e-1
+    assert (out["uncertainties"] - ref["uncertainties"]).abs().max().item() < 2e-2
+
+
 def test_T1_gives_nan_like_reference(model):
     from ppmstereo_amd.corr import CorrBlock1D
     d = synth_scale_inputs(1, 8, 32, seed=81)

@@ -26,6 +26,10 @@ MF = "v_mfma_f32_32x32x16_bf16"
 # against 1.25 ms with scalar ops: the packed fp32 ops do not hide behind the MFMAs); needs __attribute__((target("packed-fp32-ops")))
 # on the kernel, the library being built without packed-fp32 code generation
 PK = int(os.environ.get("PPMS_ATTN_PK", "0"))
+# 1: the softmax denominator is accumulated from the PACKED bf16 probabilities (v_dot2_f32_bf16 with (1, 1): one op per pair instead of
+# two fp32 adds) -- correct (15 tests) but measured SLOWER on gfx950 (1.32 vs 1.25 ms: like the packed fp32 ops, the dot op does not
+# hide behind the MFMAs), so it stays off
+DOT = int(os.environ.get("PPMS_ATTN_DOT", "0"))
 ABL = int(os.environ.get("PPMS_ATTN_ABL", "0"))     # timing experiments only (wrong results): 1 drops the softmax VALU work, 2 the LDS
                                                     # requests and waits, 4 the MFMAs, 8 the address upkeep
 
@@ -108,29 +112,37 @@ def substep(par):
         #      feeding an exp within two instructions costs a wait state), exp of pair p + 1's second score, bf16 pack of pair p.
         p = s >> 1
         half, pb, g = elem(2 * p)
+        if p < 14:
+            _, lb, lg = elem(2 * (p + 2))
+            tile = f"cur[{lb}]"
+        else:
+            lb, lg, tile = 0, 2 * (p - 14), "nxt[0]"
+
+        def arg(j):
+            E.asm("v_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt2[{p & 1}][{j}]")],
+                  [("x", "v", f"{tile}[{lg + j}]"), ("sc", "v", "scale2[0]"), ("m", "v", f"negm2[{lb}][0]")])
+
+        pf_word = f"pf{half}[{pb}][{(g & 7) >> 1}]"
         if s % 2 == 0:
             E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[{(p + 1) & 1}][0]")], [("t", "v", f"tt2[{(p + 1) & 1}][0]")])
             if PK:
                 E.asm("v_pk_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum2[{pb}]")], [("p", "v", f"pt2[{p & 1}]")])
+            elif DOT:
+                pass                                   # (the pair is summed from its packed bf16 form, odd slot)
             else:
                 for j in range(2):
                     E.asm("v_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum2[{pb}][{j}]")], [("p", "v", f"pt2[{p & 1}][{j}]")])
         else:
-            if p < 14:
-                _, lb, lg = elem(2 * (p + 2))
-                tile = f"cur[{lb}]"
-            else:
-                lb, lg, tile = 0, 2 * (p - 14), "nxt[0]"
             if PK:
                 E.asm("v_pk_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt2[{p & 1}]")],
                       [("x", "v", f"__builtin_shufflevector({tile}, {tile}, {lg}, {lg + 1})"), ("sc", "v", "scale2"), ("m", "v", f"negm2[{lb}]")])
             else:
-                for j in range(2):
-                    E.asm("v_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt2[{p & 1}][{j}]")],
-                          [("x", "v", f"{tile}[{lg + j}]"), ("sc", "v", "scale2[0]"), ("m", "v", f"negm2[{lb}][0]")])
+                arg(0)
+                arg(1)
             E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[{(p + 1) & 1}][1]")], [("t", "v", f"tt2[{(p + 1) & 1}][1]")])
-            E.asm("v_cvt_pk_bf16_f32 {d}, {p0}, {p1}", [("d", "+v", f"pf{half}[{pb}][{(g & 7) >> 1}]")],
-                  [("p0", "v", f"pt2[{p & 1}][0]"), ("p1", "v", f"pt2[{p & 1}][1]")])
+            E.asm("v_cvt_pk_bf16_f32 {d}, {p0}, {p1}", [("d", "+v", pf_word)], [("p0", "v", f"pt2[{p & 1}][0]"), ("p1", "v", f"pt2[{p & 1}][1]")])
+            if DOT:                                    # l += P0 + P1 of the bf16 values the PV product uses: one op per pair
+                E.asm("v_dot2_f32_bf16 {l}, {w}, {one}, {l}", [("l", "+v", f"lsum2[{pb}][0]")], [("w", "v", pf_word), ("one", "s", "0x3f803f80u")])
         # ---- address upkeep: K addresses move to the next stage once this sub-tile's own K requests are out (even substeps);
         #      V addresses after the tile's last V request (odd substeps) ---------------------------------------------------------
         if par == 0 and 18 <= s < 26:
