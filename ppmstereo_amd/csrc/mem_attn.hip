@@ -371,22 +371,32 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     // ---- DMA sources of this thread (tile 0); LDS chunk q = i*256 + tid, i = 0..3 -----------------------------------
     //  K tile: row = q >> 4 (key), LDS position q & 15 holds source chunk (q & 15) ^ (row & 15)
     //  V^T tile: row d = q >> 3, LDS position q & 7 holds source chunk (q & 7) ^ ((d >> 1) & 7)     (chunk = 8 keys)
-    const char* ksrc = (const char*)(kb + ((int64_t)(clip * ksel + slot0) * n + (tid >> 4)) * D) + (((tid & 15) ^ ((tid >> 4) & 15)) << 4);
-    const char* vsrc;
+    // The 8 DMA instructions of a tile address memory as (scalar tile base) + (per-thread 32-bit offset, constant for the whole kernel):
+    // the only per-tile work is two scalar 64-bit adds, and per DMA one scalar write of M0 (the wave's LDS destination).
+    const char* kbase = (const char*)(kb + (int64_t)(clip * ksel + slot0) * n * D);                    // K tile 0 of this (clip, slot)
+    const char* vbase = (const char*)(vt + (int64_t)sel[clip * 5 + slot0] * D * n);                    // V^T tile 0 of the picked frame
+    unsigned koff[4], voff[4];
     {
-        const int frame = sel[clip * 5 + slot0];
         const int d = tid >> 3;
-        vsrc = (const char*)(vt + ((int64_t)frame * D + d) * n) + (((tid & 7) ^ ((d >> 1) & 7)) << 4);
+        const unsigned k0 = (unsigned)((tid >> 4) * D * 2 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4));
+        const unsigned v0 = (unsigned)(d * n * 2 + (((tid & 7) ^ ((d >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            koff[i] = k0 + (unsigned)(i * 16 * D * 2);
+            voff[i] = v0 + (unsigned)(i * 32 * n * 2);            // V^T rows d + 32 i  (128 rows x n keys x 2 B < 4 GiB)
+        }
     }
-    const int64_t vrow32 = (int64_t)32 * n * 2;   // bytes between V^T rows d and d + 32
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem + wave * 1024);
     auto issue_tile = [&](int j) __attribute__((always_inline)) {
-        char* st = smem + (j & (ATT_NS - 1)) * ATT_STAGE + wave * 1024;
-        const char* kp = ksrc + (int64_t)j * KT * D * 2;
-        const char* vp = vsrc + (int64_t)j * KT * 2;
+        const unsigned st = lds_wave + (unsigned)((j & (ATT_NS - 1)) * ATT_STAGE);
+        const char* kp = kbase + (int64_t)j * KT * D * 2;
+        const char* vp = vbase + (int64_t)j * KT * 2;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) att_dma16(kp + i * 16 * D * 2, st + i * 4096);
+        for (int i = 0; i < 4; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(koff[i]), "s"(kp), "s"(st + (unsigned)(i * 4096)) : "memory");
 #pragma unroll
-        for (int i = 0; i < 4; ++i) att_dma16(vp + i * vrow32, st + K_TILE + i * 4096);
+        for (int i = 0; i < 4; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[i]), "s"(vp), "s"(st + (unsigned)(K_TILE + i * 4096)) : "memory");
     };
 
     f32x16 o[4][QB];
