@@ -140,6 +140,12 @@ int ppms_conv_gemm4(const ppms_conv* desc, const ppms_conv* dev_desc, int tile_p
  * (conv_gemm5.hip): 51 200 pixels = 240 tiles of 224 on 256 CUs.  Weights: pack_conv4.  nbt = 0: the library picks. */
 int ppms_conv_gemm5_applicable(const ppms_conv* desc);
 int ppms_conv_gemm5(const ppms_conv* desc, const ppms_conv* dev_desc, int nbt, void* stream);
+/* K-sliced form of the same kernel for maps with fewer tiles than CUs (the 1/8 and 1/16 scales): nslice workgroups share each
+ * tile, each sweeps its share of the activation windows and writes fp32 partial sums to the caller's workspace
+ * (ppms_conv_gemm2_slice_workspace_bytes(desc, nslice)); the slice-reduce kernel then sums them in slice order and runs the fused
+ * epilogue (bit-reproducible).  ppms_conv_gemm5_slices: the slice count that fills the chip in one round, 0 = not applicable. */
+int ppms_conv_gemm5_slices(const ppms_conv* desc);
+int ppms_conv_gemm5_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int nbt, int nslice, void* workspace, void* stream);
 /* sizeof(ppms_sp), sizeof(ppms_epilogue), sizeof(ppms_conv) as compiled: lets a foreign-language binding check its
  * struct layout at load time */
 int ppms_struct_sizes(int* sp, int* epilogue, int* conv);

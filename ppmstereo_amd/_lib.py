@@ -63,6 +63,8 @@ _SIGS = {
     "ppms_conv_gemm4": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
     "ppms_conv_gemm5_applicable": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm5": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
+    "ppms_conv_gemm5_slices": (c_int, [C.POINTER(Conv)]),
+    "ppms_conv_gemm5_sliced": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ppms_struct_sizes": (c_int, [C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),
     "ppms_dwconv_gelu": (c_int, [SP, SP, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_flow_patch7": (c_int, [c_void_p, SP, c_int, c_int, c_int, c_void_p]),

@@ -95,3 +95,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
         default: return x;
     }
 }
+
+// conv_gemm2.hip: the reduce half of a K-sliced convolution launch (shared with conv_gemm5.hip)
+struct ppms_conv;
+int ppms_launch_slice_reduce(const ppms_conv* d, const ppms_conv* dev_desc, const float* workspace, int nslice, void* stream);

@@ -441,6 +441,14 @@ extern "C" int64_t ppms_conv_gemm2_slice_workspace_bytes(const ppms_conv* d, int
     return (int64_t)nslice * d->T * d->H * d->W * d->M * 4;
 }
 
+// second half of every K-sliced launch (also conv_gemm5.hip's): sums the slices' partial tiles, adds the bias, runs the fused epilogue
+int ppms_launch_slice_reduce(const ppms_conv* d, const ppms_conv* dev_desc, const float* workspace, int nslice, void* stream) {
+    const int64_t P = (int64_t)d->T * d->H * d->W;
+    const int64_t total = P * (d->M / 8);
+    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dev_desc, workspace, nslice, P);
+    return ppms_check_launch("conv_slice_reduce");
+}
+
 // K-sliced form for small maps: nslice workgroups share each output tile (each takes every nslice-th row-step of the K loop
 // and writes fp32 partial sums to `workspace`), then a reduce kernel sums them in slice order and runs the fused epilogue.
 extern "C" int ppms_conv_gemm2_sliced(const ppms_conv* d, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream) {

@@ -37,6 +37,9 @@ struct Geo5 {
     int nchunk, n0;          // 16-channel chunks per tap (all segments), chunks of segment 0
     int kgroups;             // 1: M = 256 (4 cout blocks x 2 pixel halves), 2: M = 128 (2 x 2 x two K-groups)
     int npieces;             // DMA pieces per thread of a K-group and window
+    int nslice;              // grid-level K slices (gridDim.y): slice s takes the s-th share of every K-group's windows (small maps)
+    float* part;             // nslice > 1: fp32 partial sums [slice][pixel][M] (no bias), finished by the slice-reduce kernel
+    int64_t P;               // pixels = T*H*W
 };
 
 __device__ __forceinline__ void dma16_5(const void* src, char* lds_dst) {
@@ -172,8 +175,13 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
     const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
     const int kz1 = (ht + T + p.t_halo - 1 - tf) < (p.kt - 1) ? (ht + T + p.t_halo - 1 - tf) : (p.kt - 1);
     const int rows_per_kz = g.rdy ? p.kh : 1;
-    const int win0 = kz0 * rows_per_kz * g.nchunk + kg;                 // this K-group's first window; it takes every kgroups-th one
-    const int nwin = (kz1 + 1 - kz0) * rows_per_kz * g.nchunk / g.kgroups;
+    int win0 = kz0 * rows_per_kz * g.nchunk + kg;                       // this K-group's first window; it takes every kgroups-th one
+    int nwin = (kz1 + 1 - kz0) * rows_per_kz * g.nchunk / g.kgroups;
+    if (g.nslice > 1) {                                                 // K-sliced launch: this workgroup's share of those windows
+        const int i0 = (int)blockIdx.y * nwin / g.nslice, i1 = ((int)blockIdx.y + 1) * nwin / g.nslice;
+        win0 += g.kgroups * i0;
+        nwin = i1 - i0;                                                 // (>= 1: the host keeps nslice <= the smallest window count)
+    }
     const int wstride = g.kgroups;
     const int nsteps = nwin * g.nsweep;
 
@@ -355,9 +363,15 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
             const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
             if (px < W && py < H) {
                 const int64_t pix = (int64_t)(tf * H + py) * W + px;
+                if (g.nslice > 1) {                                  // raw partial sums; bias and the fused epilogue run in the reduce kernel
+                    float* pp = g.part + ((int64_t)blockIdx.y * g.P + pix) * p.M + cblock + q * 8;
+                    *(f32x4*)pp = (f32x4){v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(pp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
+                } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += b8[j];
-                epilogue_row8(e, v, pix, cbase + q * 8, HW);
+                    for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                    epilogue_row8(e, v, pix, cbase + q * 8, HW);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -365,7 +379,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
 }
 
 // tile shape / window geometry for a descriptor; picks (NBT, C) with the best chip fill; false when nothing fits
-static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0) {
+static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = false) {
     const int mode = (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);      // 0: x sweep, 1: y sweep, 2: 2-D sweep
     const int hx = mode != 1 ? d->kw - 1 : 0, hy = mode != 0 ? d->kh - 1 : 0;   // window halo (total) in x / y
     const int kgroups = d->M == 128 ? 2 : 1;
@@ -383,7 +397,9 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0) {
             if (Wr > 384) continue;
             const int64_t tiles = (int64_t)((d->W + C - 1) / C) * ((d->H + R - 1) / R) * d->T;
             // useful pixels per CU-slot-round: rounds of 256 workgroups (one per CU), each costing nbt blocks
-            const double eff = (double)d->T * d->H * d->W / ((double)((tiles + 255) / 256) * 256 * 32 * nbt);
+            // (K-sliced launches of small maps fill the chip through the slices: there only the ragged tile edges count)
+            const double eff = sliced ? (double)d->T * d->H * d->W / ((double)tiles * 32 * nbt)
+                                      : (double)d->T * d->H * d->W / ((double)((tiles + 255) / 256) * 256 * 32 * nbt);
             if (eff > best + 1e-9 || (eff > best - 1e-9 && Wr < bestWr)) best = eff, bestC = C, bestN = nbt, bestWr = Wr;
         }
     }
@@ -410,6 +426,9 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0) {
     g.n0 = d->seg[0].c / 16;
     g.kgroups = kgroups;
     g.npieces = (g.Wr * 4 + GT - 1) / GT;
+    g.nslice = 1;
+    g.part = nullptr;
+    g.P = (int64_t)d->T * d->H * d->W;
     return g.npieces <= MAXS5 && nchunk % kgroups == 0;
 }
 
@@ -427,7 +446,57 @@ extern "C" int ppms_conv_gemm5_applicable(const ppms_conv* d) {
     return (int64_t)g.tiles_x * g.tiles_y * d->T >= 200 ? 1 : 0;   // fewer workgroups than CUs: conv_gemm2's K slicing fills the chip better
 }
 
+// smallest number of windows any (tile, K-group) pair of the launch sweeps: frames at the ends of the volume skip the temporal taps
+// that fall outside it
+static int min_windows5(const ppms_conv* d, const Geo5& g) {
+    const int ht = d->kt >> 1;
+    int kz_min = d->kt;
+    for (int tf = 0; tf < d->T; ++tf) {
+        const int kz0 = (ht - tf - d->t_halo) > 0 ? (ht - tf - d->t_halo) : 0;
+        const int kz1 = (ht + d->T + d->t_halo - 1 - tf) < (d->kt - 1) ? (ht + d->T + d->t_halo - 1 - tf) : (d->kt - 1);
+        if (kz1 + 1 - kz0 < kz_min) kz_min = kz1 + 1 - kz0;
+    }
+    return kz_min * (g.rdy ? d->kh : 1) * g.nchunk / g.kgroups;
+}
+
+// Small maps (fewer tiles than CUs): how many grid-level K slices let this kernel fill the chip.  0: not applicable / not worth it.
+extern "C" int ppms_conv_gemm5_slices(const ppms_conv* d) {
+    if (d == nullptr || (d->M != 256 && d->M != 128) || d->m_split % 64 != 0 || d->nseg < 1 || d->nseg > 2) return 0;
+    if (d->kw == 1 && d->kh == 1) return 0;
+    if (d->epi[0].out_vt != nullptr || (d->m_split < d->M && d->epi[1].out_vt != nullptr)) return 0;   // V^T is written from the accumulators
+    for (int s = 0; s < d->nseg; ++s)
+        if (d->seg[s].c <= 0 || d->seg[s].c % 16 != 0) return 0;
+    Geo5 g;
+    if (!plan5(d, g, 0, true) || g.nsweep < 3) return 0;
+    const int64_t tiles = (int64_t)g.tiles_x * g.tiles_y * d->T;
+    if (tiles >= 200 || tiles < 8) return 0;
+    int ns = (int)((256 + tiles - 1) / tiles);                        // one workgroup per CU, one round
+    if (tiles * ns > 288) --ns;
+    const int wmin = min_windows5(d, g);
+    if (ns > wmin) ns = wmin;
+    if (ns > 16) ns = 16;
+    return ns >= 2 ? ns : 0;
+}
+
+static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, int nslice, float* part, void* stream);
+
 extern "C" int ppms_conv_gemm5(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, void* stream) {
+    return conv5_launch(d, dev_desc, nbt, 1, nullptr, stream);
+}
+
+// K-sliced form for small maps: nslice workgroups share each output tile (each sweeps its share of the windows and writes fp32 partial
+// sums to `workspace`, ppms_conv_gemm2_slice_workspace_bytes), then the slice-reduce kernel of conv_gemm2.hip sums them in slice order
+// (bit-reproducible) and runs the fused epilogue.
+extern "C" int ppms_conv_gemm5_sliced(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, int nslice, void* workspace, void* stream) {
+    PPMS_REQUIRE(nslice >= 1 && nslice <= 16, "conv_gemm5_sliced: nslice=%d", nslice);
+    if (nslice == 1) return conv5_launch(d, dev_desc, nbt, 1, nullptr, stream);
+    PPMS_REQUIRE(workspace != nullptr && ((uintptr_t)workspace & 15) == 0, "conv_gemm5_sliced: workspace missing or not 16-B aligned");
+    const int rc = conv5_launch(d, dev_desc, nbt, nslice, (float*)workspace, stream);
+    if (rc != 0) return rc;
+    return ppms_launch_slice_reduce(d, dev_desc, (const float*)workspace, nslice, stream);
+}
+
+static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, int nslice, float* part, void* stream) {
     PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm5: null descriptor");
     PPMS_REQUIRE(nbt == 0 || nbt == 7 || nbt == 8, "conv_gemm5: nbt must be 0 (choose), 7 or 8");
     PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm5: nseg=%d", d->nseg);
@@ -458,8 +527,14 @@ extern "C" int ppms_conv_gemm5(const ppms_conv* d, const ppms_conv* dev_desc, in
         if (e.kind == PPMS_EPI_GRU) PPMS_REQUIRE(e.aux_f32 != nullptr, "conv_gemm5: GRU epilogue needs z");
     }
     Geo5 g;
-    PPMS_REQUIRE(plan5(d, g, nbt), "conv_gemm5: no tile shape fits the LDS window");
+    PPMS_REQUIRE(plan5(d, g, nbt, nslice > 1), "conv_gemm5: no tile shape fits the LDS window");
     PPMS_REQUIRE(g.nsweep >= 3, "conv_gemm5: the sweep must have at least 3 taps");
+    if (nslice > 1) {
+        PPMS_REQUIRE(d->epi[0].out_vt == nullptr && (d->m_split >= d->M || d->epi[1].out_vt == nullptr), "conv_gemm5: sliced launch cannot write out_vt");
+        PPMS_REQUIRE(nslice <= min_windows5(d, g), "conv_gemm5: %d slices for %d windows", nslice, min_windows5(d, g));
+        g.nslice = nslice;
+        g.part = part;
+    }
     PPMS_REQUIRE(g.npieces <= 14 && g.npieces >= 1, "conv_gemm5: window of %d rows needs too many DMA pieces", g.Wr);
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
     size_t lds = (size_t)2 * g.kgroups * g.npieces * (NT5 / g.kgroups) * 16;        // the K-groups' pairs of window buffers
@@ -468,6 +543,6 @@ extern "C" int ppms_conv_gemm5(const ppms_conv* d, const ppms_conv* dev_desc, in
     PPMS_REQUIRE(lds <= 160 * 1024, "conv_gemm5: LDS budget exceeded (%zu B)", lds);
     static ppms_device_once once;
     once.run([] { (void)hipFuncSetAttribute((const void*)conv5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    hipLaunchKernelGGL(conv5_kernel, dim3(ntiles), dim3(NT5), lds, (hipStream_t)stream, dev_desc, g);
+    hipLaunchKernelGGL(conv5_kernel, dim3(ntiles, g.nslice), dim3(NT5), lds, (hipStream_t)stream, dev_desc, g);
     return ppms_check_launch("conv_gemm5");
 }

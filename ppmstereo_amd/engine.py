@@ -32,6 +32,9 @@ TOP_K = 5
 # tuning switches between HIP code paths of the library (A/B measurements on the GPU box; every setting runs HIP kernels only)
 USE_CONV4 = os.environ.get("PPMS_CONV4", "0") != "0"      # barrier-free k-loop kernel (conv_gemm4.hip): measured equal to conv_gemm3 so far, off
 USE_CONV5 = os.environ.get("PPMS_CONV5", "1") != "0"      # one 8-wave workgroup per CU, 7- / 8-block tiles (conv_gemm5.hip) where it applies
+# conv_gemm5's K-sliced form on the small maps (1/8, 1/16 scales): correct (tests) but measured SLOWER than conv_gemm2's slicing there
+# (1/8-scale iteration 1293 vs 1252 us, 1/16: 1072 vs 1017 us: per-workgroup fixed costs and 5 x the partial-sum traffic), so off
+USE_CONV5_SLICED = os.environ.get("PPMS_CONV5_SLICED", "0") != "0"
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
 _YS = os.environ.get("PPMS_YSWEEP", "1")                  # conv_gemm2 one-window forms: 0 = off, 1 = y-swept (1, kh, 1) convs (default),
@@ -76,6 +79,9 @@ class ConvOp:
         # small maps: K-sliced launch + reduce kernel (nslice None: ask the library; own workspace per op because ops
         # of the two streams run concurrently)
         self.nslice, self.ws = 1, None
+        if version == 5 and nslice is not None and nslice > 1:      # conv_gemm5's K-sliced form (same workspace layout as conv_gemm2's)
+            self.nslice = int(nslice)
+            self.ws = torch.empty(int(L.load().ppms_conv_gemm2_slice_workspace_bytes(C.byref(desc), self.nslice)), dtype=torch.uint8, device=device)
         if version == 2 and wm_hint == 0 and (nslice is not None or USE_SLICES):
             plan = L.load().ppms_conv_gemm2_ysweep_slices if ysweep else L.load().ppms_conv_gemm2_slices
             self.nslice = max(1, int(plan(C.byref(desc)))) if nslice is None else nslice
@@ -102,7 +108,9 @@ class ConvOp:
             self._launch()
 
     def _launch(self):
-        if self.version == 5:
+        if self.version == 5 and self.nslice > 1:
+            L.check(L.load().ppms_conv_gemm5_sliced(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, self.nslice, self.ws.data_ptr(), L.stream_ptr()))
+        elif self.version == 5:
             L.check(L.load().ppms_conv_gemm5(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         elif self.version == 4:
             L.check(L.load().ppms_conv_gemm4(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
@@ -410,6 +418,10 @@ class ScaleEngine:
         real = d4.epi[0].n_valid + (d4.epi[1].n_valid if d4.m_split < d4.M else 0)
         if USE_CONV5 and 2 * real > meta4["M"] and self.lib.ppms_conv_gemm5_applicable(C.byref(d4)):
             return ConvOp(d4, [packed4, bias4, *keep], 5, device=self.dev)
+        if USE_CONV5 and USE_CONV5_SLICED and 2 * real > meta4["M"]:
+            ns = int(self.lib.ppms_conv_gemm5_slices(C.byref(d4)))
+            if ns >= 2:
+                return ConvOp(d4, [packed4, bias4, *keep], 5, nslice=ns, device=self.dev)
         if USE_CONV4 and self.lib.ppms_conv_gemm4_applicable(C.byref(d4)):
             return ConvOp(d4, [packed4, bias4, *keep], 4, device=self.dev)
         return None

@@ -123,6 +123,9 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     d.kt, d.kh, d.kw = k3
     d.M = d.m_split = meta["M"]
     d.epi[0] = e
+    if version == 5 and nslice is not None and nslice < 0:                 # -1: let the library plan the slices (must find some)
+        nslice = int(L.load().ppms_conv_gemm5_slices(C.byref(d)))
+        assert nslice >= 2, nslice
     ConvOp(d, keep, version, tile_px if version in (4, 5) else wm, nslice=nslice if nslice is not None else 1, ysweep=ysweep)()
     torch.cuda.synchronize()
     sp = out.to_f32()[:, :cout].cpu()
@@ -242,6 +245,27 @@ def test_conv_gemm4_vs_torch(lib, name, T, H, W, segs, cout, k3, tile):
     z = torch.sigmoid(hash_normal((P, cout), 304))
     got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=tile, seg_pad=seg_pad, kind=lib.EPI_GRU, aux=aux, z=z)
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3,nslice", [
+    ("x15_scale8", 5, 40, 64, [128, 256], 256, (1, 1, 15), -1), ("x15_scale16", 5, 20, 32, [128, 256], 256, (1, 1, 15), -1),
+    ("y5_m128", 5, 20, 32, [128, 256], 128, (1, 5, 1), 4), ("3x3_m128_uneven", 2, 24, 40, [64, 32], 100, (1, 3, 3), 2),
+    ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3), 5), ("3x3_m256_scale8", 5, 40, 64, [128], 256, (1, 3, 3), -1)])
+def test_conv_gemm5_sliced_vs_torch(lib, name, T, H, W, segs, cout, k3, nslice):
+    """conv_gemm5's K-sliced form (small maps: nslice workgroups per tile, each with its share of the windows, fp32 partials + the
+    slice-reduce kernel with the fused epilogue): x / y / 2-D sweeps, M = 256 and M = 128 (two K-groups per workgroup), uneven
+    shares, temporal taps whose window count differs between frames, the library's own plan (-1) -- vs torch conv3d."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    seg_pad = [((c + 15) // 16) * 16 for c in segs]
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=5, seg_pad=seg_pad, nslice=nslice, act=1)
+    assert maxdiff(got, torch.relu(ref)) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    again = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=5, seg_pad=seg_pad, nslice=nslice, act=1)
+    assert torch.equal(got, again), "sliced launches must be bit-reproducible"
 
 
 @pytest.mark.parametrize("nbt", [5007, 5008])
