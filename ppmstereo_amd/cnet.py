@@ -148,11 +148,13 @@ class Feature(nn.Module):
         key = (N, H, W, x.device.index)
         eng = self._engines.get(key)
         if eng is None:
-            eng = _CnetEngine(self._pack(x.device), N, H, W, x.device)
+            with torch.cuda.device(x.device):
+                eng = _CnetEngine(self._pack(x.device), N, H, W, x.device)
             self._engines[key] = eng
             while len(self._engines) > 2:
                 self._engines.popitem(last=False)
-        return eng.run(x.contiguous())
+        with torch.cuda.device(x.device):                        # launches go to the current stream OF THE TENSOR'S device
+            return eng.run(x.contiguous())
 
 
 class _CnetEngine:

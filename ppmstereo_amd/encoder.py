@@ -122,11 +122,13 @@ class BasicEncoder(nn.Module):
         key = (N, H, W, img.device.index)
         eng = self._engines.get(key)
         if eng is None:
-            eng = _FnetEngine(self._pack(img.device), N, H, W, img.device, self.output_dim)
+            with torch.cuda.device(img.device):
+                eng = _FnetEngine(self._pack(img.device), N, H, W, img.device, self.output_dim)
             self._engines[key] = eng
             while len(self._engines) > 2:
                 self._engines.popitem(last=False)
-        out = eng.run(img)
+        with torch.cuda.device(img.device):                      # launches go to the current stream OF THE TENSOR'S device
+            out = eng.run(img)
         if is_list:
             return torch.split(out, out.shape[0] // 2, dim=0)
         return out

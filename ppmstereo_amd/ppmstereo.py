@@ -355,16 +355,40 @@ class PPMStereo(PPMStereoHotPath):
             return torch.stack(preds)[:, None], torch.stack(uncs)[:, None]
 
     @torch.no_grad()
-    def forward_batch_test(self, batch_dict: Dict, kernel_size: int = 20, iters: int = 20, device=None):
+    def forward_batch_test(self, batch_dict: Dict, kernel_size: int = 20, iters: int = 20, device=None, shard_ranks: bool = False):
         """PPMStereo.forward_batch_test (ppmstereo.py:238-320): batch_dict["stereo_video"] (N, 2, 3, H, W) on the host;
         per window: InputPadder(divis_by=32), one host->device copy, forward(test_mode=True), unpad, one device->host copy;
         windows of ``kernel_size`` frames every ``kernel_size // 2``, centre frames kept (:296-307).  Windows whose output the
-        reference computes and then drops are not run.  Returns {"disparity", "uncertainties"}: (N, 1, H, W) CPU tensors."""
+        reference computes and then drops are not run.  Returns {"disparity", "uncertainties"}: (N, 1, H, W) CPU tensors.
+        shard_ranks: under torch.distributed the windows are dealt round-robin over the ranks (independent units, no data-path
+        collective) and the kept frames are gathered once at the end (``dist.gather_kept_frames``); every rank returns the video."""
         video = batch_dict["stereo_video"]
         num_ims = len(video)
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         disp_preds, uncertainties = [], []
-        for start, stop, keep_from, keep_to in window_plan(num_ims, kernel_size):
+        plan = window_plan(num_ims, kernel_size)
+        if shard_ranks and torch.distributed.is_available() and torch.distributed.is_initialized():
+            from . import dist as D
+            rank, world = torch.distributed.get_rank(), torch.distributed.get_world_size()
+            mine_d, mine_u, first = [], [], 0
+            firsts = []
+            for start, stop, keep_from, keep_to in plan:          # first kept frame of every window in video coordinates
+                firsts.append(start + keep_from)
+            for wi, (start, stop, keep_from, keep_to) in enumerate(plan):
+                if wi % world != rank:
+                    continue
+                left, right = video[start:stop, 0], video[start:stop, 1]
+                padder = InputPadder(left.shape, divis_by=32)
+                left, right = padder.pad(left, right)
+                d, u = self.forward(left[None].to(dev), right[None].to(dev), iters=iters, test_mode=True)
+                d, u = padder.unpad(d[0]), padder.unpad(u[0])               # (T, 1, H0, W0)
+                mine_d.append((firsts[wi], d[keep_from:keep_to].abs()[:, :1]))
+                mine_u.append((firsts[wi], u[keep_from:keep_to].abs()[:, :1]))
+            H0, W0 = video.shape[-2:]
+            disp = D.gather_kept_frames(mine_d, num_ims, H0, W0)
+            unc = D.gather_kept_frames(mine_u, num_ims, H0, W0)
+            return {"disparity": disp.cpu(), "uncertainties": unc.cpu()}
+        for start, stop, keep_from, keep_to in plan:
             left, right = video[start:stop, 0], video[start:stop, 1]
             padder = InputPadder(left.shape, divis_by=32)
             left, right = padder.pad(left, right)

@@ -135,11 +135,13 @@ class SSTBlock(nn.Module):
             te = self.time_embed.detach().float()
             if T != self.num_frames:                                  # ppmstereo.py:347-352
                 te = F.interpolate(te.transpose(1, 2), size=T, mode="nearest").transpose(1, 2).contiguous()
-            eng = _SstEngine(self._pack(f1.device), te[0], T, h, w, f1.device)
+            with torch.cuda.device(f1.device):
+                eng = _SstEngine(self._pack(f1.device), te[0], T, h, w, f1.device)
             self._engines[key] = eng
             while len(self._engines) > 2:
                 self._engines.popitem(last=False)
-        return eng.run(f1.contiguous().float(), f2.contiguous().float())
+        with torch.cuda.device(f1.device):                       # launches go to the current stream OF THE TENSOR'S device
+            return eng.run(f1.contiguous().float(), f2.contiguous().float())
 
 
 class _SstEngine:

@@ -66,3 +66,40 @@ def test_sharded_cascade_equals_unsharded_on_the_gpu(tmp_path, c3d):
         assert res["finite"] and res["npred"] == 8
         assert res["disp"] <= 5e-5 * max(1.0, res["scale"]), res
         assert res["unc"] <= 2e-4, res
+
+
+def _window_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from ppmstereo_amd import dist as D
+    from ppmstereo_amd import weights as Wm
+    from ppmstereo_amd.ppmstereo import PPMStereo
+    from stub_encoders import StubCNet, StubFNet, frame_video
+    D.init_from_env("gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    m = PPMStereo(fnet=StubFNet(), cnet=StubCNet(), sst=None).load_hot_path_weights(Wm.hot_path_weights()).to(dev).eval()
+    video = frame_video(45, 60, 250)                        # kernel_size 20: windows [0,20) [10,30) [20,40) [30,45)
+    sharded = m.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=2, shard_ranks=True)
+    torch.cuda.synchronize()
+    D.barrier()
+    res = dict(shape=tuple(sharded["disparity"].shape))
+    if rank == 0:
+        full = m.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=2)
+        res.update(equal=bool(torch.equal(full["disparity"], sharded["disparity"]) and torch.equal(full["uncertainties"], sharded["uncertainties"])),
+                   nonzero=bool((sharded["disparity"].abs().amax((1, 2, 3)) > 0).all()))
+    torch.save(res, out + f".{rank}")
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_window_sharded_forward_batch_test_on_the_gpu(tmp_path):
+    """SURVEY 8e level 1 with a driver on the GPU: forward_batch_test(shard_ranks=True) deals the sliding windows of a 45-frame video
+    round-robin over two ranks (independent units, no data-path collective), gathers the kept frames once at the end
+    (dist.gather_kept_frames) and must return, on every rank, exactly the single-process result (same kernels per window)."""
+    out = str(tmp_path / "win.pt")
+    mp.spawn(_window_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0["shape"] == r1["shape"] == (45, 1, 60, 250)
+    assert r0["equal"] and r0["nonzero"], r0
