@@ -49,12 +49,9 @@ __device__ __forceinline__ void dma16_5(const void* src, char* lds_dst) {
 // s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
 __device__ __forceinline__ void vm_wait5(int n) {
 #define PPMS_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    if (n == 8) {                                  // the steady state
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        return;
-    }
-    switch (n) {
-        PPMS_VMW(4) PPMS_VMW(9) PPMS_VMW(10) PPMS_VMW(11) PPMS_VMW(12) PPMS_VMW(13) PPMS_VMW(14)
+    switch (n) {      // n = DMA pieces per thread and window (1..3 for the 512-thread gather of M = 256, 2..8 for M = 128 / GEMM-mode windows)
+        PPMS_VMW(1) PPMS_VMW(2) PPMS_VMW(3) PPMS_VMW(4) PPMS_VMW(5) PPMS_VMW(6) PPMS_VMW(7) PPMS_VMW(8) PPMS_VMW(9) PPMS_VMW(10) PPMS_VMW(11)
+        PPMS_VMW(12) PPMS_VMW(13) PPMS_VMW(14)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;      // 0, and any other count: the safe full drain
     }
 #undef PPMS_VMW
