@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int NT5 = 512;
-constexpr int MAXS5 = 6;                      // window 16-B pieces per thread of a K-group
+constexpr int MAXS5 = 8;                      // window 16-B pieces per thread of a K-group
 constexpr int DEPTH5 = 2;                     // A-fragment stages in registers: the next step's are loaded during this step's first MFMA group
 
 __device__ __attribute__((aligned(256))) unsigned int g_zero_page5[64];     // zero-initialised: source of padded rows
@@ -37,6 +37,10 @@ struct Geo5 {
     int nchunk, n0;          // 16-channel chunks per tap (all segments), chunks of segment 0
     int kgroups;             // 1: M = 256 (4 cout blocks x 2 pixel halves), 2: M = 128 (2 x 2 x two K-groups)
     int npieces;             // DMA pieces per thread of a K-group and window
+    int RW, logRW;           // 16-channel chunks per window row: 1 (a window = 16 channels, swept by the spatial taps) or, for convs
+                             // without a spatial sweep (kh = kw = 1: GEMM mode), 4 / 2 (M = 256 / 128): the "sweep" then steps through
+                             // the chunks of the 256- / 128-byte rows; nchunk / n0 count WINDOWS (16 RW channels) in that mode
+    int trow_inc;            // LDS row advance per step inside a window: 1 (sweep), 0 (GEMM mode)
     int nslice;              // grid-level K slices (gridDim.y): slice s takes the s-th share of every K-group's windows (small maps)
     float* part;             // nslice > 1: fp32 partial sums [slice][pixel][M] (no bias), finished by the slice-reduce kernel
     int64_t P;               // pixels = T*H*W
@@ -92,19 +96,24 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
     // per slot ONE register: pixel offset at (dt, dy) = 0 in the low 22 bits (the volume has < 2^22 pixels), y + 512 in the high 10
     // (the halo puts y in [-7, H + 7]); -1: column outside the image / slot unused
     int sl[MAXS5];
-    const int nq = g.Wr * 4;
+    const int nq = (g.Wr * 4) << g.logRW;
 #pragma unroll
     for (int i = 0; i < MAXS5; ++i) {
         const int q = gt + i * GT;
         sl[i] = -1;
         if (q < nq) {
-            const int wrow = q >> 2;
+            const int wrow = q >> (2 + g.logRW);
             const int wy = wrow / g.WRL, wx = wrow - wy * g.WRL;
             const int x = x0 + wx - g.hxw, y = y0 + wy - g.hyw;
             if ((unsigned)x < (unsigned)W && (tf * H + y) * W + x >= 0) sl[i] = ((tf * H + y) * W + x) | ((y + 512) << 22);
         }
     }
-    const int src_chunk = (gt & 3) ^ ((gt >> 4) & 3);            // 0,1: hi k0-7 / k8-15;  2,3: lo k0-7 / k8-15
+    // GEMM mode (RW > 1): a row is RW 64-B blocks; block b of row `row` holds channel chunk (b - row) mod RW (rows that are read
+    // together by consecutive lanes then start in different bank quarters), inside a block the 16-B parts are swizzled as above.
+    // GT >> (2 + logRW) is a multiple of 16, so row & 15 is the same for every piece of a thread.
+    const int row0 = gt >> (2 + g.logRW);
+    const int src_sub = (((gt >> 2) & (g.RW - 1)) - row0) & (g.RW - 1);
+    const int src_chunk = (gt & 3) ^ ((row0 >> 2) & 3);          // 0,1: hi k0-7 / k8-15;  2,3: lo k0-7 / k8-15
     const int src_plane = src_chunk >> 1, src_k8 = (src_chunk & 1) * 8;
 
     // every descriptor field the loop needs, fetched once (a descriptor load inside the loop would make the compiler drain
@@ -126,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
             dt = rowstep - ht;
         }
         const int sg = (chunk >= g.n0) ? 1 : 0;
-        const int c0 = (chunk - (sg ? g.n0 : 0)) * 16 + src_k8;
+        const int c0 = (((chunk - (sg ? g.n0 : 0)) << g.logRW) + src_sub) * 16 + src_k8;
         const bf16_t* sp = sg ? sp1 : sp0;
         const int ld = sg ? ld1 : ld0;
         const bool tok = (unsigned)(tf + dt + p.t_halo) < (unsigned)(T + 2 * p.t_halo);
@@ -185,10 +194,11 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)wbase;
     // LDS byte address of the hi fragment (chunk h) of pixel block nb at window-row offset TROW of buffer BUF; the lo fragment
     // (chunk 2 + h) of the same row is that address ^ 32
-#define CONV5_ADDR(DST, NBW, BUF, TROW)                                                                                        \
+    // (GEMM mode: SUB = the chunk of the row this step multiplies, stored in block (SUB + row) mod RW; sweep modes: RW = 1, block 0)
+#define CONV5_ADDR(DST, NBW, BUF, TROW, SUB)                                                                                   \
     _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb) {                                                                      \
         const int row = brow[nb] + (TROW);                                                                                     \
-        DST[nb] = lds0 + (BUF) * wbytes + row * 64 + ((h ^ ((row >> 2) & 3)) << 4);                                            \
+        DST[nb] = lds0 + (BUF) * wbytes + ((row * 64) << g.logRW) + ((((SUB) + row) & (g.RW - 1)) << 6) + ((h ^ ((row >> 2) & 3)) << 4); \
     }
     // One k16-step with static A stage U and static block count NBW.  Pipeline:
     //   top:     wait for A(jj) (requested during the previous step's group 1) and for the hi fragments (previous step's group 3)
@@ -227,13 +237,13 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
             }                                                                                                                  \
             ++w;                                                                                                               \
         } else {                                                                                                               \
-            ++trow;                                                                                                            \
+            trow += g.trow_inc;                                                                                                \
             if (++swx == g.swx_n) {                                                                                            \
                 swx = 0;                                                                                                       \
                 trow += g.row_jump;                                                                                            \
             }                                                                                                                  \
         }                                                                                                                      \
-        if (ahead > 0) { CONV5_ADDR(adr_hi, NBW, w & 1, trow) }                                                                \
+        if (ahead > 0) { CONV5_ADDR(adr_hi, NBW, w & 1, trow, sw) }                                                              \
         mfma_group3<NBW, MORE>(acc, areg[U][0], areg[U][2], bh, areg[U][1], areg[U][3], bx, adr_hi);                                                 \
     }
     // the whole K loop for a static block count
@@ -251,10 +261,10 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
         __builtin_amdgcn_s_barrier();                                                                                          \
         if (nwin > 1) dma_b(win0 + wstride, 1);                                                                                \
         int sw = 0, swx = 0, trow = 0, w = 0;                                                                                  \
-        int la_s = 1, la_ks = win0 * g.nsweep + 1; /* tap / packed k16-step of the next A load (nsweep >= 3); stops at the last step */ \
+        int la_s = 1, la_ks = win0 * g.nsweep + 1; /* tap / packed k16-step of the next A load (nsweep >= 2); stops at the last step */ \
         bf16x8 bh[4], bx[2];                                                                                                  \
         unsigned adr_hi[4];                                                                                                    \
-        CONV5_ADDR(adr_hi, NBW, 0, 0)                                                                                          \
+        CONV5_ADDR(adr_hi, NBW, 0, 0, 0)                                                                                       \
         _Pragma("unroll") for (int nb = 0; nb < (NBW); ++nb)                                                                    \
             asm volatile("ds_read_b128 %0, %1" : "+v"(bh[nb]) : "v"(adr_hi[nb]) : "memory");                                   \
         int j = 0;                                                                                                             \
@@ -377,12 +387,17 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
 
 // tile shape / window geometry for a descriptor; picks (NBT, C) with the best chip fill; false when nothing fits
 static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = false) {
-    const int mode = (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);      // 0: x sweep, 1: y sweep, 2: 2-D sweep
-    const int hx = mode != 1 ? d->kw - 1 : 0, hy = mode != 0 ? d->kh - 1 : 0;   // window halo (total) in x / y
+    const bool gemm = d->kw == 1 && d->kh == 1;                              // no spatial sweep: windows of 16 RW channels, no halo
+    const int mode = gemm ? 3 : (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);      // 0: x sweep, 1: y sweep, 2: 2-D sweep, 3: GEMM
+    const int hx = (mode == 0 || mode == 2) ? d->kw - 1 : 0, hy = (mode == 1 || mode == 2) ? d->kh - 1 : 0;   // window halo (total) in x / y
     const int kgroups = d->M == 128 ? 2 : 1;
     const int GT = NT5 / kgroups;
+    const int RW = gemm ? (kgroups == 1 ? 4 : 2) : 1;
     int nchunk = 0;
-    for (int s = 0; s < d->nseg; ++s) nchunk += d->seg[s].c / 16;
+    for (int s = 0; s < d->nseg; ++s) {
+        if (d->seg[s].c % (16 * RW)) return false;
+        nchunk += d->seg[s].c / (16 * RW);
+    }
     double best = -1.0;
     int bestC = -1, bestN = 0, bestWr = 0;
     for (int nbt = 7; nbt <= 8; ++nbt) {
@@ -391,7 +406,8 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = 
             if ((32 * nbt) % C) continue;
             const int R = 32 * nbt / C;
             const int Wr = ((R + hy) * (C + hx) + 15) / 16 * 16;
-            if (Wr > 384) continue;
+            if (Wr * RW > 1024) continue;                                     // one window buffer <= 64 KiB (sweep modes: Wr <= 384 rows of 64 B fit anyway)
+            if (!gemm && Wr > 384) continue;
             const int64_t tiles = (int64_t)((d->W + C - 1) / C) * ((d->H + R - 1) / R) * d->T;
             // useful pixels per CU-slot-round: rounds of 256 workgroups (one per CU), each costing nbt blocks
             // (K-sliced launches of small maps fill the chip through the slices: there only the ragged tile edges count)
@@ -412,7 +428,12 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = 
     g.Wr = bestWr;
     g.hxw = hx >> 1;
     g.hyw = hy >> 1;
-    if (mode == 0) {
+    g.RW = RW;
+    g.logRW = RW == 4 ? 2 : (RW == 2 ? 1 : 0);
+    g.trow_inc = gemm ? 0 : 1;
+    if (mode == 3) {
+        g.swx_n = 1 << 30, g.row_jump = 0, g.nsweep = RW, g.rdy = 0;
+    } else if (mode == 0) {
         g.swx_n = d->kw, g.row_jump = 0, g.nsweep = d->kw, g.rdy = 1;
     } else if (mode == 1) {
         g.swx_n = 1, g.row_jump = g.WRL - 1, g.nsweep = d->kh, g.rdy = 0;
@@ -420,9 +441,9 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = 
         g.swx_n = d->kw, g.row_jump = g.WRL - d->kw, g.nsweep = d->kh * d->kw, g.rdy = 0;
     }
     g.nchunk = nchunk;
-    g.n0 = d->seg[0].c / 16;
+    g.n0 = d->seg[0].c / (16 * RW);
     g.kgroups = kgroups;
-    g.npieces = (g.Wr * 4 + GT - 1) / GT;
+    g.npieces = (g.Wr * 4 * RW + GT - 1) / GT;
     g.nslice = 1;
     g.part = nullptr;
     g.P = (int64_t)d->T * d->H * d->W;
@@ -435,11 +456,10 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = 
 // 16-channel-aligned segments, a halo'd window that fits, and at least ~a workgroup per CU
 extern "C" int ppms_conv_gemm5_applicable(const ppms_conv* d) {
     if (d == nullptr || (d->M != 256 && d->M != 128) || d->m_split % 64 != 0 || d->nseg < 1 || d->nseg > 2) return 0;
-    if (d->kw == 1 && d->kh == 1) return 0;
     for (int s = 0; s < d->nseg; ++s)
         if (d->seg[s].c <= 0 || d->seg[s].c % 16 != 0) return 0;
     Geo5 g;
-    if (!plan5(d, g)) return 0;
+    if (!plan5(d, g)) return 0;                     // (kh = kw = 1: GEMM mode, segments in multiples of 64 / 32 channels)
     return (int64_t)g.tiles_x * g.tiles_y * d->T >= 200 ? 1 : 0;   // fewer workgroups than CUs: conv_gemm2's K slicing fills the chip better
 }
 
@@ -500,7 +520,6 @@ static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, 
     PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm5: bad volume %dx%dx%d", d->T, d->H, d->W);
     PPMS_REQUIRE((d->M == 256 || d->M == 128) && d->m_split % 64 == 0, "conv_gemm5: M=%d must be 128 or 256", d->M);
     PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15 && d->kh <= 15, "conv_gemm5: odd kernel extents <= 15");
-    PPMS_REQUIRE(d->kw > 1 || d->kh > 1, "conv_gemm5: needs a spatial sweep axis (kw > 1 or kh > 1)");
     PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm5: weights/bias missing");
     PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm5: t_halo=%d", d->t_halo);
     PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 22) && d->H < 480, "conv_gemm5: volume too large for the packed window slots (< 2^22 pixels, H < 480)");
@@ -525,16 +544,16 @@ static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, 
     }
     Geo5 g;
     PPMS_REQUIRE(plan5(d, g, nbt, nslice > 1), "conv_gemm5: no tile shape fits the LDS window");
-    PPMS_REQUIRE(g.nsweep >= 3, "conv_gemm5: the sweep must have at least 3 taps");
+    PPMS_REQUIRE(g.nsweep >= 2, "conv_gemm5: a window must serve at least 2 k-steps");
     if (nslice > 1) {
         PPMS_REQUIRE(d->epi[0].out_vt == nullptr && (d->m_split >= d->M || d->epi[1].out_vt == nullptr), "conv_gemm5: sliced launch cannot write out_vt");
         PPMS_REQUIRE(nslice <= min_windows5(d, g), "conv_gemm5: %d slices for %d windows", nslice, min_windows5(d, g));
         g.nslice = nslice;
         g.part = part;
     }
-    PPMS_REQUIRE(g.npieces <= 14 && g.npieces >= 1, "conv_gemm5: window of %d rows needs too many DMA pieces", g.Wr);
+    PPMS_REQUIRE(g.npieces <= MAXS5 && g.npieces >= 1, "conv_gemm5: window of %d rows needs too many DMA pieces", g.Wr);
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
-    size_t lds = (size_t)2 * g.kgroups * g.npieces * (NT5 / g.kgroups) * 16;        // the K-groups' pairs of window buffers
+    size_t lds = (size_t)2 * g.kgroups * g.npieces * (NT5 / g.kgroups) * 16;        // the K-groups' pairs of window buffers (GEMM mode: 2 x 64 KiB)
     if (g.kgroups == 2 && lds < (size_t)4 * 128 * 64 * 4) lds = (size_t)4 * 128 * 64 * 4;   // K-group exchange: 4 x 32 KiB
     if (lds < (size_t)8 * STG_WAVE) lds = (size_t)8 * STG_WAVE;                  // the epilogue's transposition patches
     PPMS_REQUIRE(lds <= 160 * 1024, "conv_gemm5: LDS budget exceeded (%zu B)", lds);

@@ -35,6 +35,7 @@ USE_CONV5 = os.environ.get("PPMS_CONV5", "1") != "0"      # one 8-wave workgroup
 # conv_gemm5's K-sliced form on the small maps (1/8, 1/16 scales): correct (tests) but measured SLOWER than conv_gemm2's slicing there
 # (1/8-scale iteration 1293 vs 1252 us, 1/16: 1072 vs 1017 us: per-workgroup fixed costs and 5 x the partial-sum traffic), so off
 USE_CONV5_SLICED = os.environ.get("PPMS_CONV5_SLICED", "0") != "0"
+USE_CONV5_GEMM = os.environ.get("PPMS_CONV5_GEMM", "1") != "0"       # its GEMM mode for the convs without a spatial sweep ((5,1,1) GRU pass, 1x1 heads)
 USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
 USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
 _YS = os.environ.get("PPMS_YSWEEP", "1")                  # conv_gemm2 one-window forms: 0 = off, 1 = y-swept (1, kh, 1) convs (default),
@@ -183,9 +184,16 @@ class PackedBlock:
                 self.w[name + "_2d"] = pack_conv(sweep, bias, segs, seg_pad, cout_map, m_pad)
             elif w5.shape[3] > 1:
                 sweep = w5.transpose(3, 4).contiguous()                      # y sweep: kh / kw swapped
+            rows = (max(cout_map) + 1) if cout_map is not None else w5.shape[0]
             if (USE_CONV4 or USE_CONV5) and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
-                rows = (max(cout_map) + 1) if cout_map is not None else w5.shape[0]
                 self.w4[name] = _packing.pack_conv4(sweep, bias, segs, seg_pad, cout_map, (rows + 127) // 128 * 128)
+            elif USE_CONV5 and USE_CONV5_GEMM and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith(("_y", "_p")):
+                # no spatial sweep: conv_gemm5's GEMM mode (windows of 64 channels) when the segments come in such multiples.  Only the
+                # 256-cout convs (GRU pass-T z/r 197 -> 164 us, mask_2d.2 62 -> 46 us at the 1/4 scale): with 128 couts the two K-groups
+                # get 32-channel windows = 2 k-steps per window, too short a DMA lookahead (pass-T q 110 -> 122 us, to_v 44 -> 66 us)
+                pads = list(seg_pad) if seg_pad is not None else [((c + 31) // 32) * 32 for c in segs]
+                if all(p % 32 == 0 for p in pads):
+                    self.w4[name] = _packing.pack_conv4(w5, bias, segs, pads, cout_map, (rows + 127) // 128 * 128)
 
         e = "encoder."
         put("init0", g(e + "init_conv.0.weight"), g(e + "init_conv.0.bias"), [128])

@@ -270,7 +270,11 @@ def test_conv_gemm5_sliced_vs_torch(lib, name, T, H, W, segs, cout, k3, nslice):
 
 @pytest.mark.parametrize("nbt", [5007, 5008])
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV3_CASES + [("3x3_ragged_m256", 2, 13, 45, [48, 16], 190, (1, 3, 3)), ("x15_w24", 1, 9, 24, [32], 128, (1, 1, 15)),
-                                                   ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3))])
+                                                   ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3)),
+                                                   # GEMM mode (kh = kw = 1): 64- / 32-channel windows, the temporal taps as separate windows
+                                                   ("t5_gemm_m256", 5, 20, 64, [128, 256], 256, (5, 1, 1)), ("1x1_m256_pad", 2, 13, 45, [256], 144, (1, 1, 1)),
+                                                   ("t5_gemm_m128", 5, 10, 40, [128, 256], 128, (5, 1, 1)), ("1x1_m128", 1, 9, 24, [64], 128, (1, 1, 1)),
+                                                   ("t3_gemm_m128_T2", 2, 16, 32, [64, 64], 100, (3, 1, 1))])
 def test_conv_gemm5_vs_torch(lib, name, T, H, W, segs, cout, k3, nbt):
     """One 8-wave workgroup per tile of 7 / 8 blocks of 32 pixels (4 + 3 split balanced per SIMD), all couts per workgroup:
     M = 256 (4 cout blocks x 2 pixel halves) and M = 128 (K loop split over two wave groups, partial tiles summed through LDS) --
