@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     }
     // the hand-scheduled loop (attn64_asm.h, generated by tools/gen_attn_asm.py): 2 substeps = one 64-key tile.  The O += V P group
     // of a sub-tile's second key half runs one substep late, so the first substep multiplies zeros by zeros
-    u32x4 ring[4], vh1[4] = {}, pf0[2] = {}, pf1[2] = {};
+    u32x4 ring[ATT_RING], vh1[4] = {}, pf0[2] = {}, pf1[2] = {};
     f32x2 pt2[2], tt2[2];
     const f32x2 scale2 = {scale_log2, scale_log2};
     attn64_prime(sa, ring, pt2, tt2, negm2, scale2, kaddr);

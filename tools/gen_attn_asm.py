@@ -26,6 +26,10 @@ MF = "v_mfma_f32_32x32x16_bf16"
 # against 1.25 ms with scalar ops: the packed fp32 ops do not hide behind the MFMAs); needs __attribute__((target("packed-fp32-ops")))
 # on the kernel, the library being built without packed-fp32 code generation
 PK = int(os.environ.get("PPMS_ATTN_PK", "0"))
+# fragment ring: RING buffers, a fragment is requested RING - 1 uses ahead; PAIRWAIT: one counted wait per TWO fragments (RING = 6:
+# 13 instead of 25 waits per tile -- measured no faster, 1.24 vs 1.22 ms, so 4 stays)
+RING = int(os.environ.get("PPMS_ATTN_RING", "4"))
+PAIRWAIT = RING >= 6
 # 1: the softmax denominator is accumulated from the PACKED bf16 probabilities (v_dot2_f32_bf16 with (1, 1): one op per pair instead of
 # two fp32 adds) -- correct (15 tests) but measured SLOWER on gfx950 (1.32 vs 1.25 ms: like the packed fp32 ops, the dot op does not
 # hide behind the MFMAs), so it stays off
@@ -65,7 +69,7 @@ def elem(e):
 def substep(par):
     E = Emit()
     # ---- LDS queue simulation: ids in issue order; entry state = this substep's ring units 0, 1, 2 in flight -------------------
-    queue = ["u0", "u1", "u2"]
+    queue = [f"u{i}" for i in range(RING - 1)]
 
     def wait_for(tag):
         younger = len(queue) - 1 - queue.index(tag)
@@ -74,7 +78,7 @@ def substep(par):
     def ring_read(u):                 # u in 0..14: >= 12 -> next substep's unit u - 12
         nxt = u >= 12
         uu = u - 12 if nxt else u
-        buf = u % 4
+        buf = u % RING
         if uu < 8:                    # K fragment, k-step uu, for S of sub-tile k+1 (own) / k+2 (prefetch)
             imm = (0 if par == 0 else 8192) if nxt else (8192 if par == 0 else 0)
             E.asm(f"ds_read_b128 {{d}}, {{a}} offset:{imm}", [("d", "+v", f"ring[{buf}]")], [("a", "v", f"kaddr[{uu}]")])
@@ -85,28 +89,29 @@ def substep(par):
     cons = {0: 0, 2: 1, 4: 2, 6: 3, 16: 4, 18: 5, 20: 6, 22: 7, 24: 8, 26: 9, 28: 10, 30: 11}     # slot -> ring unit consumed there
     for s in range(32):
         # ---- the MFMA of this slot ------------------------------------------------------------------------------------------
-        if s in cons:
-            wait_for("u" + str(cons[s]))
+        if s in cons and not (PAIRWAIT and cons[s] % 2 == 1):
+            wait_for("u" + str(cons[s] + (1 if PAIRWAIT else 0)))
         b = s & 1
         if s < 8 or 16 <= s < 24:
             u = (s >> 1) if s < 8 else 4 + ((s - 16) >> 1)
             if u == 0:
-                E.asm(f"{MF} {{c}}, {{a}}, {{b}}, 0", [("c", "=&v", f"nxt[{b}]")], [("a", "v", f"ring[{u % 4}]"), ("b", "v", f"qf[{b}][{u}]")])
+                E.asm(f"{MF} {{c}}, {{a}}, {{b}}, 0", [("c", "=&v", f"nxt[{b}]")], [("a", "v", f"ring[{u % RING}]"), ("b", "v", f"qf[{b}][{u}]")])
             else:
-                E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+v", f"nxt[{b}]")], [("a", "v", f"ring[{u % 4}]"), ("b", "v", f"qf[{b}][{u}]")])
+                E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+v", f"nxt[{b}]")], [("a", "v", f"ring[{u % RING}]"), ("b", "v", f"qf[{b}][{u}]")])
         elif s < 16:
             dblk = (s - 8) >> 1
             E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{dblk}][{b}]")], [("a", "v", f"vh1[{dblk}]"), ("b", "v", f"pf1[{b}]")])
         else:
             u = 8 + ((s - 24) >> 1)
-            E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{u - 8}][{b}]")], [("a", "v", f"ring[{u % 4}]"), ("b", "v", f"pf0[{b}]")])
-        # ---- LDS requests behind the second MFMA of a fragment ------------------------------------------------------------------
-        if (s - 1) in cons:
-            ring_read(cons[s - 1] + 3)
+            E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{u - 8}][{b}]")], [("a", "v", f"ring[{u % RING}]"), ("b", "v", f"pf0[{b}]")])
+        # ---- LDS requests behind the second MFMA of a fragment (the dedicated V^T fragments first: they stay older than every
+        #      request made for the next substep) -------------------------------------------------------------------------------------
         if s in (17, 19, 21, 23):
             dblk = (s - 17) >> 1
             E.asm(f"ds_read_b128 {{d}}, {{a}} offset:{dblk * 4096}", [("d", "+v", f"vh1[{dblk}]")], [("a", "v", f"vaddr[{par * 2 + 1}]")])
             queue.append(f"h{dblk}")
+        if (s - 1) in cons:
+            ring_read(cons[s - 1] + RING - 1)
         # ---- VALU, in PAIRS of scores (registers 2p, 2p + 1 of a tile are two consecutive keys of one query): pair p owns slots 2p
         #      and 2p + 1.  even slot: exp of pair p + 1's first score, sum of pair p.  odd slot: arguments of pair p + 2 (first: an fma
         #      feeding an exp within two instructions costs a wait state), exp of pair p + 1's second score, bf16 pack of pair p.
@@ -149,11 +154,13 @@ def substep(par):
             E.asm("v_add_u32 {a}, {a}, {dl}", [("a", "+v", f"kaddr[{s - 18}]")], [("dl", "s", "delta")])
         if par == 1 and 26 <= s < 30:
             E.asm("v_add_u32 {a}, {a}, {dl}", [("a", "+v", f"vaddr[{s - 26}]")], [("dl", "s", "delta")])
-    assert queue[-3:] == ["n0", "n1", "n2"], queue
+    if par == 1:      # the tile's KV stage returns to the DMA ring at the barrier behind this substep: its last LDS reads (h3) must have landed
+        wait_for("h3")
+    assert queue[-(RING - 1):] == [f"n{i}" for i in range(RING - 1)], queue
     return "\n".join(E.lines)
 
 
-SIG = ("f32x16 (&cur)[2], f32x16 (&nxt)[2], const bf16x8 (&qf)[2][8], f32x16 (&o)[4][2], u32x4 (&ring)[4], u32x4 (&vh1)[4],\n"
+SIG = ("f32x16 (&cur)[2], f32x16 (&nxt)[2], const bf16x8 (&qf)[2][8], f32x16 (&o)[4][2], u32x4 (&ring)[ATT_RING], u32x4 (&vh1)[4],\n"
        "        u32x4 (&pf0)[2], u32x4 (&pf1)[2], f32x2 (&pt2)[2], f32x2 (&tt2)[2], f32x2 (&lsum2)[2], const f32x2 (&negm2)[2], f32x2 scale2,\n"
        "        unsigned (&kaddr)[8], unsigned (&vaddr)[4], int delta")
 
@@ -161,19 +168,20 @@ SIG = ("f32x16 (&cur)[2], f32x16 (&nxt)[2], const bf16x8 (&qf)[2][8], f32x16 (&o
 def gen():
     out = ['''// GENERATED by tools/gen_attn_asm.py -- do not edit.  (Schedule and register roles: see the generator's docstring.)
 #pragma once
-''']
+constexpr int ATT_RING = %d;        // K / V^T fragment buffers in registers
+''' % RING]
     out.append(f"template <int PAR>\n__device__ __forceinline__ void attn64_substep({SIG}) {{")
     out.append("    if constexpr (PAR == 0) {\n" + substep(0) + "\n    } else {\n" + substep(1) + "\n    }\n}\n")
     # prime: ring units 0..2 of substep 0 (S of sub-tile 1: tile 0, keys 32..63), arguments of pairs 0 and 1, exps of pair 0
     E = Emit()
-    for u in range(3):
+    for u in range(RING - 1):
         E.asm("ds_read_b128 {d}, {a} offset:8192", [("d", "+v", f"ring[{u}]")], [("a", "v", f"kaddr[{u}]")])
     for pr in range(2):
         for j in range(2):
             E.asm("v_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt2[{pr}][{j}]")], [("x", "v", f"cur[0][{2 * pr + j}]"), ("sc", "v", "scale2[0]"), ("m", "v", "negm2[0][0]")])
     for j in range(2):
         E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[0][{j}]")], [("t", "v", f"tt2[0][{j}]")])
-    out.append("__device__ __forceinline__ void attn64_prime(f32x16 (&cur)[2], u32x4 (&ring)[4], f32x2 (&pt2)[2], f32x2 (&tt2)[2], const f32x2 (&negm2)[2], f32x2 scale2,\n"
+    out.append("__device__ __forceinline__ void attn64_prime(f32x16 (&cur)[2], u32x4 (&ring)[ATT_RING], f32x2 (&pt2)[2], f32x2 (&tt2)[2], const f32x2 (&negm2)[2], f32x2 scale2,\n"
                "                                             unsigned (&kaddr)[8]) {\n" + "\n".join(E.lines) + "\n}\n")
     # tail: drains the LDS queue.  (The O += V P group of the last sub-tile's keys 16..31 that follows is written with MFMA builtins
     # in mem_attn.hip: outside the loop the register allocator moves accumulator tuples around with v_accvgpr_* copies, and it pads
