@@ -19,6 +19,11 @@ side = torch.cuda.Stream()
 A = torch.randn(8192, 8192, device=dev); B = torch.randn(8192, 8192, device=dev)
 def heavy_conv(): eng.op["m1"]()
 def heavy_mm(): torch.mm(A, B)
+Ab, Bb = A.bfloat16(), B.bfloat16()
+def heavy_mm_bf16(): torch.mm(Ab, Bb)
+def heavy_attn():
+    eng_a = m.update_block04.engine(T, h, w, dev)
+    eng_a.attend()
 def run(heavy, main_fn, n=30):
     ref = main_fn().clone(); torch.cuda.synchronize()
     bad, worst = 0, None
@@ -49,4 +54,4 @@ tests = {"bilinear(ones,x4)": lambda: E.bilinear(ones, (4 * h, 4 * w), False), "
          "bilinear(rnd,x4,align)": lambda: E.bilinear(rnd, (4 * h, 4 * w), True), "convex_upsample": cvx, "nhwc_to_nchw": cvt,
          "torch.interpolate": lambda: F.interpolate(rnd, size=(4 * h, 4 * w), mode="bilinear", align_corners=False)}
 for name, fn in tests.items():
-    print(f"{name:24s} alone {run(None, fn)[0]:2d}   with conv3 {run(heavy_conv, fn)}   with torch.mm {run(heavy_mm, fn)}")
+    print(f"{name:24s} alone {run(None, fn)[0]:2d}   with conv {run(heavy_conv, fn)}   with torch.mm fp32 {run(heavy_mm, fn)[0]}   with torch.mm bf16 {run(heavy_mm_bf16, fn)[0]}")
