@@ -27,9 +27,11 @@ STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
 SOURCES = ["corr.hip", "conv_gemm2.hip", "conv_gemm3.hip", "conv_gemm4.hip", "conv_gemm5.hip", "small_ops.hip", "encoder_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
 HEADERS = ["common.h", "conv_epilogue.h", "conv5_asm.h", "attn64_asm.h", os.path.join("..", "..", "include", "ppms.h")]
-# Packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32) are disabled (NO_PK): a wave of the bilinear resize kernel returned
-# wrong values in lanes 48-63 when an MFMA-heavy kernel of another stream shared its SIMD (DESIGN.md section 5,
-# tools/race_probe.py, tests/test_gpu_concurrency.py).  Sources listed in PACKED_FP32_SOURCES keep the packed forms.
+# Packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) are disabled (NO_PK).  Measured on MI355X: such an instruction
+# with op_sel:[0,1] (low result = src0.lo op src1.hi -- the compiler picks that form freely, e.g. in the bilinear resize kernel) reads
+# src1.hi as 0 in lanes 48-63 whenever ANOTHER wave on the same SIMD is issuing MFMAs, and the engine runs MFMA kernels beside small
+# kernels on two streams.  Register-only reproducer: tools/pk_opsel_probe.py; evidence: profiles/r02_pk_opsel_probe.txt; static guard:
+# tools/check_no_packed_fp32.py (tests/test_host_logic.py); DESIGN.md section 5.  Sources listed in PACKED_FP32_SOURCES keep the packed forms.
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA = [x for x in os.environ.get("PPMS_BUILD_DEFINES", "").split() if x]        # build-time A/B only, e.g. "-DPPMS_CONV4_PRIO=2"
