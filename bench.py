@@ -195,6 +195,17 @@ def main():
                                   launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / args.steps, 3),
                                   flop_per_launch=c_flop / c_n, per_op=per_op))
         roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first
+    # the same clip with test_mode=False (the reference's training-style return): every iteration runs the mask head, the convex
+    # upsampling and the full-resolution resize of its prediction.  Reported beside the headline number, never as `value`.
+    n_all = 3
+    torch.cuda.synchronize()
+    D.barrier()
+    t_all = time.perf_counter()
+    for _ in range(n_all):
+        model.cascade(feats, iters, T, shard=shard, test_mode=False)
+    torch.cuda.synchronize()
+    D.barrier()
+    all_ms = D.max_over_ranks(time.perf_counter() - t_all) / n_all * 1e3
     encoders = None
     if args.with_encoders and rank == 0 and not sharded:
         # SURVEY 8 rows f3-f5 on the same clip geometry: fnet on the 2T images, cnet on the T left images, SST on the 1/16 features
@@ -233,7 +244,11 @@ def main():
                    data="synthetic", frames_per_s=round((1 if sharded else world) * args.steps * T / elapsed, 2),
                    config=dict(workload=f"{label}: T={T} clip at {H}x{W}, iters={iters}, hot path only (3-scale cascade from encoder outputs: "
                                         "corr pyramid build + lookup, QAM pick, pick-and-play memory attention, ConvGRU3D update, heads, convex upsample, "
-                                        "test_mode: only the last prediction is resized)", T=T, H=H, W=W, iters=iters, parallelism=par),
+                                        "test_mode=True as PPMStereo.forward_batch_test calls it: predictions[-1] is the output, so the mask head, the "
+                                        "convex upsampling and the full-resolution resize run only where their result is consumed -- the last iteration "
+                                        "of each scale; ms_per_step_all_predictions times the same clip with every iteration's prediction produced)",
+                                T=T, H=H, W=W, iters=iters, parallelism=par),
+                   ms_per_step_all_predictions=round(all_ms, 3),
                    roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None, cpu_baseline=cpu,
                    library=os.path.relpath(L.lib_path(), ROOT), **({"encoders": encoders} if encoders else {}))
         print(json.dumps(out))

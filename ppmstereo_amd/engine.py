@@ -742,7 +742,9 @@ class ScaleEngine:
         o["sa_mlp2"]()
         L.check(lib.ppms_layernorm(self.M3.data_ptr(), 384, ln["n2"][0].data_ptr(), ln["n2"][1].data_ptr(), self.XT.view(), self.XA.view(), self.P, 384, s))
 
-    def update(self):
+    def update(self, need_mask: bool = True):
+        """need_mask False: the mask head is skipped -- its only consumer is the convex upsampling of THIS iteration's flow
+        (ppmstereo.py:573-576), which test_mode callers need from the last iteration of a scale only."""
         o = self.op
         if self.pk.attn is not None:
             self.block16_attention()
@@ -763,16 +765,18 @@ class ScaleEngine:
         self._halo_sp(self.RH, 2)
         o["q3"]()
         self._halo_sp(self.Hb[0], 1)                # FlowHead3D / mask_3d: 3x3x3 convs of the new hidden state
-        with self._fork():                        # mask head || flow head
-            o["m1"]()
-            o["m2"]()
+        if need_mask:
+            with self._fork():                    # mask head || flow head
+                o["m1"]()
+                o["m2"]()
         o["fh1"]()
         o["fh2"]()
         self._halo_f32(self._FH2Y_full, 1)          # the second 3x3x3 conv gathers the 54 pre-gather channels over +-1 frame
         L.check(self.lib.ppms_tap_gather_sum(self.FH2Y.data_ptr(), 64, self.pk.fh2_bias.data_ptr(), self.DFLOW.data_ptr(), 4, 2, 3, 3, 3,
                                              self.T, self.h, self.w, self.halo, self._s()))
         L.check(self.lib.ppms_flow_add(self.FLOW.data_ptr(), self.DFLOW.data_ptr(), 4, self.P, self._s()))   # ppmstereo.py:571
-        self._join()
+        if need_mask:
+            self._join()
 
     def upsample(self) -> torch.Tensor:
         if self.pk.convex_3d:                       # ppmstereo.py:573-576
@@ -784,14 +788,17 @@ class ScaleEngine:
                                                   self.h, self.w, self._s()))
         return self.FLOW_OUT
 
-    def iterate(self):
+    def iterate(self, need_up: bool = True):
+        """One refinement iteration (ppmstereo.py:482-576).  need_up False: the iteration's upsampled prediction is not wanted (test_mode
+        returns the last one only, :801-804), so the mask head and the convex upsampling -- which feed nothing else -- are not run and
+        None is returned; the recurrent state (flow, hidden states, memory) is identical either way."""
         self.lookup()
         self.motion_and_value()
         self.uncertainty()
         self.pick()
         self.attend()
-        self.update()
-        return self.upsample()
+        self.update(need_mask=need_up)
+        return self.upsample() if need_up else None
 
 
 def bilinear(x: torch.Tensor, size, align_corners: bool, mul: float = 1.0) -> torch.Tensor:

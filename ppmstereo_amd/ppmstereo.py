@@ -49,7 +49,9 @@ def _run_iterations(eng, iters: int, isc: int, t: int, h: int, w: int, predictio
     PPMStereo.forward(test_mode=True) returns predictions[-1] alone (:801-804), so every other resize is dead work there."""
     flow_out = None
     for it in range(iters):
-        flow_out = eng.iterate()
+        # the upsampled flow of an iteration is consumed by its prediction (when emitted) and, after the last iteration, by the next
+        # scale's initialisation (:724-725): anywhere else the mask head + convex upsampling are dead work and are not launched
+        flow_out = eng.iterate(need_up=(emit == "all" or it + 1 == iters))
         if emit == "none" or (emit == "last" and it + 1 < iters):
             continue
         unc_up = bilinear(eng.UNC_local().view(t, 1, h, w), (4 * isc * h, 4 * isc * w), False)

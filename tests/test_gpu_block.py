@@ -324,6 +324,18 @@ def test_cascade_is_bit_stable_over_many_runs(model):
     assert bad == 0, f"{bad} of 25 runs differ"
 
 
+def test_test_mode_drops_only_dead_work(model):
+    """test_mode=True launches the mask head, the convex upsampling and the full-resolution resize only where their result is consumed
+    (the last iteration of each scale); what it returns must be bit-identical to predictions[-1] / uncertainties[-1] of the same clip
+    with every iteration's prediction produced (ppmstereo.py:801-804), at BASELINE config 2's size."""
+    T, H, Wd = 5, 320, 512
+    feats = {k: v.to(DEV) for k, v in synth_cascade_feats(T, H, Wd).items()}
+    preds, uncs = [], []
+    model.cascade(feats, 10, T, preds, uncs, test_mode=False)
+    d, c = model.cascade(feats, 10, T, test_mode=True)
+    assert len(preds) == 20 and torch.equal(d, preds[-1]) and torch.equal(c, uncs[-1])
+
+
 def test_attention_is_a_convex_combination(model):
     """Softmax-weighted aggregation property at full 1/4-scale size (n = 10240, 5 frames): with V == const vector c per
     channel the output must equal bf16(c) whatever Q, K are."""
