@@ -169,9 +169,10 @@ int ppms_f32_to_sp(const float* src, int src_ld, ppms_sp dst, int64_t pixels, vo
 int ppms_sp_to_f32(ppms_sp src, float* dst, int dst_ld, int64_t pixels, void* stream);
 
 /* Tail of a few-output-channel conv evaluated as a 1x1 GEMM to (taps*cout) channels followed by a shifted sum:
- * out[p][c] = bias[c] + sum_tap y[p + d(tap)][tap*cout + c] (zero padded).  FlowHead3D.conv2, ppmtereo_update.py:674. */
-int ppms_tap_gather_sum(const float* y, int y_ld, const float* bias, float* out, int out_ld, int cout, int kt, int kh, int kw,
-                        int T, int H, int W, int t_halo, void* stream);    /* t_halo: frames of y readable beyond [0, T) (see ppms_conv) */
+ * out[p][c] = bias[c] + sum_tap y[p + d(tap)][tap*cout + c] (zero padded).  FlowHead3D.conv2, ppmtereo_update.py:674.
+ * accum (may be NULL; fp32 [pixel][accum_ld]): accum[p][c] += out[p][c] in the same launch -- flow = flow + delta_flow, ppmstereo.py:571. */
+int ppms_tap_gather_sum(const float* y, int y_ld, const float* bias, float* out, int out_ld, float* accum, int accum_ld, int cout, int kt, int kh,
+                        int kw, int T, int H, int W, int t_halo, void* stream);   /* t_halo: frames of y readable beyond [0, T) (see ppms_conv) */
 /* flow = flow + delta_flow (ppmstereo.py:571); flow: fp32 [pixel][2], dflow: fp32 [pixel][dflow_ld] */
 int ppms_flow_add(float* flow_nhwc, const float* dflow, int dflow_ld, int64_t pixels, void* stream);
 /* PPMStereo.convex_upsample, ppmstereo.py:185-197.  flow: fp32 [pixel][2]; mask: fp32 [pixel][mask_ld] (144 used);

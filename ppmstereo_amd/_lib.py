@@ -75,7 +75,7 @@ _SIGS = {
     "ppms_nhwc_to_nchw": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ppms_f32_to_sp": (c_int, [c_void_p, c_int, SP, c_int64, c_void_p]),
     "ppms_sp_to_f32": (c_int, [SP, c_void_p, c_int, c_int64, c_void_p]),
-    "ppms_tap_gather_sum": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ppms_tap_gather_sum": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_flow_add": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "ppms_convex_upsample": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ppms_convex_upsample_3d": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

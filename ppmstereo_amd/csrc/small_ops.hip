@@ -338,8 +338,8 @@ extern "C" int ppms_sp_to_f32(ppms_sp src, float* dst, int dst_ld, int64_t pixel
 //   out[p][c] = bias[c] + sum_tap y[p + d(tap)][tap*cout + c],  d(tap) = (kz - kt/2, ky - kh/2, kx - kw/2), zero outside.
 // Used for FlowHead3D.conv2 (256 -> 2, 3x3x3, ppmtereo_update.py:674): 8 GEMM k-steps instead of 216.
 __global__ __launch_bounds__(256) void tap_gather_sum_kernel(const float* __restrict__ y, int y_ld, const float* __restrict__ bias,
-                                                             float* __restrict__ out, int out_ld, int cout, int kt, int kh, int kw, int T,
-                                                             int H, int W, int t_halo, int64_t total) {
+                                                             float* __restrict__ out, int out_ld, float* __restrict__ accum, int accum_ld, int cout,
+                                                             int kt, int kh, int kw, int T, int H, int W, int t_halo, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % cout);
@@ -355,13 +355,16 @@ __global__ __launch_bounds__(256) void tap_gather_sum_kernel(const float* __rest
                     acc += y[(((int64_t)tt * H + y2) * W + x2) * y_ld + tap * cout + c];
             }
     out[pix * out_ld + c] = acc;
+    if (accum != nullptr) accum[pix * accum_ld + c] += acc;          // flow += delta_flow (ppmstereo.py:571) without a second launch
 }
-extern "C" int ppms_tap_gather_sum(const float* y, int y_ld, const float* bias, float* out, int out_ld, int cout, int kt, int kh, int kw,
-                                   int T, int H, int W, int t_halo, void* stream) {
+// accum (optional, [pixels][accum_ld], accum_ld >= cout): accum[p][c] += out[p][c] in the same launch
+extern "C" int ppms_tap_gather_sum(const float* y, int y_ld, const float* bias, float* out, int out_ld, float* accum, int accum_ld, int cout, int kt,
+                                   int kh, int kw, int T, int H, int W, int t_halo, void* stream) {
     PPMS_REQUIRE(y && out && cout > 0 && kt * kh * kw * cout <= y_ld && out_ld >= cout && t_halo >= 0, "tap_gather_sum: bad arguments");
+    PPMS_REQUIRE(accum == nullptr || accum_ld >= cout, "tap_gather_sum: accum_ld=%d < cout=%d", accum_ld, cout);
     const int64_t total = (int64_t)T * H * W * cout;
-    hipLaunchKernelGGL(tap_gather_sum_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, y, y_ld, bias, out, out_ld, cout,
-                       kt, kh, kw, T, H, W, t_halo, total);
+    hipLaunchKernelGGL(tap_gather_sum_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, y, y_ld, bias, out, out_ld, accum, accum_ld,
+                       cout, kt, kh, kw, T, H, W, t_halo, total);
     return ppms_check_launch("tap_gather_sum");
 }
 

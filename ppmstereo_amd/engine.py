@@ -772,9 +772,9 @@ class ScaleEngine:
         o["fh1"]()
         o["fh2"]()
         self._halo_f32(self._FH2Y_full, 1)          # the second 3x3x3 conv gathers the 54 pre-gather channels over +-1 frame
-        L.check(self.lib.ppms_tap_gather_sum(self.FH2Y.data_ptr(), 64, self.pk.fh2_bias.data_ptr(), self.DFLOW.data_ptr(), 4, 2, 3, 3, 3,
-                                             self.T, self.h, self.w, self.halo, self._s()))
-        L.check(self.lib.ppms_flow_add(self.FLOW.data_ptr(), self.DFLOW.data_ptr(), 4, self.P, self._s()))   # ppmstereo.py:571
+        # delta_flow = the gathered taps, and flow = flow + delta_flow (ppmstereo.py:571) in the same launch
+        L.check(self.lib.ppms_tap_gather_sum(self.FH2Y.data_ptr(), 64, self.pk.fh2_bias.data_ptr(), self.DFLOW.data_ptr(), 4, self.FLOW.data_ptr(), 2,
+                                             2, 3, 3, 3, self.T, self.h, self.w, self.halo, self._s()))
         if need_mask:
             self._join()
 

@@ -622,10 +622,17 @@ def test_tap_gather_sum(lib, T, H, W):
     yd[:, :54] = y.to(DEV)
     out = torch.zeros(P, 4, device=DEV)
     bd = bs.to(DEV)
-    L.check(L.load().ppms_tap_gather_sum(yd.data_ptr(), 64, bd.data_ptr(), out.data_ptr(), 4, 2, 3, 3, 3, T, H, W, 0, L.stream_ptr()))
+    flow = hash_normal((P, 2), 513).to(DEV)
+    flow0 = flow.clone()
+    L.check(L.load().ppms_tap_gather_sum(yd.data_ptr(), 64, bd.data_ptr(), out.data_ptr(), 4, flow.data_ptr(), 2, 2, 3, 3, 3, T, H, W, 0, L.stream_ptr()))
     torch.cuda.synchronize()
     ref = _ref_conv([x], wt, bs, (3, 3, 3), T, H, W)
     assert maxdiff(out[:, :2], ref) < 3e-5
+    assert torch.equal(flow, flow0 + out[:, :2])                                    # the fused flow += delta_flow (ppmstereo.py:571)
+    out2 = torch.zeros(P, 4, device=DEV)
+    L.check(L.load().ppms_tap_gather_sum(yd.data_ptr(), 64, bd.data_ptr(), out2.data_ptr(), 4, None, 0, 2, 3, 3, 3, T, H, W, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(out2, out)
 
 
 def test_pwchain_vs_unfused_layers(lib):
