@@ -1,12 +1,16 @@
 """Summarise a rocprofv3 kernel trace of bench.py: per-scale wall/busy time and the per-launch durations of the last
-1/4-scale iteration.  usage: tools/trace_iter.py <kernel_trace.csv>"""
+1/4-scale iteration (of the last test_mode=True cascade).  usage: tools/trace_iter.py <kernel_trace.csv> [4|8|16]"""
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 cb = [i for i, r in enumerate(rows) if "corr_build" in r["Kernel_Name"]]
-s16, s8, s4 = cb[-3], cb[-2], cb[-1]
+# bench.py ends with 3 test_mode=False cascades (ms_per_step_all_predictions): analyse the last test_mode=True one, the 4th from the end
+ncas = len(cb) // 3
+pick = ncas - 4 if ncas >= 5 else ncas - 1
+s16, s8, s4 = cb[3 * pick], cb[3 * pick + 1], cb[3 * pick + 2]
+end4 = cb[3 * pick + 3] if pick + 1 < ncas else len(rows)
 
 
 def seg(a, b, label):
@@ -26,7 +30,7 @@ def seg(a, b, label):
     return rs
 
 
-r16, r8, r4 = seg(s16, s8, "scale16"), seg(s8, s4, "scale8"), seg(s4, len(rows), "scale4")
+r16, r8, r4 = seg(s16, s8, "scale16"), seg(s8, s4, "scale8"), seg(s4, end4, "scale4")
 which = {"16": r16, "8": r8, "4": r4}[sys.argv[2] if len(sys.argv) > 2 else "4"]
 look = [i for i, r in enumerate(which) if "corr_lookup" in r["Kernel_Name"]]
 it = which[look[-2]:look[-1]]
