@@ -229,6 +229,23 @@ def main():
 
         encoders = dict(fnet_ms=timed(lambda: fnet([i1, i2])), cnet_ms=timed(lambda: cnet(i1)), sst_ms=timed(lambda: sst(f16a, f16b, T)),
                         note="once per clip, in front of the timed path; not part of `value`")
+        # the whole reference call with HOST buffers on both sides (SURVEY 8d's wall time): PPMStereo.forward_batch_test on a CPU video
+        # tensor -> pad, host->device copy, fnet + cnet + SST, the cascade, unpad, device->host copy.  PCIe inclusive; never `value`.
+        from ppmstereo_amd.ppmstereo import PPMStereo
+        del fnet, cnet, sst
+        whole = PPMStereo()
+        whole.load_hot_path_weights(Wm.hot_path_weights())
+        whole.fnet.load_state_dict(Wm.fnet_weights(), strict=True), whole.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
+        sd = whole.state_dict()
+        sd.update(Wm.sst_weights())
+        whole.load_state_dict(sd, strict=True)
+        whole = whole.to(dev).eval()
+        video = Wm.hash_uniform((T, 2, 3, H, W), 613, 0.0, 255.0).round().contiguous()           # host tensor, as the reference's loader hands it over
+        call_ms = timed(lambda: whole.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=iters), reps=5)
+        encoders["whole_call_ms"] = call_ms
+        encoders["whole_call_px_per_s"] = round(T * H * W / (call_ms * 1e-3), 1)
+        encoders["whole_call_note"] = ("PPMStereo.forward_batch_test(host video) -> host disparity: H2D + encoders + SST + cascade + D2H, "
+                                       "one window; PCIe inclusive, not `value`")
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
