@@ -20,6 +20,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define PPMS_GLOBAL __attribute__((address_space(1)))
 __device__ __forceinline__ u32x4 gload16(const void* p) { return *(const PPMS_GLOBAL u32x4*)(uintptr_t)p; }
 __device__ __forceinline__ void gstore16(void* p, u32x4 v) { *(PPMS_GLOBAL u32x4*)(uintptr_t)p = v; }
+// typed forms.  A FLAT access also counts in lgkmcnt, so the next LDS wait (the epilogues' staging reads) would have to sit out the
+// whole memory round trip of every earlier store: the conv epilogues ran at one HBM latency per 8-row step until these were used.
+template <class T> __device__ __forceinline__ T gld(const void* p) { return *(const PPMS_GLOBAL T*)(uintptr_t)p; }
+template <class T> __device__ __forceinline__ void gst(void* p, const T& v) { *(PPMS_GLOBAL T*)(uintptr_t)p = v; }
 
 // ---- error plumbing (no C++ exceptions cross the ABI) ----------------------------------------
 void ppms_set_error(const char* fmt, ...);
@@ -93,6 +97,38 @@ __device__ __forceinline__ float apply_act(float x, int act) {
         case PPMS_ACT_TANH: return tanh_fast(x);
         case PPMS_ACT_ELU1: return x > 0.0f ? x + 1.0f : expf(x);      // elu(x) + 1 (attention.py:14-15)
         default: return x;
+    }
+}
+
+// The same on N values with ONE dispatch: called per element, the switch above becomes a chain of scalar branches around every value
+// (8 chains per 8-cout row: most of the 0.8 us an epilogue row step took before this form existed).
+template <int N>
+__device__ __forceinline__ void apply_act_n(float (&y)[N], int act, float scale) {
+    switch (act) {
+        case PPMS_ACT_RELU:
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = (y[j] < 0.0f ? 0.0f : y[j]) * scale;
+            break;
+        case PPMS_ACT_GELU:
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = gelu_erf(y[j]) * scale;
+            break;
+        case PPMS_ACT_SIGMOID:
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = sigmoid_fast(y[j]) * scale;
+            break;
+        case PPMS_ACT_TANH:
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = tanh_fast(y[j]) * scale;
+            break;
+        case PPMS_ACT_ELU1:
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = (y[j] > 0.0f ? y[j] + 1.0f : expf(y[j])) * scale;
+            break;
+        default:
+#pragma unroll
+            for (int j = 0; j < N; ++j) y[j] = y[j] * scale;
+            break;
     }
 }
 

@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+// LD = false: the descriptor is known to be a plain STORE without pre_f32 -- the instantiation contains no load at all (see epilogue_row8)
+template <bool LD = true>
 __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const float* vin, int64_t pix, int cl, int hw, bool with_vt = true) {
     // v[0..3]: acc + bias for couts cl..cl+3 (local to this half) at pixel pix.  Everything is predicated (no early
     // exits, no runtime trip counts) so that the caller's loops unroll fully and the accumulators stay in registers.
@@ -10,28 +12,29 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
     float y[4];
     float ax[4] = {0.0f, 0.0f, 0.0f, 0.0f};
     float v[4] = {vin[0], vin[1], vin[2], vin[3]};
-    if (e.pre_f32 != nullptr && nv > 0) {     // iteration-invariant part of the pre-activation (n_valid is a multiple of 4 here)
-        const f32x4 p4 = *(const f32x4*)(e.pre_f32 + pix * e.pre_f32_ld + cl);
+    if (LD && e.pre_f32 != nullptr && nv > 0) {     // iteration-invariant part of the pre-activation (n_valid is a multiple of 4 here)
+        const f32x4 p4 = gld<f32x4>(e.pre_f32 + pix * e.pre_f32_ld + cl);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] += p4[j];
     }
-    const int kind = e.kind;
+    const int kind = LD ? e.kind : PPMS_EPI_STORE;
     if (nv > 0 && (kind == PPMS_EPI_RESID || kind == PPMS_EPI_RH || kind == PPMS_EPI_GRU)) {
         const bf16_t* ah = (const bf16_t*)e.aux_sp.hi + pix * e.aux_sp.ld + cl;
         const bf16_t* al = (const bf16_t*)e.aux_sp.lo + pix * e.aux_sp.ld + cl;
         if (all4) {
-            const bf16x4 h4 = *(const bf16x4*)ah, l4 = *(const bf16x4*)al;
+            const bf16x4 h4 = gld<bf16x4>(ah), l4 = gld<bf16x4>(al);
 #pragma unroll
             for (int j = 0; j < 4; ++j) ax[j] = join_bf16(h4[j], l4[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < nv) ax[j] = join_bf16(ah[j], al[j]);
+                if (j < nv) ax[j] = join_bf16(gld<bf16_t>(ah + j), gld<bf16_t>(al + j));
         }
     }
     if (kind == PPMS_EPI_RESID) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = apply_act(ax[j] + v[j], e.act) * e.scale;
+        for (int j = 0; j < 4; ++j) y[j] = ax[j] + v[j];
+        apply_act_n<4>(y, e.act, e.scale);
     } else if (kind == PPMS_EPI_RH) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) y[j] = sigmoid_fast(v[j]) * ax[j];
@@ -39,7 +42,7 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
         const float* zp = e.aux_f32 + pix * e.aux_f32_ld + cl;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float z = (j < nv) ? zp[j] : 0.0f;
+            const float z = (j < nv) ? gld<float>(zp + j) : 0.0f;
             y[j] = (1.0f - z) * ax[j] + z * tanh_fast(v[j]);
         }
     } else if (kind == PPMS_EPI_ADDF32) {
@@ -47,11 +50,12 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             y[j] = 0.0f;
-            if (j < nv) op[j] += v[j];
+            if (j < nv) gst<float>(op + j, gld<float>(op + j) + v[j]);
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) y[j] = apply_act(v[j], e.act) * e.scale;
+        for (int j = 0; j < 4; ++j) y[j] = v[j];
+        apply_act_n<4>(y, e.act, e.scale);
     }
     if (kind != PPMS_EPI_ADDF32 && nv > 0) {
         if (e.out_sp.hi != nullptr) {
@@ -66,14 +70,14 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
                 l4[j] = ll;
             }
             if (all4) {
-                *(bf16x4*)oh = h4;
-                *(bf16x4*)ol = l4;
+                gst<bf16x4>(oh, h4);
+                gst<bf16x4>(ol, l4);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (j < nv) {
-                        oh[j] = h4[j];
-                        ol[j] = l4[j];
+                        gst<bf16_t>(oh + j, h4[j]);
+                        gst<bf16_t>(ol + j, l4[j]);
                     }
             }
         }
@@ -81,11 +85,11 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
             float* op = e.out_f32 + pix * e.out_f32_ld + cl;
             if (all4) {
                 f32x4 o = {y[0], y[1], y[2], y[3]};
-                *(f32x4*)op = o;
+                gst<f32x4>(op, o);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (j < nv) op[j] = y[j];
+                    if (j < nv) gst<float>(op + j, y[j]);
             }
         }
         if (with_vt && e.out_vt != nullptr) {
@@ -94,7 +98,7 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
             bf16_t* vp = (bf16_t*)e.out_vt + (frame * e.n_valid + cl) * hw + rem;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < nv) vp[(int64_t)j * hw] = (bf16_t)y[j];
+                if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, (bf16_t)y[j]);
         }
     }
 }
@@ -119,11 +123,42 @@ __device__ __forceinline__ void epilogue_vt4(const ppms_epilogue& e, const float
     bf16_t* vp = (bf16_t*)e.out_vt + (frame * e.n_valid + cl) * hw + rem;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (j < nv) vp[(int64_t)j * hw] = (bf16_t)(apply_act(v[j], e.act) * e.scale);
+        if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, (bf16_t)(apply_act(v[j], e.act) * e.scale));
 }
 
-// v[0..7]: acc + bias for couts cl..cl+7 (local to this half, cl % 8 == 0) at pixel pix
-__device__ __forceinline__ void epilogue_row8(const ppms_epilogue& e, const float* vin, int64_t pix, int cl, int hw) {
+// v[0..7]: acc + bias for couts cl..cl+7 (local to this half, cl % 8 == 0) at pixel pix.
+// LD = false: for descriptors that are a plain STORE without pre_f32 (epilogue_is_plain): no aux / pre / gate operand exists, and the
+// instantiation contains NO LOAD.  That matters more than the instruction count: vmcnt counts loads and stores in one order, so inside a
+// row loop whose body can load anything the compiler has to drain vmcnt to 0 somewhere in every step -- which also waits for the previous
+// step's stores, one HBM write round trip (~1 us) per 8-row step (measured: 17-19 us of epilogue per 1/4-scale conv launch).
+__device__ __forceinline__ bool epilogue_is_plain(const ppms_epilogue& e) { return e.kind == PPMS_EPI_STORE && e.pre_f32 == nullptr && e.out_vt == nullptr; }
+// The operands a row's epilogue reads besides the accumulators (pre_f32 share, aux_sp state, GRU gate), fetched by row8_fetch and
+// consumed by row8_finish: callers that walk rows in a loop fetch row i + 1 BEFORE finishing (= storing) row i, so that the wait for
+// a row's operands is a wait for loads that are OLDER than the previous row's stores (vmcnt is one in-order counter for both).
+struct row8_aux {
+    f32x4 p0, p1, z0, z1;
+    bf16x8 h8, l8;
+};
+__device__ __forceinline__ void row8_fetch(const ppms_epilogue& e, int64_t pix, int cl, row8_aux& a) {
+    if (e.n_valid - cl < 8) return;                // (ragged tail rows load inside row8_finish)
+    if (e.pre_f32 != nullptr) {
+        const float* pp = e.pre_f32 + pix * e.pre_f32_ld + cl;
+        a.p0 = gld<f32x4>(pp), a.p1 = gld<f32x4>(pp + 4);
+    }
+    const int kind = e.kind;
+    if (kind == PPMS_EPI_RESID || kind == PPMS_EPI_RH || kind == PPMS_EPI_GRU) {
+        a.h8 = gld<bf16x8>((const bf16_t*)e.aux_sp.hi + pix * e.aux_sp.ld + cl);
+        a.l8 = gld<bf16x8>((const bf16_t*)e.aux_sp.lo + pix * e.aux_sp.ld + cl);
+    }
+    if (kind == PPMS_EPI_GRU) {
+        const float* zp = e.aux_f32 + pix * e.aux_f32_ld + cl;
+        a.z0 = gld<f32x4>(zp), a.z1 = gld<f32x4>(zp + 4);
+    }
+}
+
+// LD = false: a must not be read (plain STORE descriptors, see epilogue_is_plain)
+template <bool LD = true>
+__device__ __forceinline__ void row8_finish(const ppms_epilogue& e, const float* vin, int64_t pix, int cl, int hw, const row8_aux& a) {
     const int nv = e.n_valid - cl;
     if (nv <= 0) return;
     if (nv < 8) {                                  // ragged tail of the valid couts: the 4-wide predicated form, twice
@@ -132,7 +167,7 @@ __device__ __forceinline__ void epilogue_row8(const ppms_epilogue& e, const floa
             float v4[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) v4[j] = s ? vin[4 + j] : vin[j];
-            epilogue_group(e, v4, pix, cl + 4 * s, hw, false);
+            epilogue_group<LD>(e, v4, pix, cl + 4 * s, hw, false);
         }
         return;
     }
@@ -142,50 +177,46 @@ __device__ __forceinline__ void epilogue_row8(const ppms_epilogue& e, const floa
         v[j] = vin[j];
         ax[j] = 0.0f;
     }
-    if (e.pre_f32 != nullptr) {
-        const float* pp = e.pre_f32 + pix * e.pre_f32_ld + cl;
-        const f32x4 p0 = *(const f32x4*)pp, p1 = *(const f32x4*)(pp + 4);
+    if (LD && e.pre_f32 != nullptr) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[j] += p0[j];
-            v[4 + j] += p1[j];
+            v[j] += a.p0[j];
+            v[4 + j] += a.p1[j];
         }
     }
-    const int kind = e.kind;
+    const int kind = LD ? e.kind : PPMS_EPI_STORE;
     if (kind == PPMS_EPI_RESID || kind == PPMS_EPI_RH || kind == PPMS_EPI_GRU) {
-        const bf16x8 h8 = *(const bf16x8*)((const bf16_t*)e.aux_sp.hi + pix * e.aux_sp.ld + cl);
-        const bf16x8 l8 = *(const bf16x8*)((const bf16_t*)e.aux_sp.lo + pix * e.aux_sp.ld + cl);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ax[j] = join_bf16(h8[j], l8[j]);
+        for (int j = 0; j < 8; ++j) ax[j] = join_bf16(a.h8[j], a.l8[j]);
     }
     if (kind == PPMS_EPI_RESID) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = apply_act(ax[j] + v[j], e.act) * e.scale;
+        for (int j = 0; j < 8; ++j) y[j] = ax[j] + v[j];
+        apply_act_n<8>(y, e.act, e.scale);
     } else if (kind == PPMS_EPI_RH) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) y[j] = sigmoid_fast(v[j]) * ax[j];
     } else if (kind == PPMS_EPI_GRU) {
-        const float* zp = e.aux_f32 + pix * e.aux_f32_ld + cl;
-        const f32x4 z0 = *(const f32x4*)zp, z1 = *(const f32x4*)(zp + 4);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float z = j < 4 ? z0[j & 3] : z1[j & 3];
+            const float z = j < 4 ? a.z0[j & 3] : a.z1[j & 3];
             y[j] = (1.0f - z) * ax[j] + z * tanh_fast(v[j]);
         }
     } else if (kind == PPMS_EPI_ADDF32) {
         float* op = e.out_f32 + pix * e.out_f32_ld + cl;
-        f32x4 o0 = *(f32x4*)op, o1 = *(f32x4*)(op + 4);
+        f32x4 o0 = gld<f32x4>(op), o1 = gld<f32x4>(op + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             o0[j] += v[j];
             o1[j] += v[4 + j];
         }
-        *(f32x4*)op = o0;
-        *(f32x4*)(op + 4) = o1;
+        gst<f32x4>(op, o0);
+        gst<f32x4>(op + 4, o1);
         return;
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) y[j] = apply_act(v[j], e.act) * e.scale;
+        for (int j = 0; j < 8; ++j) y[j] = v[j];
+        apply_act_n<8>(y, e.act, e.scale);
     }
     if (e.out_sp.hi != nullptr) {
         bf16x8 h8, l8;
@@ -196,15 +227,23 @@ __device__ __forceinline__ void epilogue_row8(const ppms_epilogue& e, const floa
             h8[j] = hh;
             l8[j] = ll;
         }
-        *(bf16x8*)((bf16_t*)e.out_sp.hi + pix * e.out_sp.ld + cl) = h8;
-        *(bf16x8*)((bf16_t*)e.out_sp.lo + pix * e.out_sp.ld + cl) = l8;
+        gst<bf16x8>((bf16_t*)e.out_sp.hi + pix * e.out_sp.ld + cl, h8);
+        gst<bf16x8>((bf16_t*)e.out_sp.lo + pix * e.out_sp.ld + cl, l8);
     }
     if (e.out_f32 != nullptr) {
         float* op = e.out_f32 + pix * e.out_f32_ld + cl;
         const f32x4 o0 = {y[0], y[1], y[2], y[3]}, o1 = {y[4], y[5], y[6], y[7]};
-        *(f32x4*)op = o0;
-        *(f32x4*)(op + 4) = o1;
+        gst<f32x4>(op, o0);
+        gst<f32x4>(op + 4, o1);
     }
+}
+
+// one row, operands fetched on the spot (callers without a row loop to pipeline: the slice-reduce kernel)
+template <bool LD = true>
+__device__ __forceinline__ void epilogue_row8(const ppms_epilogue& e, const float* vin, int64_t pix, int cl, int hw) {
+    row8_aux a;
+    if (LD) row8_fetch(e, pix, cl, a);
+    row8_finish<LD>(e, vin, pix, cl, hw, a);
 }
 
 // accumulator block (couts mb*32 .. +31 of the wave's 64) of 32 pixels -> the wave's staging patch [pixel][cout]

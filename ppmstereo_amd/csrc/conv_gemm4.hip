@@ -279,18 +279,24 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
     // ---- epilogue: accumulators -> wave-private LDS patch [32 px][64 couts] -> 8 couts of one pixel per lane -------
     const int cblock = (mgrp * 2 + wm) * 64;
     const int half = (cblock >= p.m_split) ? 1 : 0;
-    const ppms_epilogue& e = p.epi[half];
+    const ppms_epilogue e = p.epi[half];          // BY VALUE (SGPRs): through a reference every field is re-read from memory behind every
+                                                  // store of the row loop (the stores might alias the descriptor), one scalar-load round trip each
     const int cbase = cblock - (half ? p.m_split : 0);
     float* stg = (float*)(smem + wave * STG_WAVE);
     const int q = lane & 7;
     float b8[8];
     {
-        const f32x4 b0 = *(const f32x4*)(p.bias + cblock + q * 8), b1 = *(const f32x4*)(p.bias + cblock + q * 8 + 4);
+        const f32x4 b0 = gld<f32x4>(p.bias + cblock + q * 8), b1 = gld<f32x4>(p.bias + cblock + q * 8 + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             b8[j] = b0[j];
             b8[4 + j] = b1[j];
         }
+        // the bias must have LANDED before the row loop: vmcnt counts loads and stores in one order, so a wait for this load placed
+        // inside the loop (where its first use is) is a wait for every store of the previous 8-row step too -- one HBM write round
+        // trip (~1 us) per step, which is what the epilogues cost before this line
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(b8[j]));
     }
     if (ABL_E) {
 #pragma unroll
@@ -301,49 +307,56 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
                 for (int i = 0; i < 16; ++i) ((volatile float*)smem)[tid] = acc[a][b][i];
         return;
     }
-#pragma unroll 1
-    for (int nb = 0; nb < NB; ++nb) {              // (not unrolled: code size; the selects keep every accumulator index static)
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                f32x4 a4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float x = acc[mb][0][4 * gq + j];
-#pragma unroll
-                    for (int k = 1; k < NB; ++k) x = (nb == k) ? acc[mb][k][4 * gq + j] : x;
-                    a4[j] = x;
+    // the row loop exists twice: once for plain STORE epilogues, whose body holds no load (so nothing in it ever waits for the previous
+    // step's stores: conv_epilogue.h), once for everything else
+    auto rows = [&](auto ld_tag) {
+        constexpr bool LD = decltype(ld_tag)::value;
+    #pragma unroll 1
+        for (int nb = 0; nb < NB; ++nb) {              // (not unrolled: code size; the selects keep every accumulator index static)
+    #pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+    #pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 a4;
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = acc[mb][0][4 * gq + j];
+    #pragma unroll
+                        for (int k = 1; k < NB; ++k) x = (nb == k) ? acc[mb][k][4 * gq + j] : x;
+                        a4[j] = x;
+                    }
+                    if (LD && e.out_vt != nullptr) {                           // pixel-major V^T straight from the accumulator layout
+                        const int pid = wn * (32 * NB) + nb * 32 + r;
+                        const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+                        const int c4 = mb * 32 + 8 * gq + 4 * h;
+                        const f32x4 bb = gld<f32x4>(p.bias + cblock + c4);
+                        float v4[4];
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
+                        if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+                    }
+                    stage_write32(stg, r, h, mb, gq, a4);
                 }
-                if (e.out_vt != nullptr) {                           // pixel-major V^T straight from the accumulator layout
-                    const int pid = wn * (32 * NB) + nb * 32 + r;
-                    const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
-                    const int c4 = mb * 32 + 8 * gq + 4 * h;
-                    const f32x4 bb = *(const f32x4*)(p.bias + cblock + c4);
-                    float v4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
-                    if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+            __builtin_amdgcn_wave_barrier();
+    #pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                const int prow = it * 8 + (lane >> 3);
+                float v[8];
+                stage_read8(stg, prow, q, v);
+                const int pid = wn * (32 * NB) + nb * 32 + prow;
+                const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+                if (px < W && py < H) {
+                    const int64_t pix = (int64_t)(tf * H + py) * W + px;
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                    epilogue_row8<LD>(e, v, pix, cbase + q * 8, HW);
                 }
-                stage_write32(stg, r, h, mb, gq, a4);
             }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-            const int prow = it * 8 + (lane >> 3);
-            float v[8];
-            stage_read8(stg, prow, q, v);
-            const int pid = wn * (32 * NB) + nb * 32 + prow;
-            const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
-            if (px < W && py < H) {
-                const int64_t pix = (int64_t)(tf * H + py) * W + px;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += b8[j];
-                epilogue_row8(e, v, pix, cbase + q * 8, HW);
-            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
-    }
+    };
+    if (epilogue_is_plain(e)) rows(std::false_type{});
+    else rows(std::true_type{});
 }
 
 // patch shape / window geometry for a descriptor and a pixel-tile size; false when no patch shape fits

@@ -44,7 +44,19 @@ struct Geo5 {
     int nslice;              // grid-level K slices (gridDim.y): slice s takes the s-th share of every K-group's windows (small maps)
     float* part;             // nslice > 1: fp32 partial sums [slice][pixel][M] (no bias), finished by the slice-reduce kernel
     int64_t P;               // pixels = T*H*W
+#ifdef PPMS_CONV5_TIMING
+    long long* dbg;          // debug build only: [workgroup][8] wall-clock stamps (100 MHz) of wave 0: start, loop start, loop end, reduced, end
+#endif
 };
+
+#ifdef PPMS_CONV5_TIMING
+static long long* g_conv5_dbg = nullptr;
+#define CONV5_STAMP(K)                                                                    \
+    if (g.dbg != nullptr && (__builtin_amdgcn_readfirstlane(threadIdx.x) & 255) == 0) /* whole waves 0 and 4: a wave-uniform branch */        \
+        g.dbg[(int64_t)blockIdx.x * 16 + (__builtin_amdgcn_readfirstlane(threadIdx.x) >> 8) * 8 + (K)] = wall_clock64();
+#else
+#define CONV5_STAMP(K)
+#endif
 
 __device__ __forceinline__ void dma16_5(const void* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const PPMS_GLOBAL void*)(uintptr_t)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
@@ -65,6 +77,7 @@ __device__ __forceinline__ void vm_wait5(int n) {
 
 __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restrict__ pd, const Geo5 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    CONV5_STAMP(0)
     const ppms_conv& p = *pd;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the role branches below must be scalar
@@ -281,7 +294,9 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
         _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(areg[0][k]), "v"(areg[1][k]), "v"(bh[k]));         \
     }
     static_assert(DEPTH5 == 2, "two A stages: U and U ^ 1; the step loop is unrolled twice");
+    CONV5_STAMP(1)
     if (nbw == 4) CONV5_LOOP(4) else CONV5_LOOP(3)
+    CONV5_STAMP(2)
 #undef CONV5_LOOP
 #undef CONV5_STEP
 #undef CONV5_ADDR
@@ -318,71 +333,91 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
         if (kg == 1) return;
     }
 
+    CONV5_STAMP(3)
     // ---- epilogue: accumulators -> wave-private LDS patch [32 px][64 couts] -> 8 couts of one pixel per lane -------
     const int cblock = wm * 64;
     const int half = (cblock >= p.m_split) ? 1 : 0;
-    const ppms_epilogue& e = p.epi[half];
+    const ppms_epilogue e = p.epi[half];          // BY VALUE (SGPRs): through a reference every field is re-read from memory behind every
+                                                  // store of the row loop (the stores might alias the descriptor), one scalar-load round trip each
     const int cbase = cblock - (half ? p.m_split : 0);
     float* stg = (float*)(smem + wave * STG_WAVE);
     const int q = lane & 7;
     float b8[8];
     {
-        const f32x4 b0 = *(const f32x4*)(p.bias + cblock + q * 8), b1 = *(const f32x4*)(p.bias + cblock + q * 8 + 4);
+        const f32x4 b0 = gld<f32x4>(p.bias + cblock + q * 8), b1 = gld<f32x4>(p.bias + cblock + q * 8 + 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             b8[j] = b0[j];
             b8[4 + j] = b1[j];
         }
+        // the bias must have LANDED before the row loop: vmcnt counts loads and stores in one order, so a wait for this load placed
+        // inside the loop (where its first use is) is a wait for every store of the previous 8-row step too -- one HBM write round
+        // trip (~1 us) per step, which is what the epilogues cost before this line
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(b8[j]));
     }
-#pragma unroll 1
-    for (int nb = 0; nb < nbw; ++nb) {             // (not unrolled: code size; the selects keep every accumulator index static)
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                f32x4 a4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float x = acc[mb][0][4 * gq + j];
-#pragma unroll
-                    for (int k = 1; k < 4; ++k) x = (nb == k) ? acc[mb][k][4 * gq + j] : x;
-                    a4[j] = x;
+    // the row loop exists twice: once for plain STORE epilogues, whose body holds no load (so nothing in it ever waits for the previous
+    // step's stores: conv_epilogue.h), once for everything else
+    auto rows = [&](auto ld_tag) {
+        constexpr bool LD = decltype(ld_tag)::value;
+    #pragma unroll 1
+        for (int nb = 0; nb < nbw; ++nb) {             // (not unrolled: code size; the selects keep every accumulator index static)
+    #pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+    #pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 a4;
+    #pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = acc[mb][0][4 * gq + j];
+    #pragma unroll
+                        for (int k = 1; k < 4; ++k) x = (nb == k) ? acc[mb][k][4 * gq + j] : x;
+                        a4[j] = x;
+                    }
+                    if (LD && e.out_vt != nullptr) {                     // pixel-major V^T straight from the accumulator layout
+                        const int pid = (blk0 + nb) * 32 + r;
+                        const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+                        const int c4 = mb * 32 + 8 * gq + 4 * h;
+                        const f32x4 bb = gld<f32x4>(p.bias + cblock + c4);
+                        float v4[4];
+    #pragma unroll
+                        for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
+                        if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+                    }
+                    stage_write32(stg, r, h, mb, gq, a4);
                 }
-                if (e.out_vt != nullptr) {                           // pixel-major V^T straight from the accumulator layout
-                    const int pid = (blk0 + nb) * 32 + r;
-                    const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
-                    const int c4 = mb * 32 + 8 * gq + 4 * h;
-                    const f32x4 bb = *(const f32x4*)(p.bias + cblock + c4);
-                    float v4[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
-                    if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+            __builtin_amdgcn_wave_barrier();
+            if (nb == 0) { CONV5_STAMP(5) }
+    #pragma unroll 1
+            for (int it = 0; it < 4; ++it) {
+                if (nb == 0 && it == 1) { CONV5_STAMP(6) }
+                const int prow = it * 8 + (lane >> 3);
+                float v[8];
+                stage_read8(stg, prow, q, v);
+                const int pid = (blk0 + nb) * 32 + prow;
+                const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+                if (px < W && py < H) {
+                    const int64_t pix = (int64_t)(tf * H + py) * W + px;
+                    if (g.nslice > 1) {                                  // raw partial sums; bias and the fused epilogue run in the reduce kernel
+                        float* pp = g.part + ((int64_t)blockIdx.y * g.P + pix) * p.M + cblock + q * 8;
+                        gst<f32x4>(pp, (f32x4){v[0], v[1], v[2], v[3]});
+                        gst<f32x4>(pp + 4, (f32x4){v[4], v[5], v[6], v[7]});
+                    } else {
+    #pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                        // (fetching the next row's operands before this row's stores -- row8_fetch / row8_finish, two alternating operand
+                        //  sets -- was measured: slower, 21.6 -> 32 us for the z/r conv; the register pressure spills and the waits stay)
+                        epilogue_row8<LD>(e, v, pix, cbase + q * 8, HW);
+                    }
                 }
-                stage_write32(stg, r, h, mb, gq, a4);
             }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll 1
-        for (int it = 0; it < 4; ++it) {
-            const int prow = it * 8 + (lane >> 3);
-            float v[8];
-            stage_read8(stg, prow, q, v);
-            const int pid = (blk0 + nb) * 32 + prow;
-            const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
-            if (px < W && py < H) {
-                const int64_t pix = (int64_t)(tf * H + py) * W + px;
-                if (g.nslice > 1) {                                  // raw partial sums; bias and the fused epilogue run in the reduce kernel
-                    float* pp = g.part + ((int64_t)blockIdx.y * g.P + pix) * p.M + cblock + q * 8;
-                    *(f32x4*)pp = (f32x4){v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(pp + 4) = (f32x4){v[4], v[5], v[6], v[7]};
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += b8[j];
-                    epilogue_row8(e, v, pix, cbase + q * 8, HW);
-                }
-            }
+            __builtin_amdgcn_wave_barrier();
+            if (nb == 0) { CONV5_STAMP(7) }
         }
-        __builtin_amdgcn_wave_barrier();
-    }
+    };
+    if (g.nslice == 1 && epilogue_is_plain(e)) rows(std::false_type{});
+    else rows(std::true_type{});
+    CONV5_STAMP(4)
 }
 
 // tile shape / window geometry for a descriptor; picks (NBT, C) with the best chip fill; false when nothing fits
@@ -496,6 +531,9 @@ extern "C" int ppms_conv_gemm5_slices(const ppms_conv* d) {
 }
 
 static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, int nslice, float* part, void* stream);
+#ifdef PPMS_CONV5_TIMING
+extern "C" void ppms_debug_conv5_timing(long long* p) { g_conv5_dbg = p; }      // debug builds only (tools/conv5_phase_probe.py)
+#endif
 
 extern "C" int ppms_conv_gemm5(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, void* stream) {
     return conv5_launch(d, dev_desc, nbt, 1, nullptr, stream);
@@ -559,6 +597,9 @@ static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, 
     PPMS_REQUIRE(lds <= 160 * 1024, "conv_gemm5: LDS budget exceeded (%zu B)", lds);
     static ppms_device_once once;
     once.run([] { (void)hipFuncSetAttribute((const void*)conv5_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+#ifdef PPMS_CONV5_TIMING
+    g.dbg = g_conv5_dbg;
+#endif
     hipLaunchKernelGGL(conv5_kernel, dim3(ntiles, g.nslice), dim3(NT5), lds, (hipStream_t)stream, dev_desc, g);
     return ppms_check_launch("conv_gemm5");
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
                 for (int g = 0; g < 4; ++g) {
                     const int cl = mb * 32 + 8 * g + 4 * h;          // within the block
                     const int cg = mblk * 64 + cl;                    // global cout
-                    const f32x4 b4 = *(const f32x4*)(L.bias + cg);
+                    const f32x4 b4 = gld<f32x4>(L.bias + cg);
                     float y[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) y[j] = acc[mb][4 * g + j] + b4[j];
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
 #pragma unroll
                     for (int j = 0; j < 4; ++j) y[j] = gelu_erf(y[j]);
                     if (L.post_s != nullptr) {
-                        const f32x4 s4 = *(const f32x4*)(L.post_s + cg), t4 = *(const f32x4*)(L.post_t + cg);
+                        const f32x4 s4 = gld<f32x4>(L.post_s + cg), t4 = gld<f32x4>(L.post_t + cg);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) y[j] = gelu_erf(y[j] + (y[j] * s4[j] + t4[j]));
                     }
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
                         } else {                                                // ragged tail of the valid couts
                             const bf16_t* e = (const bf16_t*)&v;
                             for (int j = 0; j < 8; ++j)
-                                if (ocg + j < L.n_valid) op[j] = e[j];
+                                if (ocg + j < L.n_valid) gst<bf16_t>(op + j, e[j]);
                         }
                     }
                 }
