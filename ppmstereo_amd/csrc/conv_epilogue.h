@@ -126,39 +126,53 @@ __device__ __forceinline__ void epilogue_vt4(const ppms_epilogue& e, const float
         if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, (bf16_t)(apply_act(v[j], e.act) * e.scale));
 }
 
-// v[0..7]: acc + bias for couts cl..cl+7 (local to this half, cl % 8 == 0) at pixel pix.
-// LD = false: for descriptors that are a plain STORE without pre_f32 (epilogue_is_plain): no aux / pre / gate operand exists, and the
-// instantiation contains NO LOAD.  That matters more than the instruction count: vmcnt counts loads and stores in one order, so inside a
-// row loop whose body can load anything the compiler has to drain vmcnt to 0 somewhere in every step -- which also waits for the previous
-// step's stores, one HBM write round trip (~1 us) per 8-row step (measured: 17-19 us of epilogue per 1/4-scale conv launch).
-__device__ __forceinline__ bool epilogue_is_plain(const ppms_epilogue& e) { return e.kind == PPMS_EPI_STORE && e.pre_f32 == nullptr && e.out_vt == nullptr; }
-// The operands a row's epilogue reads besides the accumulators (pre_f32 share, aux_sp state, GRU gate), fetched by row8_fetch and
-// consumed by row8_finish: callers that walk rows in a loop fetch row i + 1 BEFORE finishing (= storing) row i, so that the wait for
-// a row's operands is a wait for loads that are OLDER than the previous row's stores (vmcnt is one in-order counter for both).
+// Row form: v[0..7] = acc + bias for couts cl..cl+7 (local to this half, cl % 8 == 0) at pixel pix.
+// ---- row epilogue in two halves: row8_fetch issues the loads of a row's extra operands (pre_f32 share, aux_sp state, GRU gate),
+// row8_finish consumes them, applies the epilogue and stores.  A row loop fetches the operands of a GROUP of rows first and finishes them
+// afterwards: vmcnt is one in-order counter for loads and stores, so the wait for a row's operands also waits for every store issued
+// before those loads -- one memory round trip per wait.  Grouping pays that once per group instead of once per row.
+// Both are specialised on the descriptor's CLASS so that an instantiation holds exactly the loads / registers its class needs:
+enum {
+    EPI_CLS_PLAIN = 0,     // STORE, no pre_f32, no out_vt: no load at all
+    EPI_CLS_PRE = 1,       // STORE + pre_f32
+    EPI_CLS_AUX = 2,       // RESID / RH without pre_f32: aux_sp
+    EPI_CLS_GRU = 3,       // GRU (aux_sp + gate, pre_f32 optional)
+    EPI_CLS_ANY = 4        // everything else (ADDF32, RESID / RH with pre_f32, out_vt): all fields checked at run time
+};
+__device__ __forceinline__ int epilogue_class(const ppms_epilogue& e) {
+    if (e.out_vt != nullptr) return EPI_CLS_ANY;
+    if (e.kind == PPMS_EPI_STORE) return e.pre_f32 != nullptr ? EPI_CLS_PRE : EPI_CLS_PLAIN;
+    if ((e.kind == PPMS_EPI_RESID || e.kind == PPMS_EPI_RH) && e.pre_f32 == nullptr) return EPI_CLS_AUX;
+    if (e.kind == PPMS_EPI_GRU) return EPI_CLS_GRU;
+    return EPI_CLS_ANY;
+}
+__device__ __forceinline__ bool epilogue_is_plain(const ppms_epilogue& e) { return epilogue_class(e) == EPI_CLS_PLAIN; }
+
 struct row8_aux {
     f32x4 p0, p1, z0, z1;
     bf16x8 h8, l8;
 };
+template <int CLS>
 __device__ __forceinline__ void row8_fetch(const ppms_epilogue& e, int64_t pix, int cl, row8_aux& a) {
-    if (e.n_valid - cl < 8) return;                // (ragged tail rows load inside row8_finish)
-    if (e.pre_f32 != nullptr) {
+    if (CLS == EPI_CLS_PLAIN || e.n_valid - cl < 8) return;       // (ragged tail rows load inside row8_finish)
+    if ((CLS == EPI_CLS_PRE || CLS == EPI_CLS_GRU || CLS == EPI_CLS_ANY) && e.pre_f32 != nullptr) {
         const float* pp = e.pre_f32 + pix * e.pre_f32_ld + cl;
         a.p0 = gld<f32x4>(pp), a.p1 = gld<f32x4>(pp + 4);
     }
     const int kind = e.kind;
-    if (kind == PPMS_EPI_RESID || kind == PPMS_EPI_RH || kind == PPMS_EPI_GRU) {
+    if (CLS == EPI_CLS_AUX || CLS == EPI_CLS_GRU || (CLS == EPI_CLS_ANY && (kind == PPMS_EPI_RESID || kind == PPMS_EPI_RH || kind == PPMS_EPI_GRU))) {
         a.h8 = gld<bf16x8>((const bf16_t*)e.aux_sp.hi + pix * e.aux_sp.ld + cl);
         a.l8 = gld<bf16x8>((const bf16_t*)e.aux_sp.lo + pix * e.aux_sp.ld + cl);
     }
-    if (kind == PPMS_EPI_GRU) {
+    if (CLS == EPI_CLS_GRU || (CLS == EPI_CLS_ANY && kind == PPMS_EPI_GRU)) {
         const float* zp = e.aux_f32 + pix * e.aux_f32_ld + cl;
         a.z0 = gld<f32x4>(zp), a.z1 = gld<f32x4>(zp + 4);
     }
 }
 
-// LD = false: a must not be read (plain STORE descriptors, see epilogue_is_plain)
-template <bool LD = true>
+template <int CLS>
 __device__ __forceinline__ void row8_finish(const ppms_epilogue& e, const float* vin, int64_t pix, int cl, int hw, const row8_aux& a) {
+    constexpr bool LD = CLS != EPI_CLS_PLAIN;
     const int nv = e.n_valid - cl;
     if (nv <= 0) return;
     if (nv < 8) {                                  // ragged tail of the valid couts: the 4-wide predicated form, twice
@@ -177,14 +191,14 @@ __device__ __forceinline__ void row8_finish(const ppms_epilogue& e, const float*
         v[j] = vin[j];
         ax[j] = 0.0f;
     }
-    if (LD && e.pre_f32 != nullptr) {
+    if ((CLS == EPI_CLS_PRE || CLS == EPI_CLS_GRU || CLS == EPI_CLS_ANY) && e.pre_f32 != nullptr) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             v[j] += a.p0[j];
             v[4 + j] += a.p1[j];
         }
     }
-    const int kind = LD ? e.kind : PPMS_EPI_STORE;
+    const int kind = (CLS == EPI_CLS_PLAIN || CLS == EPI_CLS_PRE) ? PPMS_EPI_STORE : (CLS == EPI_CLS_GRU ? PPMS_EPI_GRU : e.kind);
     if (kind == PPMS_EPI_RESID || kind == PPMS_EPI_RH || kind == PPMS_EPI_GRU) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) ax[j] = join_bf16(a.h8[j], a.l8[j]);
@@ -238,12 +252,13 @@ __device__ __forceinline__ void row8_finish(const ppms_epilogue& e, const float*
     }
 }
 
-// one row, operands fetched on the spot (callers without a row loop to pipeline: the slice-reduce kernel)
+// one row, operands fetched on the spot (callers without a row loop to group: the slice-reduce kernel)
 template <bool LD = true>
 __device__ __forceinline__ void epilogue_row8(const ppms_epilogue& e, const float* vin, int64_t pix, int cl, int hw) {
+    constexpr int CLS = LD ? EPI_CLS_ANY : EPI_CLS_PLAIN;
     row8_aux a;
-    if (LD) row8_fetch(e, pix, cl, a);
-    row8_finish<LD>(e, vin, pix, cl, hw, a);
+    row8_fetch<CLS>(e, pix, cl, a);
+    row8_finish<CLS>(e, vin, pix, cl, hw, a);
 }
 
 // accumulator block (couts mb*32 .. +31 of the wave's 64) of 32 pixels -> the wave's staging patch [pixel][cout]

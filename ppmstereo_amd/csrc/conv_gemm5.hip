@@ -356,10 +356,11 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(b8[j]));
     }
-    // the row loop exists twice: once for plain STORE epilogues, whose body holds no load (so nothing in it ever waits for the previous
-    // step's stores: conv_epilogue.h), once for everything else
-    auto rows = [&](auto ld_tag) {
-        constexpr bool LD = decltype(ld_tag)::value;
+    // the row loop is instantiated per epilogue class (conv_epilogue.h): each instance holds exactly the loads its class needs -- the plain
+    // one none at all -- and fetches the extra operands of a GROUP of G 8-row steps before it finishes (stores) them, so the wait for
+    // them (which on this one in-order counter is also a wait for the previous group's stores) comes once per group, not per step
+    auto rows = [&](auto cls_tag, auto grp_tag) {
+        constexpr int CLS = decltype(cls_tag)::value, G = decltype(grp_tag)::value;
     #pragma unroll 1
         for (int nb = 0; nb < nbw; ++nb) {             // (not unrolled: code size; the selects keep every accumulator index static)
     #pragma unroll
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
                         for (int k = 1; k < 4; ++k) x = (nb == k) ? acc[mb][k][4 * gq + j] : x;
                         a4[j] = x;
                     }
-                    if (LD && e.out_vt != nullptr) {                     // pixel-major V^T straight from the accumulator layout
+                    if (CLS == EPI_CLS_ANY && e.out_vt != nullptr) {                     // pixel-major V^T straight from the accumulator layout
                         const int pid = (blk0 + nb) * 32 + r;
                         const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
                         const int c4 = mb * 32 + 8 * gq + 4 * h;
@@ -389,25 +390,33 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
             __builtin_amdgcn_wave_barrier();
             if (nb == 0) { CONV5_STAMP(5) }
     #pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-                if (nb == 0 && it == 1) { CONV5_STAMP(6) }
-                const int prow = it * 8 + (lane >> 3);
-                float v[8];
-                stage_read8(stg, prow, q, v);
-                const int pid = (blk0 + nb) * 32 + prow;
-                const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
-                if (px < W && py < H) {
-                    const int64_t pix = (int64_t)(tf * H + py) * W + px;
-                    if (g.nslice > 1) {                                  // raw partial sums; bias and the fused epilogue run in the reduce kernel
-                        float* pp = g.part + ((int64_t)blockIdx.y * g.P + pix) * p.M + cblock + q * 8;
-                        gst<f32x4>(pp, (f32x4){v[0], v[1], v[2], v[3]});
-                        gst<f32x4>(pp + 4, (f32x4){v[4], v[5], v[6], v[7]});
-                    } else {
+            for (int it0 = 0; it0 < 4; it0 += G) {
+                if (nb == 0 && it0 == G) { CONV5_STAMP(6) }
+                row8_aux aux[G];
+                int64_t pixg[G];
+                bool okg[G];
     #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += b8[j];
-                        // (fetching the next row's operands before this row's stores -- row8_fetch / row8_finish, two alternating operand
-                        //  sets -- was measured: slower, 21.6 -> 32 us for the z/r conv; the register pressure spills and the waits stay)
-                        epilogue_row8<LD>(e, v, pix, cbase + q * 8, HW);
+                for (int gi = 0; gi < G; ++gi) {
+                    const int pid = (blk0 + nb) * 32 + (it0 + gi) * 8 + (lane >> 3);
+                    const int px = x0 + (pid & (g.C - 1)), py = y0 + (pid >> g.logC);
+                    okg[gi] = px < W && py < H;
+                    pixg[gi] = (int64_t)(tf * H + py) * W + px;
+                    if (okg[gi] && g.nslice == 1) row8_fetch<CLS>(e, pixg[gi], cbase + q * 8, aux[gi]);
+                }
+    #pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    float v[8];
+                    stage_read8(stg, (it0 + gi) * 8 + (lane >> 3), q, v);
+                    if (okg[gi]) {
+                        if (g.nslice > 1) {                              // raw partial sums; bias and the fused epilogue run in the reduce kernel
+                            float* pp = g.part + ((int64_t)blockIdx.y * g.P + pixg[gi]) * p.M + cblock + q * 8;
+                            gst<f32x4>(pp, (f32x4){v[0], v[1], v[2], v[3]});
+                            gst<f32x4>(pp + 4, (f32x4){v[4], v[5], v[6], v[7]});
+                        } else {
+    #pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                            row8_finish<CLS>(e, v, pixg[gi], cbase + q * 8, HW, aux[gi]);
+                        }
                     }
                 }
             }
@@ -415,8 +424,19 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
             if (nb == 0) { CONV5_STAMP(7) }
         }
     };
-    if (g.nslice == 1 && epilogue_is_plain(e)) rows(std::false_type{});
-    else rows(std::true_type{});
+    using I0 = std::integral_constant<int, EPI_CLS_PLAIN>;
+    using I1 = std::integral_constant<int, EPI_CLS_PRE>;
+    using I2 = std::integral_constant<int, EPI_CLS_AUX>;
+    using I3 = std::integral_constant<int, EPI_CLS_GRU>;
+    using I4 = std::integral_constant<int, EPI_CLS_ANY>;
+    using G1 = std::integral_constant<int, 1>;
+    using G4 = std::integral_constant<int, 4>;
+    const int cls = g.nslice > 1 ? (int)EPI_CLS_PLAIN : epilogue_class(e);
+    if (cls == EPI_CLS_PLAIN) rows(I0{}, G1{});
+    else if (cls == EPI_CLS_PRE) rows(I1{}, G4{});
+    else if (cls == EPI_CLS_AUX) rows(I2{}, G4{});
+    else if (cls == EPI_CLS_GRU) rows(I3{}, G1{});        // (groups of two rows were measured: 24 more live registers spill, 30.7 -> 38 us)
+    else rows(I4{}, G1{});
     CONV5_STAMP(4)
 }
 
