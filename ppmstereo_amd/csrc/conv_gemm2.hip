@@ -304,11 +304,11 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     }
     // the row loop exists twice: once for plain STORE epilogues, whose body holds no load (so nothing in it ever waits for the previous
     // step's stores: conv_epilogue.h), once for everything else
-    auto rows = [&](auto ld_tag) {
-        constexpr bool LD = decltype(ld_tag)::value;
+    auto rows = [&](auto cls_tag, auto grp_tag) {
+        constexpr int CLS = decltype(cls_tag)::value, G = decltype(grp_tag)::value;
     #pragma unroll 1
         for (int nb = 0; nb < 2; ++nb) {
-            if (LD && e.out_vt != nullptr) {                                   // pixel-major V^T straight from the accumulator layout
+            if (CLS == EPI_CLS_ANY && e.out_vt != nullptr) {                                   // pixel-major V^T straight from the accumulator layout
                 const int pid = wn * 64 + nb * 32 + r;
                 const int pf_ = pid & (F - 1), ps_ = pid >> g.logF;
                 const int px = x0 + (g.ysweep ? ps_ : pf_), py = y0 + (g.ysweep ? pf_ : ps_);
@@ -336,32 +336,53 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
                 }
             __builtin_amdgcn_wave_barrier();
     #pragma unroll 1
-            for (int it = 0; it < 4; ++it) {
-                const int prow = it * 8 + (lane >> 3);
-                float v[8];
-                stage_read8(stg, prow, q, v);
-                const int pid = wn * 64 + nb * 32 + prow;
-                const int pf_ = pid & (F - 1), ps_ = pid >> g.logF;
-                const int px = x0 + (g.ysweep ? ps_ : pf_), py = y0 + (g.ysweep ? pf_ : ps_);
-                if (px < W && py < H) {
-                    const int64_t pix = (int64_t)(tf * H + py) * W + px;
-                    if (g.nslice > 1) {                                  // K-sliced launch: raw partial sums, finished by the reduce kernel
-                        float* pp = g.part + ((int64_t)blockIdx.y * g.P + pix) * p.M + cblock + q * 8;
-                        const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                        gst<f32x4>(pp, o0);
-                        gst<f32x4>(pp + 4, o1);
-                    } else {
+            for (int it0 = 0; it0 < 4; it0 += G) {          // groups of G 8-row steps: operands first, then the stores (conv_epilogue.h)
+                row8_aux aux[G];
+                int64_t pixg[G];
+                bool okg[G];
     #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += b8[j];
-                        epilogue_row8<LD>(e, v, pix, cbase + q * 8, HW);
+                for (int gi = 0; gi < G; ++gi) {
+                    const int pid = wn * 64 + nb * 32 + (it0 + gi) * 8 + (lane >> 3);
+                    const int pf_ = pid & (F - 1), ps_ = pid >> g.logF;
+                    const int px = x0 + (g.ysweep ? ps_ : pf_), py = y0 + (g.ysweep ? pf_ : ps_);
+                    okg[gi] = px < W && py < H;
+                    pixg[gi] = (int64_t)(tf * H + py) * W + px;
+                    if (okg[gi] && g.nslice == 1) row8_fetch<CLS>(e, pixg[gi], cbase + q * 8, aux[gi]);
+                }
+    #pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    float v[8];
+                    stage_read8(stg, (it0 + gi) * 8 + (lane >> 3), q, v);
+                    if (okg[gi]) {
+                        if (g.nslice > 1) {                              // K-sliced launch: raw partial sums, finished by the reduce kernel
+                            float* pp = g.part + ((int64_t)blockIdx.y * g.P + pixg[gi]) * p.M + cblock + q * 8;
+                            const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                            gst<f32x4>(pp, o0);
+                            gst<f32x4>(pp + 4, o1);
+                        } else {
+    #pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += b8[j];
+                            row8_finish<CLS>(e, v, pixg[gi], cbase + q * 8, HW, aux[gi]);
+                        }
                     }
                 }
             }
             __builtin_amdgcn_wave_barrier();
         }
     };
-    if (epilogue_is_plain(e)) rows(std::false_type{});
-    else rows(std::true_type{});
+    using I0 = std::integral_constant<int, EPI_CLS_PLAIN>;
+    using I1 = std::integral_constant<int, EPI_CLS_PRE>;
+    using I2 = std::integral_constant<int, EPI_CLS_AUX>;
+    using I3 = std::integral_constant<int, EPI_CLS_GRU>;
+    using I4 = std::integral_constant<int, EPI_CLS_ANY>;
+    using G1 = std::integral_constant<int, 1>;
+    using G4 = std::integral_constant<int, 4>;
+    const int cls = g.nslice > 1 ? (int)EPI_CLS_PLAIN : epilogue_class(e);       // (a K-sliced launch stores raw partials: no operand to load)
+    if (cls == EPI_CLS_PLAIN) rows(I0{}, G1{});
+    else if (cls == EPI_CLS_PRE) rows(I1{}, G4{});
+    else if (cls == EPI_CLS_AUX) rows(I2{}, G4{});
+    else if (cls == EPI_CLS_GRU) rows(I3{}, G1{});
+    else rows(I4{}, G1{});
 }
 
 // Second half of a K-sliced convolution: sums the slices' partial tiles in slice order (deterministic), adds the bias and
