@@ -333,11 +333,20 @@ __device__ __forceinline__ void att_dma16(const void* src, char* lds_wave_base) 
 
 #include "attn64_asm.h"
 
+#ifdef PPMS_ATTN_TIMING
+static __device__ long long* g_attn_dbg_dev = nullptr;          // debug builds only: [workgroup][4] wall-clock stamps (100 MHz) of wave 0
+#define ATTN_STAMP(K)                                                                                                   \
+    if (g_attn_dbg_dev != nullptr && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) /* all of wave 0: a uniform branch */ \
+        g_attn_dbg_dev[(int64_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + (K)] = wall_clock64();
+#else
+#define ATTN_STAMP(K)
+#endif
 __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
                                                             const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
                                                             float scale_log2, int n, float* __restrict__ part_o, float* __restrict__ part_ml,
                                                             int32_t* __restrict__ redo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    ATTN_STAMP(0)
     constexpr int QB = 2;                         // 32-query blocks per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -459,6 +468,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     f32x2 pt2[2], tt2[2];
     const f32x2 scale2 = {scale_log2, scale_log2};
     attn64_prime(sa, ring, pt2, tt2, negm2, scale2, kaddr);
+    ATTN_STAMP(1)
     for (int j = 0; j < nt; ++j) {
         const bool more3 = j + 3 < nt;
         if (more3) issue_tile(j + 3);
@@ -475,6 +485,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         if (j + 1 == nt) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
     attn64_tail();
+    ATTN_STAMP(2)
     const float lsum[QB] = {lsum2[0][0] + lsum2[0][1], lsum2[1][0] + lsum2[1][1]};
 #pragma unroll
     for (int dblk = 0; dblk < 4; ++dblk)          // O += V P for keys 16..31 of the last sub-tile
@@ -512,6 +523,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
             part_ml[row * 2 + 1] = l_tot;
         }
     }
+    ATTN_STAMP(3)
 }
 
 // merges the per-frame partials of split mode: O = sum_s O_s 2^(m_s - m), l = sum_s l_s 2^(m_s - m); then the same
@@ -560,6 +572,9 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 
 }  // namespace
 
+#ifdef PPMS_ATTN_TIMING
+extern "C" void ppms_debug_attn_timing(long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg_dev), &p, sizeof(p)); }   // tools/attn_phase_probe.py
+#endif
 extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
                              ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, void* stream) {
     PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
