@@ -116,14 +116,15 @@ constexpr int STG_WAVE = 32 * STG_LD * 4;         // bytes of one wave's staging
 
 // the transposed V operand of the memory attention (bf16 [frame][n_valid][H*W]) is pixel-major: it is written from
 // the accumulator layout (lanes = adjacent pixels), before the transposition.  STORE epilogues only.
-__device__ __forceinline__ void epilogue_vt4(const ppms_epilogue& e, const float* v, int64_t pix, int cl, int hw) {
+__device__ __forceinline__ void epilogue_vt4(const ppms_epilogue& e, const float* v, int frame, int rem, int cl, int hw) {
+    // (frame, rem) = the pixel's frame and its offset inside the frame: the callers know both (a 64-bit division per call otherwise)
     const int nv = e.n_valid - cl;
-    const int64_t frame = pix / hw;
-    const int64_t rem = pix - frame * hw;
-    bf16_t* vp = (bf16_t*)e.out_vt + (frame * e.n_valid + cl) * hw + rem;
+    bf16_t* vp = (bf16_t*)e.out_vt + ((int64_t)frame * e.n_valid + cl) * hw + rem;
+    float y[4] = {v[0], v[1], v[2], v[3]};
+    apply_act_n<4>(y, e.act, e.scale);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, (bf16_t)(apply_act(v[j], e.act) * e.scale));
+        if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, (bf16_t)y[j]);
 }
 
 // Row form: v[0..7] = acc + bias for couts cl..cl+7 (local to this half, cl % 8 == 0) at pixel pix.

@@ -41,7 +41,19 @@ struct Geo2 {
     int nslice;              // grid-level K slices (gridDim.y): slice s takes the row-steps s*KG + kg, + KG*nslice, ...
     float* part;             // nslice > 1: fp32 partial sums [slice][pixel][M] (no bias), finished by conv_slice_reduce_kernel
     int64_t P;               // pixels = T*H*W
+#ifdef PPMS_CONV2_TIMING
+    long long* dbg;          // debug build only: [workgroup (x + gridDim.x * y)][8] wall-clock stamps (100 MHz) of wave 0
+#endif
 };
+
+#ifdef PPMS_CONV2_TIMING
+static long long* g_conv2_dbg = nullptr;
+#define CONV2_STAMP(K)                                                                                                    \
+    if (g.dbg != nullptr && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) /* all of wave 0: a uniform branch */       \
+        g.dbg[((int64_t)blockIdx.x + (int64_t)gridDim.x * blockIdx.y) * 8 + (K)] = wall_clock64();
+#else
+#define CONV2_STAMP(K)
+#endif
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
@@ -50,11 +62,14 @@ __device__ __forceinline__ int swz2(int row, int chunk) { return row * 64 + ((ch
 // concurrently in one workgroup; partial accumulators are summed through LDS in fixed order (deterministic) and wave
 // group 0 runs the epilogue.
 template <int WM, int KG>
-__global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* __restrict__ pd, const Geo2 g) {
+__global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv, const Geo2 g) {
     constexpr int NT = 128 * WM;              // threads of one K-group
     constexpr int MAXSLOT = (WM == 4) ? 2 : (WM == 3) ? 3 : (WM == 2) ? 4 : 8;      // window 16-B chunks per thread and plane
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const ppms_conv& p = *pd;
+    CONV2_STAMP(0)
+    // the descriptor travels BY VALUE in the kernel arguments (copied from the host descriptor at launch): one dependent memory round trip
+    // less at the head of every launch than through the device copy, and kernarg loads are known not to alias the kernel's stores
+    const ppms_conv& p = pv;
     const int kg = (KG > 1) ? (int)threadIdx.x / NT : 0;
     const int tid = (KG > 1) ? (int)threadIdx.x % NT : (int)threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -176,9 +191,11 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         load_a(rs * g.ksw);
         load_b(trow, rs - trow * g.nchunk);
     }
+    CONV2_STAMP(1)
     store_a(0);
     store_b(0);
     __syncthreads();
+    CONV2_STAMP(2)
     int bsel = 0, kx = 0, swx = 0, trow = 0;     // kx: tap index inside the window; trow: its LDS row offset
     for (int j = 0; j < nsteps; ++j) {
         const bool more = j + 1 < nsteps;
@@ -243,6 +260,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         }
     }
 
+    CONV2_STAMP(3)
     // ---- intra-workgroup split-K: fixed-order sum of the K-groups' partial tiles through LDS ----------------------
     if (KG > 1) {
         // (the loop's last barrier guarantees nobody still reads the staging area that is reused here)
@@ -278,6 +296,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
         if (kg > 0) return;
     }
 
+    CONV2_STAMP(4)
     // ---- epilogue: accumulators -> wave-private LDS patch [32 px][64 couts] -> 8 couts of one pixel per lane -------
     // (the loop's / the reduction's last barrier guarantees nobody still reads the operand stages reused here; from
     // here on every wave touches only its own patch, and LDS operations of one wave execute in order)
@@ -322,7 +341,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
                         float v4[4];
     #pragma unroll
                         for (int j = 0; j < 4; ++j) v4[j] = (nb ? acc[mb][1][4 * gq + j] : acc[mb][0][4 * gq + j]) + bb[j];
-                        if (px < W && py < H) epilogue_vt4(e, v4, pix, cbase + c4, HW);
+                        if (px < W && py < H) epilogue_vt4(e, v4, tf, py * W + px, cbase + c4, HW);
                     }
             }
     #pragma unroll
@@ -383,13 +402,14 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv* _
     else if (cls == EPI_CLS_AUX) rows(I2{}, G4{});
     else if (cls == EPI_CLS_GRU) rows(I3{}, G1{});
     else rows(I4{}, G1{});
+    CONV2_STAMP(5)
 }
 
 // Second half of a K-sliced convolution: sums the slices' partial tiles in slice order (deterministic), adds the bias and
 // runs the conv's own fused epilogue.  One thread = one pixel x 8 couts (coalesced 32-byte reads per slice).
-__global__ __launch_bounds__(256) void conv_slice_reduce_kernel(const ppms_conv* __restrict__ pd, const float* __restrict__ part, int nslice,
+__global__ __launch_bounds__(256) void conv_slice_reduce_kernel(const ppms_conv pv, const float* __restrict__ part, int nslice,
                                                                 int64_t P) {
-    const ppms_conv& p = *pd;
+    const ppms_conv& p = pv;
     const int groups = p.M >> 3;
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= P * groups) return;
@@ -427,13 +447,22 @@ int launch2(const ppms_conv* d, const ppms_conv* dev_desc, const Geo2& g, int nt
         ppms_set_error("conv_gemm2: LDS budget exceeded (%zu B)", lds);
         return PPMS_EINVAL;
     }
-    hipLaunchKernelGGL((conv2_kernel<WM, KG>), dim3(ntiles * g.mgroups, g.nslice), dim3(128 * WM * KG), lds, stream, dev_desc, g);
+#ifdef PPMS_CONV2_TIMING
+    Geo2 gd = g;
+    gd.dbg = g_conv2_dbg;
+    hipLaunchKernelGGL((conv2_kernel<WM, KG>), dim3(ntiles * g.mgroups, g.nslice), dim3(128 * WM * KG), lds, stream, *d, gd);
+    return ppms_check_launch("conv_gemm2");
+#endif
+    hipLaunchKernelGGL((conv2_kernel<WM, KG>), dim3(ntiles * g.mgroups, g.nslice), dim3(128 * WM * KG), lds, stream, *d, g);
     return ppms_check_launch("conv_gemm2");
 }
 
 }  // namespace
 
 static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, int nslice, float* part, void* stream, int ysweep = 0);
+#ifdef PPMS_CONV2_TIMING
+extern "C" void ppms_debug_conv2_timing(long long* p) { g_conv2_dbg = p; }      // debug builds only (tools/conv2_phase_probe.py)
+#endif
 
 // wm_hint: 0 = choose (all couts per workgroup when the grid still fills the chip, otherwise 64-cout blocks)
 extern "C" int ppms_conv_gemm2(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, void* stream) {
@@ -480,7 +509,7 @@ extern "C" int64_t ppms_conv_gemm2_slice_workspace_bytes(const ppms_conv* d, int
 int ppms_launch_slice_reduce(const ppms_conv* d, const ppms_conv* dev_desc, const float* workspace, int nslice, void* stream) {
     const int64_t P = (int64_t)d->T * d->H * d->W;
     const int64_t total = P * (d->M / 8);
-    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dev_desc, workspace, nslice, P);
+    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, *d, workspace, nslice, P);
     return ppms_check_launch("conv_slice_reduce");
 }
 
@@ -494,7 +523,7 @@ extern "C" int ppms_conv_gemm2_sliced(const ppms_conv* d, const ppms_conv* dev_d
     if (rc != 0) return rc;
     const int64_t P = (int64_t)d->T * d->H * d->W;
     const int64_t total = P * (d->M / 8);
-    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dev_desc, (const float*)workspace, nslice, P);
+    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, *d, (const float*)workspace, nslice, P);
     return ppms_check_launch("conv_gemm2_sliced");
 }
 
@@ -511,7 +540,7 @@ extern "C" int ppms_conv_gemm2_ysweep(const ppms_conv* d, const ppms_conv* dev_d
     if (rc != 0) return rc;
     const int64_t P = (int64_t)d->T * d->H * d->W;
     const int64_t total = P * (d->M / 8);
-    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, dev_desc, (const float*)workspace, nslice, P);
+    hipLaunchKernelGGL(conv_slice_reduce_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, *d, (const float*)workspace, nslice, P);
     return ppms_check_launch("conv_gemm2_ysweep");
 }
 

@@ -50,9 +50,9 @@ __device__ __forceinline__ void dma16(const void* src, char* lds_dst) {
     __builtin_amdgcn_global_load_lds((const PPMS_GLOBAL void*)(uintptr_t)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-__global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv* __restrict__ pd, const Geo3 g) {
+__global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv pv, const Geo3 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const ppms_conv& p = *pd;
+    const ppms_conv& p = pv;                       // by value in the kernel arguments (see conv_gemm2.hip)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(const ppms_conv* __restri
                         float v4[4];
     #pragma unroll
                         for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
-                        if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+                        if (px < W && py < H) epilogue_vt4(e, v4, tf, py * W + px, cbase + c4, HW);
                     }
                     stage_write32(stg, r, h, mb, gq, a4);
                 }
@@ -392,6 +392,6 @@ extern "C" int ppms_conv_gemm3(const ppms_conv* d, const ppms_conv* dev_desc, vo
     PPMS_REQUIRE(g.Wr <= 64 * MAXS && lds <= 80 * 1024, "conv_gemm3: window of %d rows does not fit", g.Wr);
     static ppms_device_once once;
     once.run([] { (void)hipFuncSetAttribute((const void*)conv3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); });
-    hipLaunchKernelGGL(conv3_kernel, dim3(ntiles * g.mgroups), dim3(NT), lds, (hipStream_t)stream, dev_desc, g);
+    hipLaunchKernelGGL(conv3_kernel, dim3(ntiles * g.mgroups), dim3(NT), lds, (hipStream_t)stream, *d, g);
     return ppms_check_launch("conv_gemm3");
 }

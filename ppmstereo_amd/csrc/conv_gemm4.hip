@@ -69,9 +69,9 @@ constexpr int PRIO = PPMS_CONV4_PRIO;
 constexpr bool ABL_A = PPMS_ABL & 1, ABL_B = PPMS_ABL & 2, ABL_D = PPMS_ABL & 4, ABL_E = PPMS_ABL & 8;
 
 template <int NB>
-__global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restrict__ pd, const Geo4 g) {
+__global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv pv, const Geo4 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const ppms_conv& p = *pd;
+    const ppms_conv& p = pv;                       // by value in the kernel arguments (see conv_gemm2.hip)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv4_kernel(const ppms_conv* __restri
                         float v4[4];
     #pragma unroll
                         for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
-                        if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+                        if (px < W && py < H) epilogue_vt4(e, v4, tf, py * W + px, cbase + c4, HW);
                     }
                     stage_write32(stg, r, h, mb, gq, a4);
                 }
@@ -470,8 +470,8 @@ extern "C" int ppms_conv_gemm4(const ppms_conv* d, const ppms_conv* dev_desc, in
         (void)hipFuncSetAttribute((const void*)conv4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     });
     if (npx == 256)
-        hipLaunchKernelGGL(conv4_kernel<4>, dim3(ntiles * g.mgroups), dim3(NT), lds, (hipStream_t)stream, dev_desc, g);
+        hipLaunchKernelGGL(conv4_kernel<4>, dim3(ntiles * g.mgroups), dim3(NT), lds, (hipStream_t)stream, *d, g);
     else
-        hipLaunchKernelGGL(conv4_kernel<2>, dim3(ntiles * g.mgroups), dim3(NT), lds, (hipStream_t)stream, dev_desc, g);
+        hipLaunchKernelGGL(conv4_kernel<2>, dim3(ntiles * g.mgroups), dim3(NT), lds, (hipStream_t)stream, *d, g);
     return ppms_check_launch("conv_gemm4");
 }

@@ -75,10 +75,10 @@ __device__ __forceinline__ void vm_wait5(int n) {
 
 #include "conv5_asm.h"
 
-__global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restrict__ pd, const Geo5 g) {
+__global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const Geo5 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     CONV5_STAMP(0)
-    const ppms_conv& p = *pd;
+    const ppms_conv& p = pv;                       // by value in the kernel arguments (see conv_gemm2.hip)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: the role branches below must be scalar
     const int r = lane & 31, h = lane >> 5;
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv* __restri
                         float v4[4];
     #pragma unroll
                         for (int j = 0; j < 4; ++j) v4[j] = a4[j] + bb[j];
-                        if (px < W && py < H) epilogue_vt4(e, v4, (int64_t)(tf * H + py) * W + px, cbase + c4, HW);
+                        if (px < W && py < H) epilogue_vt4(e, v4, tf, py * W + px, cbase + c4, HW);
                     }
                     stage_write32(stg, r, h, mb, gq, a4);
                 }
@@ -620,6 +620,6 @@ static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, 
 #ifdef PPMS_CONV5_TIMING
     g.dbg = g_conv5_dbg;
 #endif
-    hipLaunchKernelGGL(conv5_kernel, dim3(ntiles, g.nslice), dim3(NT5), lds, (hipStream_t)stream, dev_desc, g);
+    hipLaunchKernelGGL(conv5_kernel, dim3(ntiles, g.nslice), dim3(NT5), lds, (hipStream_t)stream, *d, g);
     return ppms_check_launch("conv_gemm5");
 }
