@@ -69,6 +69,9 @@ def cpu_baseline(T, H, W, iters, threads):
                 seconds_per_clip=total)
 
 
+TIMING_EVERY = 5          # per-launch events in steps 0, 5, 10, ... of the timed region
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,7 +116,7 @@ def main():
     torch.cuda.synchronize()
     assert torch.isfinite(disp).all()
 
-    # HIP events around EVERY launch of the two dominant kernel families (memory attention; the large-map implicit-GEMM
+    # HIP events around every launch (in the sampled steps: TIMING_EVERY) of the two dominant kernel families (memory attention; the large-map implicit-GEMM
     # convolution kernels conv5_kernel / conv3_kernel -- whichever the engine picked per conv), on the stream each is launched on
     Tl = T // world if sharded else T
     engs = [(model.update_block16.engine(Tl, H // 16, W // 16, dev, shard), iters // 2), (model.update_block08.engine(Tl, H // 8, W // 8, dev, shard), iters // 2),
@@ -131,15 +134,21 @@ def main():
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for a, b in step_ev:
+    from ppmstereo_amd import engine as _engine
+    for i, (a, b) in enumerate(step_ev):
+        # the per-launch HIP events of the roofline entries are recorded in every TIMING_EVERY-th step of the timed region only (steps 0, 5,
+        # ...): ~330 event pairs per clip cost ~2 ms of the clip's 43, and `value` is the time of ALL steps
+        _engine.KERNEL_TIMING["on"] = (not args.no_kernel_timing) and i % TIMING_EVERY == 0
         a.record()
         step()
         b.record()
+    _engine.KERNEL_TIMING["on"] = False               # nothing below is event-timed per launch
     torch.cuda.synchronize()
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
     step_ms = [a.elapsed_time(b) for a, b in step_ev]
 
+    n_sampled = len(range(0, args.steps, TIMING_EVERY))                # steps whose launches carried events
     px = T * H * W
     value = (1 if sharded else world) * args.steps * px / elapsed
     ksel = min(5, T)
@@ -160,11 +169,11 @@ def main():
         tfile = _latest_profile("attn_traffic.json")
         if tfile and (T, H, W) == (5, 320, 512):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        roofs.append(dict(bound="mfma", kernel="memory attention = one ppms_mem_attn call (attention kernel + combine), every call of the timed region "
+        roofs.append(dict(bound="mfma", kernel="memory attention = one ppms_mem_attn call (attention kernel + combine), every call in every 5th step of the timed region "
                                                "(3 scales: 1/16, 1/8, 1/4); algorithmic FLOPs = sum over launches of 4*n*(k*n)*128*T",
                           achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
                           traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/rNN_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-                          launches=n_launch, avg_ms=round(tot_ms / n_launch, 4), total_ms_per_step=round(tot_ms / args.steps, 3),
+                          launches=n_launch, avg_ms=round(tot_ms / n_launch, 4), total_ms_per_step=round(tot_ms / n_sampled, 3),
                           flop_per_launch=tot_flop / n_launch, per_scale=per_scale))
         # ---- large-map conv kernels: algorithmic FLOPs of a launch = 2 * pixels * couts * cin * taps from its descriptor
         if conv3:
@@ -187,12 +196,12 @@ def main():
                 if tfile and (T, H, W) == (5, 320, 512):
                     ctraffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
                 roofs.append(dict(bound="mfma", kernel="conv5_kernel / conv3_kernel (large-map implicit-GEMM convolutions, bf16x3 split MFMA; per_op names the kernel), "
-                                                       "every launch of the timed region; "
+                                                       "every launch in every 5th step of the timed region; "
                                                        "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / 3 (three MFMAs per product)",
                                   achieved=round(cach, 2), peak=round(CONV_BOUND_TFLOPS, 1), unit="TFLOP/s", frac=round(cach / CONV_BOUND_TFLOPS, 4),
                                   frac_of_bf16_dense=round(cach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=ctraffic,
                                   traffic_note="HBM bytes of ONE zr1_0 launch at the 1/4 scale, profiles/rNN_conv_traffic.json",
-                                  launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / args.steps, 3),
+                                  launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / n_sampled, 3),
                                   flop_per_launch=c_flop / c_n, per_op=per_op))
         roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first
     # the same clip with test_mode=False (the reference's training-style return): every iteration runs the mask head, the convex
