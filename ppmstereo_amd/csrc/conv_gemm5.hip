@@ -302,35 +302,39 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
 #undef CONV5_ADDR
     __syncthreads();                               // the window buffers become the reduction / epilogue staging areas
 
-    // ---- M = 128: sum the two K-groups' partial tiles (fixed order: group 0 + group 1) through LDS ---------------------------
+    // ---- M = 128: sum the two K-groups' partial tiles through LDS; BOTH groups then finish the tile: the two waves that hold partials of
+    // the same (64 couts x nbw blocks) tile swap halves -- group 1 hands over its blocks 0-1, group 0 its blocks 2.. -- and each runs the
+    // epilogue on the blocks it received (8 instead of 4 waves in the epilogue; a + b is the same fp32 value in either order) -------------
+    int nb_lo = 0, nb_hi = nbw;
     if (g.kgroups == 2) {
         float* red = (float*)smem + (wm * 2 + wn) * (128 * 64);              // one 32 KiB slot per (wm, wn): 128 registers x 64 lanes
-        if (kg == 1) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < 4; ++nb)
+                if ((nb < 2) == (kg == 1)) {                                 // (uniform: nb is static, kg is per wave) the blocks the OTHER group finishes
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const f32x4 v4 = {acc[mb][nb][4 * q4], acc[mb][nb][4 * q4 + 1], acc[mb][nb][4 * q4 + 2], acc[mb][nb][4 * q4 + 3]};
                         *(f32x4*)(red + (((mb * 4 + nb) * 4 + q4) * 64 + lane) * 4) = v4;
                     }
-        }
+                }
         __syncthreads();
-        if (kg == 0) {
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 4; ++nb)
+            for (int nb = 0; nb < 4; ++nb)
+                if ((nb < 2) == (kg == 0)) {
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const f32x4 v4 = *(const f32x4*)(red + (((mb * 4 + nb) * 4 + q4) * 64 + lane) * 4);
 #pragma unroll
                         for (int e2 = 0; e2 < 4; ++e2) acc[mb][nb][4 * q4 + e2] += v4[e2];
                     }
-        }
+                }
         __syncthreads();                           // the exchange area is reused as the epilogue's staging patches
-        if (kg == 1) return;
+        nb_lo = kg ? 2 : 0;
+        nb_hi = kg ? nbw : 2;
     }
 
     CONV5_STAMP(3)
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
     auto rows = [&](auto cls_tag, auto grp_tag) {
         constexpr int CLS = decltype(cls_tag)::value, G = decltype(grp_tag)::value;
     #pragma unroll 1
-        for (int nb = 0; nb < nbw; ++nb) {             // (not unrolled: code size; the selects keep every accumulator index static)
+        for (int nb = nb_lo; nb < nb_hi; ++nb) {       // (not unrolled: code size; the selects keep every accumulator index static)
     #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
     #pragma unroll
@@ -388,10 +392,10 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
                     stage_write32(stg, r, h, mb, gq, a4);
                 }
             __builtin_amdgcn_wave_barrier();
-            if (nb == 0) { CONV5_STAMP(5) }
+            if (nb == nb_lo) { CONV5_STAMP(5) }
     #pragma unroll 1
             for (int it0 = 0; it0 < 4; it0 += G) {
-                if (nb == 0 && it0 == G) { CONV5_STAMP(6) }
+                if (nb == nb_lo && it0 == G) { CONV5_STAMP(6) }
                 row8_aux aux[G];
                 int64_t pixg[G];
                 bool okg[G];
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (nb == 0) { CONV5_STAMP(7) }
+            if (nb == nb_lo) { CONV5_STAMP(7) }
         }
     };
     using I0 = std::integral_constant<int, EPI_CLS_PLAIN>;
