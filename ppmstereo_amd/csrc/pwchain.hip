@@ -36,10 +36,14 @@ struct ChainParams {
 __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restrict__ cp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ChainParams& c = *cp;
-    char* bufX = smem;                        // chain input (kept for the residual)
-    char* bufA = smem + ACT_BUF;              // ping
-    char* bufB = smem + 2 * ACT_BUF;          // pong
-    char* wsm = smem + 3 * ACT_BUF;           // one 64-cout weight block
+    // Two activation buffers, used alternately, + one weight block: 80 KiB, so that TWO workgroups share a CU (three buffers: one
+    // workgroup per CU and, with 400 tiles on 256 CUs, a half-empty second round).  The residual operand is the chain INPUT, buffer 0:
+    // a residual layer is either the first layer (buffer 0 is its source) or the second one (buffer 0 is its DESTINATION: every lane
+    // reads the residual at exactly the address it then writes, and nothing else reads buffer 0 in that layer); the host side
+    // (engine.py PwChain) refuses chains with a residual further down, where buffer 0 no longer holds the input.
+    char* bufX = smem;                        // chain input = buffer 0
+    char* bufA = smem + ACT_BUF;              // buffer 1
+    char* wsm = smem + 2 * ACT_BUF;           // one 64-cout weight block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int64_t p0 = (int64_t)blockIdx.x * TP;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
     for (int l = 0; l < c.nlayers; ++l) {
         const Layer& L = c.layer[l];
         const bool last = (l == c.nlayers - 1);
-        char* dst = (src == bufA) ? bufB : bufA;
+        char* dst = (src == bufX) ? bufA : bufX;
         const int mblocks = L.M / 64;
         for (int mblk = 0; mblk < mblocks; ++mblk) {
             __syncthreads();                                      // previous users of wsm / producers of src are done
@@ -178,9 +182,9 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
 
 extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
     PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");
-    constexpr size_t lds = 3 * ACT_BUF + W_BLK;                // 112 KiB
+    constexpr size_t lds = 2 * ACT_BUF + W_BLK;                // 80 KiB: two workgroups per CU
     static ppms_device_once once;
-    once.run([] { (void)hipFuncSetAttribute((const void*)pwchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(3 * ACT_BUF + W_BLK)); });
+    once.run([] { (void)hipFuncSetAttribute((const void*)pwchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ACT_BUF + W_BLK)); });
     hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params);
     return ppms_check_launch("pwchain");
 }

@@ -155,6 +155,8 @@ class PwChain:
         device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         cp = L.ChainParams()
         cp.inp, cp.out, cp.nlayers, cp.P = inp, out, len(layers), pixels
+        # (pwchain.hip keeps two activation buffers: the residual operand = the chain input survives only up to the second layer)
+        assert not any(resid for _, _, resid, _ in layers[2:]), "pwchain: a residual layer must be the first or the second of its chain"
         for i, (pack, n_valid, resid, post) in enumerate(layers):
             packed, bias, meta = pack
             assert meta["nk"] == 2 and meta["version"] == 2, "chain layers are 1x1 convs with 64 (padded) input channels"
