@@ -98,8 +98,10 @@ typedef struct ppms_conv {
     ppms_epilogue epi[2];
 } ppms_conv;
 
-/* desc: host copy (validated, sizes the grid); dev_desc: the same bytes in device memory (caller-owned, must stay
- * valid until the kernel has run -- descriptors are built once per scale, every pointer in them is fixed). */
+/* desc: host copy (validated, sizes the grid, and -- since ABI v2 -- copied into the kernel arguments at launch, so it may be
+ * changed or freed as soon as the call returns); dev_desc: the same bytes in device memory (caller-owned; must be non-NULL, kept in
+ * the signature for ABI stability: the kernels no longer read it -- a descriptor in the kernel arguments saves a dependent memory
+ * round trip at the head of every launch and is known not to alias the kernel's stores). */
 /* Data-reuse tiling: all couts of a pixel tile per workgroup, LDS activation window swept by the kw taps.
  * desc->w must be in the pack_conv2 layout (ppmstereo_amd/packing.py).
  * wm_hint: 64-cout blocks per workgroup (1..4), 0 = let the library choose from the grid size. */
