@@ -42,6 +42,10 @@ struct Geo2 {
     float* part;             // nslice > 1: fp32 partial sums [slice][pixel][M] (no bias), finished by conv_slice_reduce_kernel
     int64_t P;               // pixels = T*H*W
     unsigned wr_magic;       // ceil(2^20 / WR): wrow / WR == (wrow * wr_magic) >> 20 for every window row (checked on the host); 0: divide
+    // x / d == __umulhi(x, floor(2^32 / d) + 1) for x, d < 2^16 (host-checked ranges): the set-up of a small-map launch was mostly runtime
+    // integer divisions (tile index, row-step -> tap / chunk), ~40 instructions each
+    unsigned m_mgroups, m_tiles_x, m_tiles_y, m_nchunk, m_kho, m_kstride;
+    int kho;                 // kernel rows NOT swept inside a window (p.kh, or 1 for the y-swept / 2-D forms)
 #ifdef PPMS_CONV2_TIMING
     long long* dbg;          // debug build only: [workgroup (x + gridDim.x * y)][8] wall-clock stamps (100 MHz) of wave 0
 #endif
@@ -55,6 +59,9 @@ static long long* g_conv2_dbg = nullptr;
 #else
 #define CONV2_STAMP(K)
 #endif
+
+// x / d with m = floor(2^32 / d) + 1 (exact while x * d < 2^32; the host checks the ranges), m == 0 standing for d == 1
+__device__ __forceinline__ int fdiv(int x, unsigned m) { return m ? (int)__umulhi((unsigned)x, m) : x; }
 
 __device__ __forceinline__ int swz2(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
 
@@ -76,12 +83,12 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
-    const int mgrp = blockIdx.x % g.mgroups;
-    int tile = blockIdx.x / g.mgroups;
-    const int tx = tile % g.tiles_x;
-    tile /= g.tiles_x;
-    const int ty = tile % g.tiles_y;
-    const int tf = tile / g.tiles_y;                       // frame
+    const int tile0 = fdiv((int)blockIdx.x, g.m_mgroups);
+    const int mgrp = (int)blockIdx.x - tile0 * g.mgroups;
+    const int tile1 = fdiv(tile0, g.m_tiles_x);
+    const int tx = tile0 - tile1 * g.tiles_x;
+    const int tf = fdiv(tile1, g.m_tiles_y);               // frame
+    const int ty = tile1 - tf * g.tiles_y;
     const int x0 = tx * g.C, y0 = ty * g.R;
     const int H = p.H, W = p.W, T = p.T;
     const int HW = H * W;
@@ -131,8 +138,8 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
         for (int i = 0; i < 4; ++i) *(u32x4*)(s + i * NT * 16) = ra[i];
     };
     auto load_b = [&](int trow, int chunk) {
-        const int kho = (g.ysweep || g.hs2) ? 1 : p.kh;            // kernel rows NOT swept inside a window
-        const int ky = trow % kho, kz = trow / kho;
+        const int kho = g.kho;                                     // kernel rows NOT swept inside a window
+        const int kz = fdiv(trow, g.m_kho), ky = trow - kz * kho;
         const int dy = kho == 1 ? 0 : ky - hy, dt = kz - ht;
         const int s = (chunk >= g.n0) ? 1 : 0;
         const int c0 = (chunk - (s ? g.n0 : 0)) * BK + cB * 8;
@@ -187,9 +194,9 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
     const int rs_end = (kz1 + 1) * rs_per_kz;
     const int kstride = KG * g.nslice;        // row-step = trow * nchunk + chunk; K-group kg of slice s takes every kstride-th one
     int rs = kz0 * rs_per_kz + (int)blockIdx.y * KG + kg;
-    const int nsteps = ((rs_end - kz0 * rs_per_kz) / kstride) * g.ksw;     // identical for every group (rs_per_kz % kstride == 0)
+    const int nsteps = fdiv(rs_end - kz0 * rs_per_kz, g.m_kstride) * g.ksw;      // identical for every group (rs_per_kz % kstride == 0)
     {
-        const int trow = rs / g.nchunk;
+        const int trow = fdiv(rs, g.m_nchunk);
         load_a(rs * g.ksw);
         load_b(trow, rs - trow * g.nchunk);
     }
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
             const int nrs = need_b ? rs + kstride : rs;
             load_a(nrs * g.ksw + (need_b ? 0 : kx + 1));
             if (need_b) {
-                const int trow = nrs / g.nchunk;
+                const int trow = fdiv(nrs, g.m_nchunk);
                 load_b(trow, nrs - trow * g.nchunk);
             }
         }
@@ -659,6 +666,17 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
         else if (nwg <= 512 && nchunk % 2 == 0) kgs = 2;   // ~68 KiB of LDS each: two such workgroups share a CU
     }
     if (kgs > 1) g.bstages = 1;                // K-groups keep ONE window copy each (LDS budget), at one more barrier per window
+    {   // multiply-high reciprocals of the kernel's runtime divisors (fdiv)
+        auto magic = [](int dd) { return dd == 1 ? 0u : (unsigned)((1ull << 32) / (unsigned)dd) + 1u; };
+        g.kho = (ysweep || win2d) ? 1 : d->kh;
+        const int64_t rows_all = (int64_t)d->kt * d->kh * nchunk;
+        const int kstride = kgs * nslice;
+        PPMS_REQUIRE((int64_t)nwg * g.mgroups < (1ll << 32) && (int64_t)ntiles * g.tiles_x < (1ll << 32) && rows_all * nchunk < (1ll << 32) &&
+                         rows_all * kstride < (1ll << 32),
+                     "conv_gemm2: geometry too large for the 32-bit reciprocal divisions");
+        g.m_mgroups = magic(g.mgroups), g.m_tiles_x = magic(g.tiles_x), g.m_tiles_y = magic(g.tiles_y), g.m_nchunk = magic(nchunk), g.m_kho = magic(g.kho),
+        g.m_kstride = magic(kstride);
+    }
     if (kgs == 4) return launch2<1, 4>(d, dev_desc, g, ntiles, st);
     if (kgs == 2) return launch2<1, 2>(d, dev_desc, g, ntiles, st);
     switch (wm) {
