@@ -48,7 +48,7 @@ extern "C" int ppms_device_info(char* name, int name_cap, int* cu_count, int* cl
 // one thread = a run of DW_PX pixels along x times 8 channels: per kernel row it loads the DW_PX + K - 1 window
 // positions once (16-byte loads of the hi and lo planes, channel-last rows are contiguous) and sweeps the K taps over
 // them from registers; the weights sit in LDS transposed to [tap][channel] (two b128 reads per tap).
-constexpr int DW_PX = 4;
+constexpr int DW_PX = 2;            // (4: 31.6 us at the 1/4 scale, 2: 28.3 -- twice the threads hide more of the load latency)
 template <int K>
 __global__ __launch_bounds__(256) void dwconv_gelu_kernel(ppms_sp x, ppms_sp y, const float* __restrict__ w, const float* __restrict__ b,
                                                           int H, int W, int64_t rows, int groups) {
