@@ -13,9 +13,26 @@ __global__ __launch_bounds__(256) void corr_build_kernel(const float* __restrict
                                                          float* __restrict__ p3, float* __restrict__ p4, int C, int H, int W) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int row = blockIdx.y;               // b*H + y
+    // XCD-aware order: workgroups go to the 8 XCDs round-robin by dispatch index and every XCD has its own L2.  The x1 tiles of one
+    // epipolar line all stream the same f2 line (C x W floats), so they are dealt to ONE XCD: of 8 * ntx consecutive workgroups, number
+    // 8 t + k is tile t of line k of the group (plain order: each XCD fetches every f2 line itself, ntx times the traffic)
+    int row, tx;
+    {
+        const int ntx = gridDim.x, nrow = gridDim.y;
+        const int lin = blockIdx.x + ntx * blockIdx.y;
+        const int grp = lin / (8 * ntx), in = lin - grp * 8 * ntx;
+        const int full = nrow / 8;                       // groups of 8 lines; the last nrow % 8 lines keep the plain order
+        if (grp < full) {
+            row = grp * 8 + (in & 7);
+            tx = in >> 3;
+        } else {
+            const int rest = lin - full * 8 * ntx;
+            row = full * 8 + rest / ntx;
+            tx = rest - (rest / ntx) * ntx;
+        }
+    }
     const int b = row / H, y = row - b * H;
-    const int i0 = blockIdx.x * 32;
+    const int i0 = tx * 32;
     const int li = lane & 31, lk = lane >> 5;
     const int64_t chan_stride = (int64_t)H * W;
     const float* a_base = f1 + ((int64_t)b * C * H + y) * W;      // + c*chan_stride + x
