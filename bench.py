@@ -207,14 +207,16 @@ def main():
     # the same clip with test_mode=False (the reference's training-style return): every iteration runs the mask head, the convex
     # upsampling and the full-resolution resize of its prediction.  Reported beside the headline number, never as `value`.
     n_all = 3
-    torch.cuda.synchronize()
-    D.barrier()
-    t_all = time.perf_counter()
-    for _ in range(n_all):
-        model.cascade(feats, iters, T, shard=shard, test_mode=False)
-    torch.cuda.synchronize()
-    D.barrier()
-    all_ms = D.max_over_ranks(time.perf_counter() - t_all) / n_all * 1e3
+    all_ms = None
+    if not sharded:                                # (replicas: every rank times its own clip; the frame-sharded mode reports `value` only)
+        torch.cuda.synchronize()
+        D.barrier()
+        t_all = time.perf_counter()
+        for _ in range(n_all):
+            model.cascade(feats, iters, T, shard=shard, test_mode=False)
+        torch.cuda.synchronize()
+        D.barrier()
+        all_ms = D.max_over_ranks(time.perf_counter() - t_all) / n_all * 1e3
     encoders = None
     if args.with_encoders and rank == 0 and not sharded:
         # SURVEY 8 rows f3-f5 on the same clip geometry: fnet on the 2T images, cnet on the T left images, SST on the 1/16 features
@@ -274,7 +276,7 @@ def main():
                                         "convex upsampling and the full-resolution resize run only where their result is consumed -- the last iteration "
                                         "of each scale; ms_per_step_all_predictions times the same clip with every iteration's prediction produced)",
                                 T=T, H=H, W=W, iters=iters, parallelism=par),
-                   ms_per_step_all_predictions=round(all_ms, 3),
+                   ms_per_step_all_predictions=None if all_ms is None else round(all_ms, 3),
                    roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None, cpu_baseline=cpu,
                    library=os.path.relpath(L.lib_path(), ROOT), **({"encoders": encoders} if encoders else {}))
         print(json.dumps(out))
