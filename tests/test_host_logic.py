@@ -266,3 +266,26 @@ def test_library_holds_no_packed_fp32_arithmetic():
     n_obj, n_ins, n_mfma, hits = chk.scan(os.path.join(root, "ppmstereo_amd", "libppms.so"))
     assert n_obj >= 10 and n_ins > 100000 and n_mfma > 500, (n_obj, n_ins, n_mfma)       # the scan really saw the device code
     assert hits == [], hits[:5]
+
+
+def test_corr_build_workgroup_order_is_a_bijection():
+    """corr_build_kernel deals the x1 tiles of an epipolar line to one XCD by remapping its dispatch index (corr.hip): groups of 8 lines x
+    ntx tiles, workgroup 8 t + k of a group = tile t of line k; the last nrow % 8 lines keep the plain order.  The same arithmetic here:
+    every (line, tile) pair must come out exactly once for any grid."""
+    def remap(ntx, nrow):
+        seen = set()
+        for lin in range(ntx * nrow):
+            grp = lin // (8 * ntx)
+            inn = lin - grp * 8 * ntx
+            full = nrow // 8
+            if grp < full:
+                row, tx = grp * 8 + (inn & 7), inn >> 3
+            else:
+                rest = lin - full * 8 * ntx
+                row, tx = full * 8 + rest // ntx, rest % ntx
+            assert 0 <= row < nrow and 0 <= tx < ntx
+            seen.add((row, tx))
+        assert len(seen) == ntx * nrow
+    for ntx in (1, 2, 3, 4, 5, 8, 10, 40):
+        for nrow in (1, 7, 8, 9, 15, 16, 100, 230, 400):
+            remap(ntx, nrow)
