@@ -73,6 +73,9 @@ __device__ __forceinline__ void vm_wait5(int n) {
 #undef PPMS_VMW
 }
 
+#ifndef CONV5_ABL_A
+#define CONV5_ABL_A 0        // ablation builds (-DCONV5_ABL_A=1): every k-step loads the FIRST step's weights (L1 hits): wrong results, timing only
+#endif
 #include "conv5_asm.h"
 
 __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const Geo5 g) {
@@ -230,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
         __builtin_amdgcn_sched_barrier(0);                                                                                     \
         /* (every MFMA group is unconditional straight-line code: an if / else around asm groups that redefine the eight      */ \
         /*  accumulator tuples makes the register allocator copy and spill them; the last step simply re-requests data)        */ \
-        mfma_group1<NBW, MORE>(acc, areg[U][1], areg[U][3], bh, areg[(U) ^ 1], avoff, abase + (int64_t)la_ks * astep);         \
+        mfma_group1<NBW, MORE>(acc, areg[U][1], areg[U][3], bh, areg[(U) ^ 1], avoff, abase + (int64_t)(CONV5_ABL_A ? 0 : la_ks) * astep);         \
         if (ahead >= 2) {                                                                                                      \
             ++la_ks;                                                                                                           \
             if (++la_s == g.nsweep) la_s = 0, la_ks += (wstride - 1) * g.nsweep; /* next window of this K-group */             \
