@@ -489,6 +489,14 @@ extern "C" int ppms_conv_gemm2_slices(const ppms_conv* d) {
     if (nwg >= 512) return 1;
     const int rs_per_kz = d->kh * nchunk;
     const int64_t steps = (int64_t)d->kt * rs_per_kz * d->kw;        // k-steps of the whole K loop
+    // Short K loops: the unsliced launch splits K INSIDE the workgroup (2 or 4 K-groups, conv2_launch) and needs no reduce launch; it wins
+    // when that leaves <= 10 k-steps per K-group, the workgroups fit one round on the chip and still make >= 512 waves (tools/slice_tune.py,
+    // 1/16 and 1/8 scales of config 2: mask head 25.8 -> 21.6 us, the GRU's (1,1,5) tails 26 -> 18 us, the 384-wide 1x1 GEMMs 21.7 -> 16.5 us)
+    {
+        const int64_t ntiles = (P + 127) / 128;
+        const int kg = (ntiles < 160 || d->M == 64) ? ((nwg <= 128 && nchunk % 4 == 0) ? 4 : (nwg <= 512 && nchunk % 2 == 0) ? 2 : 1) : 1;
+        if (kg > 1 && steps / kg <= 10 && nwg <= 256 && nwg * kg * 2 >= 512) return 1;
+    }
     int best = 1;
     for (int s = 2; s <= 8; ++s)
         if (rs_per_kz % s == 0 && nwg * s <= 1024 && steps / s >= 6) best = s;

@@ -195,6 +195,11 @@ def test_k_slicing_plan_for_small_maps():
     assert s(5, 80, 128, 256, (1, 1, 15), [128, 256]) == 1         # 1/4 scale: enough workgroups
     assert s(5, 20, 32, 128, (1, 1, 1), [128], out_vt=True) == 1   # to_v writes V^T from the accumulators
     assert s(5, 20, 32, 64, (1, 1, 1), [128]) == 1                 # 4 k-steps in all: nothing to slice
+    # short K loops stay unsliced when the in-workgroup K-groups leave <= 10 k-steps each and the grid is one round of >= 512 waves
+    assert s(5, 40, 64, 128, (1, 1, 5), [128]) == 1                # GRU (1,1,5) tail at 1/8: 200 workgroups x 2 K-groups, 20 k-steps
+    assert s(5, 20, 32, 256, (1, 3, 3), [128]) == 1                # mask head at 1/16: 100 workgroups x 4 K-groups, 36 k-steps
+    assert s(5, 20, 32, 64, (1, 3, 3), [128]) > 1                  # 25 workgroups: too few waves without slices
+    assert s(5, 20, 32, 768, (1, 1, 1), [384]) > 1                 # 300 workgroups: more than one round unsliced
     n = s(5, 20, 32, 192, (1, 3, 3), [320])                        # final_conv at 1/16: 30 row-steps per temporal tap
     assert n in (2, 3, 5, 6) and 30 % n == 0
     d = _desc(5, 20, 32, 256, (1, 1, 15), [128, 384])
