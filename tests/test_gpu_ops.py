@@ -295,6 +295,33 @@ def test_conv_gemm5_vs_torch(lib, name, T, H, W, segs, cout, k3, nbt):
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
+@pytest.mark.parametrize("cout", [128, 256, 190])
+def test_conv_gemm5_epilogue_classes(lib, cout):
+    """conv_gemm5 instantiates its row loop per descriptor class (conv_epilogue.h): plain store (no load in the loop), hoisted share
+    (operands of four rows fetched before they are stored), aux state (RESID / RH), GRU, and the run-time-checked rest -- and with 128
+    couts both K-groups run it on swapped halves of the tile.  Every class against torch, at 128 / 256 / ragged 190 couts."""
+    L = lib
+    T, H, W, k3 = 2, 12, 64, (1, 3, 3)
+    P = T * H * W
+    xs = [hash_normal((P, 64), 700), hash_normal((P, 32), 701)]
+    wt = hash_normal((cout, 96, *k3), 702) / math.sqrt(96 * 9)
+    bs = hash_normal((cout,), 703) * 0.1
+    lin = _ref_conv(xs, wt, bs, k3, T, H, W)
+    aux, z, pre = hash_normal((P, cout), 704), torch.sigmoid(hash_normal((P, cout), 705)), hash_normal((P, cout), 706)
+    run = lambda **k: _run_conv(L, xs, wt, bs, k3, T, H, W, version=5, **k)
+    tol = lambda ref: 5e-5 * max(1.0, ref.abs().max().item())
+    for act, f in ((L.ACT_NONE, lambda t: t), (L.ACT_RELU, F.relu), (L.ACT_GELU, F.gelu), (L.ACT_SIGMOID, torch.sigmoid), (L.ACT_TANH, torch.tanh)):
+        assert maxdiff(run(act=act), f(lin)) < tol(f(lin)), ("plain", act)                                     # EPI_CLS_PLAIN
+    if cout % 4 == 0:                                        # (pre_f32 is for couts in multiples of 4: the library refuses it otherwise)
+        assert maxdiff(run(act=L.ACT_GELU, pre=pre), F.gelu(lin + pre)) < tol(lin), "pre"                       # EPI_CLS_PRE
+        assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z, pre=pre), (1 - z) * aux + z * torch.tanh(lin + pre)) < tol(lin), "gru + pre"
+        assert maxdiff(run(kind=L.EPI_RH, aux=aux, pre=pre), torch.sigmoid(lin + pre) * aux) < tol(lin), "rh + pre"   # EPI_CLS_ANY
+    assert maxdiff(run(kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + lin)) < tol(lin), "resid"       # EPI_CLS_AUX
+    assert maxdiff(run(kind=L.EPI_RH, aux=aux), torch.sigmoid(lin) * aux) < tol(lin), "rh"
+    assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < tol(lin), "gru"    # EPI_CLS_GRU
+    assert torch.equal(run(kind=L.EPI_GRU, aux=aux, z=z), run(kind=L.EPI_GRU, aux=aux, z=z))
+
+
 def test_conv_gemm5_full_map(lib):
     """The shapes the 1/4 scale of BASELINE config 2 really runs (5 x 80 x 128 pixels) through the library's own tile choice
     (7-block tiles: 240 workgroups): the GRU (1,1,15) conv to 256 couts, a 3x3 conv to 256, and the q-gate conv to 128 couts."""
