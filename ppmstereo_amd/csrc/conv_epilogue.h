@@ -138,12 +138,13 @@ enum {
     EPI_CLS_PRE = 1,       // STORE + pre_f32
     EPI_CLS_AUX = 2,       // RESID / RH without pre_f32: aux_sp
     EPI_CLS_GRU = 3,       // GRU (aux_sp + gate, pre_f32 optional)
-    EPI_CLS_ANY = 4        // everything else (ADDF32, RESID / RH with pre_f32, out_vt): all fields checked at run time
+    EPI_CLS_ANY = 4,       // everything else (ADDF32, out_vt): all fields checked at run time
+    EPI_CLS_AUXPRE = 5     // RESID / RH with pre_f32 (the r gate of the GRU passes with the hoisted input share)
 };
 __device__ __forceinline__ int epilogue_class(const ppms_epilogue& e) {
     if (e.out_vt != nullptr) return EPI_CLS_ANY;
     if (e.kind == PPMS_EPI_STORE) return e.pre_f32 != nullptr ? EPI_CLS_PRE : EPI_CLS_PLAIN;
-    if ((e.kind == PPMS_EPI_RESID || e.kind == PPMS_EPI_RH) && e.pre_f32 == nullptr) return EPI_CLS_AUX;
+    if (e.kind == PPMS_EPI_RESID || e.kind == PPMS_EPI_RH) return e.pre_f32 == nullptr ? EPI_CLS_AUX : EPI_CLS_AUXPRE;
     if (e.kind == PPMS_EPI_GRU) return EPI_CLS_GRU;
     return EPI_CLS_ANY;
 }
@@ -156,12 +157,13 @@ struct row8_aux {
 template <int CLS>
 __device__ __forceinline__ void row8_fetch(const ppms_epilogue& e, int64_t pix, int cl, row8_aux& a) {
     if (CLS == EPI_CLS_PLAIN || e.n_valid - cl < 8) return;       // (ragged tail rows load inside row8_finish)
-    if ((CLS == EPI_CLS_PRE || CLS == EPI_CLS_GRU || CLS == EPI_CLS_ANY) && e.pre_f32 != nullptr) {
+    if ((CLS == EPI_CLS_PRE || CLS == EPI_CLS_GRU || CLS == EPI_CLS_ANY || CLS == EPI_CLS_AUXPRE) && e.pre_f32 != nullptr) {
         const float* pp = e.pre_f32 + pix * e.pre_f32_ld + cl;
         a.p0 = gld<f32x4>(pp), a.p1 = gld<f32x4>(pp + 4);
     }
     const int kind = e.kind;
-    if (CLS == EPI_CLS_AUX || CLS == EPI_CLS_GRU || (CLS == EPI_CLS_ANY && (kind == PPMS_EPI_RESID || kind == PPMS_EPI_RH || kind == PPMS_EPI_GRU))) {
+    if (CLS == EPI_CLS_AUX || CLS == EPI_CLS_AUXPRE || CLS == EPI_CLS_GRU ||
+        (CLS == EPI_CLS_ANY && (kind == PPMS_EPI_RESID || kind == PPMS_EPI_RH || kind == PPMS_EPI_GRU))) {
         a.h8 = gld<bf16x8>((const bf16_t*)e.aux_sp.hi + pix * e.aux_sp.ld + cl);
         a.l8 = gld<bf16x8>((const bf16_t*)e.aux_sp.lo + pix * e.aux_sp.ld + cl);
     }
@@ -192,7 +194,7 @@ __device__ __forceinline__ void row8_finish(const ppms_epilogue& e, const float*
         v[j] = vin[j];
         ax[j] = 0.0f;
     }
-    if ((CLS == EPI_CLS_PRE || CLS == EPI_CLS_GRU || CLS == EPI_CLS_ANY) && e.pre_f32 != nullptr) {
+    if ((CLS == EPI_CLS_PRE || CLS == EPI_CLS_GRU || CLS == EPI_CLS_ANY || CLS == EPI_CLS_AUXPRE) && e.pre_f32 != nullptr) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             v[j] += a.p0[j];

@@ -403,6 +403,8 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
     using I2 = std::integral_constant<int, EPI_CLS_AUX>;
     using I3 = std::integral_constant<int, EPI_CLS_GRU>;
     using I4 = std::integral_constant<int, EPI_CLS_ANY>;
+    using I5 = std::integral_constant<int, EPI_CLS_AUXPRE>;
+    using G2 = std::integral_constant<int, 2>;
     using G1 = std::integral_constant<int, 1>;
     using G4 = std::integral_constant<int, 4>;
     const int cls = g.nslice > 1 ? (int)EPI_CLS_PLAIN : epilogue_class(e);       // (a K-sliced launch stores raw partials: no operand to load)
@@ -410,6 +412,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
     else if (cls == EPI_CLS_PRE) rows(I1{}, G4{});
     else if (cls == EPI_CLS_AUX) rows(I2{}, G4{});
     else if (cls == EPI_CLS_GRU) rows(I3{}, G1{});
+    else if (cls == EPI_CLS_AUXPRE) rows(I5{}, G2{});
     else rows(I4{}, G1{});
     CONV2_STAMP(5)
 }

@@ -436,6 +436,8 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
     using I2 = std::integral_constant<int, EPI_CLS_AUX>;
     using I3 = std::integral_constant<int, EPI_CLS_GRU>;
     using I4 = std::integral_constant<int, EPI_CLS_ANY>;
+    using I5 = std::integral_constant<int, EPI_CLS_AUXPRE>;
+    using G2 = std::integral_constant<int, 2>;
     using G1 = std::integral_constant<int, 1>;
     using G4 = std::integral_constant<int, 4>;
     const int cls = g.nslice > 1 ? (int)EPI_CLS_PLAIN : epilogue_class(e);
@@ -443,6 +445,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
     else if (cls == EPI_CLS_PRE) rows(I1{}, G4{});
     else if (cls == EPI_CLS_AUX) rows(I2{}, G4{});
     else if (cls == EPI_CLS_GRU) rows(I3{}, G1{});        // (groups of two rows were measured: 24 more live registers spill, 30.7 -> 38 us)
+    else if (cls == EPI_CLS_AUXPRE) rows(I5{}, G2{});
     else rows(I4{}, G1{});
     CONV5_STAMP(4)
 }
