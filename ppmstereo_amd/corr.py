@@ -45,10 +45,17 @@ class CorrBlock1D:
         self.num_levels, self.radius = num_levels, radius
         B, _, H, W = fmap1.shape
         self.shape = (B, H, W)
-        self.coords = coords_grid(B, H, W, fmap1.device)
-        self.levels = build_pyramid(fmap1, fmap2)
+        self._device, self._coords = fmap1.device, None      # .coords is built on first access: the kernels take x from the pixel index,
+        self.levels = build_pyramid(fmap1, fmap2)             # and a grid per CorrBlock1D is 5 small launches per scale of every clip
         # reference attribute: list of (B*H*W1, 1, 1, W2_l), num_levels + 1 entries (the last is never read)
         self.corr_pyramid = [lv.view(lv.shape[0], 1, 1, lv.shape[1]) for lv in self.levels]
+
+    @property
+    def coords(self) -> torch.Tensor:
+        """reference attribute (corr.py:62): (B, 2, H, W) pixel coordinates"""
+        if self._coords is None:
+            self._coords = coords_grid(*self.shape, self._device)
+        return self._coords
 
     def __call__(self, flow: torch.Tensor) -> torch.Tensor:
         B, H, W = self.shape
