@@ -117,6 +117,43 @@ def test_cascade():
     g.check("disparity", disp[None], 5e-4), g.check("uncertainty", unc[None], 5e-5)
 
 
+def it10_cascade_inputs():
+    """Inputs of the cascade_it10 fixture (tools/gen_golden.py:it10_fixtures): T=5, 64x256, shifted right features."""
+    T, H, Wd = 5, 64, 256
+    fm1 = hash_normal((T, 256, H // 4, Wd // 4), 171)
+    fm2 = 0.8 * torch.roll(fm1, shifts=-3, dims=3) + 0.6 * hash_normal((T, 256, H // 4, Wd // 4), 172)
+    ctx = [hash_normal((T, 256, H // s, Wd // s), 173 + i) for i, s in enumerate((4, 8, 16))]
+    return T, O.pre_loop_glue(fm1, fm2, *ctx)
+
+
+def test_cascade_at_north_star_iteration_counts():
+    """iters = 10 -> 5 / 5 / 10 iterations (ppmstereo.py:482,708,744,777), every one of the 20 predictions of the reference's
+    PPMStereo.forward(test_mode=False).  Measured: the oracle's EPE against the reference grows from 1.5e-5 px (first prediction) to
+    9.6e-5 px (20th), max 4.5e-4 px -- bf16 rounding flips of the attention operands on ~1e-7 differences between two fp32 CPU
+    evaluation orders, amplified by the recurrence; 10x inside the 1e-3 EPE budget."""
+    g = Golden("cascade_it10")
+    T, feats = it10_cascade_inputs()
+    preds, uncs = [], []
+    disp, unc = O.cascade(W, feats, 10, T, preds, uncs)
+    assert len(preds) == 20 and int(g.raw("n_attn_calls")) == T * 20
+    g.check("predictions", torch.stack(preds), 8e-4), g.check("uncertainties", torch.stack(uncs), 1e-4)
+    g.check("disparity", disp[None], 8e-4), g.check("uncertainty", unc[None], 1e-4)
+    k, step = g.keys["disparity"]
+    epe = float(abs(disp[None].numpy().reshape(-1)[::step] - g.raw("disparity")).mean())
+    assert epe < 2e-4, f"EPE of the oracle against the reference at iters=10: {epe}"
+
+
+def test_forward_update_block_ten_iterations():
+    g = Golden("fub04_it10")
+    T, h, w, iters = 5, 16, 64, 10
+    d = synth_scale_inputs(T, h, w, seed=1052, with_mhs=True)
+    preds, uncs = [], []
+    fo, net, mhs = O.forward_update_block(W["update_block04"], W["att.2"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"], d["inp"],
+                                          d["mhs"], iters, 1, T, False, preds, uncs)
+    g.check("flow_out", fo, 4e-4), g.check("net", net, 6e-4), g.check("mhs", mhs, 5e-4)
+    g.check("preds", torch.stack(preds), 4e-4), g.check("uncs", torch.stack(uncs), 5e-5)
+
+
 def test_forward_batch_test_stitching():
     """PPMStereo.forward_batch_test (ppmstereo.py:238-320) on 25 frames of 60x250 with kernel_size 20: InputPadder to
     64x256, windows [0,20) [10,25) ([20,25) computed and dropped by the reference), kept frames 0-14 / 15-24."""

@@ -134,8 +134,43 @@ def bare_model(attention_type=None, use_convex_3d=False):
     return m.eval()
 
 
+def it10_fixtures(m):
+    """North-star iteration counts (ppmstereo.py:482: 5 / 5 / 10 iterations at iters=10): the reference's own PPMStereo.forward with stub
+    encoders on a T=5, 64x256 clip, EVERY prediction of the cascade kept (test_mode=False returns the stacked list, :795-810), and ten
+    iterations of forward_update_block at one scale.  The right features are the left ones shifted along the epipolar line + noise, so
+    the correlation volume has real peaks (as ppmstereo_amd.synth)."""
+    T, H, W = 5, 64, 256
+    fm1 = hash_normal((T, 256, H // 4, W // 4), 171)
+    fm2 = 0.8 * torch.roll(fm1, shifts=-3, dims=3) + 0.6 * hash_normal((T, 256, H // 4, W // 4), 172)
+    ctx = [hash_normal((T, 256, H // s, W // s), 173 + i) for i, s in enumerate((4, 8, 16))]
+
+    class FNet(nn.Module):
+        def forward(self, x):
+            return fm1, fm2
+
+    class CNet(nn.Module):
+        def forward(self, x):
+            return ctx[0], ctx[1], ctx[2]
+
+    m.fnet, m.cnet = FNet(), CNet()
+    img = torch.zeros(1, T, 3, H, W)
+    ATTN_LOG.clear()
+    preds, uncs = m.forward(img, img, iters=10, test_mode=False)          # (20, 1, T, 1, H, W)
+    assert preds.shape[0] == 20 and len(ATTN_LOG) == T * 20
+    save("cascade_it10", predictions=preds[:, 0], uncertainties=uncs[:, 0], disparity=preds[-1], uncertainty=uncs[-1], n_attn_calls=len(ATTN_LOG))
+    T, h, w, iters = 5, 16, 64, 10
+    d = synth_scale_inputs(T, h, w, seed=1052, with_mhs=True)
+    cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
+    preds, uncs = [], []
+    fo, net, mhs = m.forward_update_block(None, m.update_block04, cb, d["flow"], d["net"], d["inp"], d["mhs"], m.att[2], preds, uncs, iters, 1, T)
+    save("fub04_it10", flow_out=fo, net=net, mhs=mhs, preds=torch.stack(preds), uncs=torch.stack(uncs))
+
+
 @torch.no_grad()
 def main():
+    if "it10" in sys.argv[1:]:                   # only the fixtures of round 3 (the full run regenerates them too)
+        it10_fixtures(bare_model())
+        return
     # ---- G1: CorrBlock1D build + lookup (corr.py:55-104) -------------------------------------
     d = synth_scale_inputs(2, 4, 32, seed=11)
     cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
@@ -320,6 +355,9 @@ def main():
         img = hash_uniform((n, 3, hh, ww), 900 + hh)
         c4, c8, c16 = cnet(img)
         save(name, c4=c4, c8=c8, c16=c16)
+
+    # ---- G13: iters = 10 (5 / 5 / 10 iterations), the north-star iteration counts ----------------
+    it10_fixtures(bare_model())
 
     # ---- G7: T == 1 -> NaN known answer (SURVEY.md hazard 1) ------------------------------------
     d = synth_scale_inputs(1, 8, 32, seed=81)
