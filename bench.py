@@ -83,8 +83,9 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets around the attention / conv3 kernels")
-    ap.add_argument("--with-encoders", action="store_true", help="also time fnet + cnet + SST block (the producers of the path's inputs, once per "
-                    "clip, outside `value`) and report them under `encoders`")
+    ap.add_argument("--no-encoders", action="store_true", help="skip the encoder / whole-call timings (fnet + cnet + SST block and "
+                    "PPMStereo.forward_batch_test on a host video: once per clip, outside `value`, reported under `encoders` / `whole_call_ms`)")
+    ap.add_argument("--with-encoders", action="store_true", help=argparse.SUPPRESS)        # (the default since round 3)
     ap.add_argument("--replicas", action="store_true", help="N > 1: force clip replicas even when T divides over the ranks")
     args = ap.parse_args()
 
@@ -121,12 +122,13 @@ def main():
     Tl = T // world if sharded else T
     engs = [(model.update_block16.engine(Tl, H // 16, W // 16, dev, shard), iters // 2), (model.update_block08.engine(Tl, H // 8, W // 8, dev, shard), iters // 2),
             (model.update_block04.engine(Tl, H // 4, W // 4, dev, shard), iters)]
-    conv3 = {}
+    conv3, family = {}, {}
     if not args.no_kernel_timing:
         for (e, n_it), sc in zip(engs, (16, 8, 4)):
             e.enable_attn_timing(args.steps * n_it)
-            for name, op in e.conv_ops().items():
-                if op.version in (3, 4, 5):
+            for name, op in e.conv_family_ops().items():          # every convolution-family launch of every scale (roofline_3, timed in
+                family[(sc, name)] = op                            # ONE extra step behind the timed region: ~900 event pairs cost ~5 ms)
+                if getattr(op, "version", 0) in (3, 5):            # the large-map kernels (roofline / roofline_2): inside the timed region
                     op.events = []
                     conv3[(sc, name)] = op
 
@@ -147,17 +149,31 @@ def main():
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
     step_ms = [a.elapsed_time(b) for a, b in step_ev]
+    attn_ms = [e.attn_times_ms() for e, _ in engs] if not args.no_kernel_timing else []
+    fam_events = {}
+    if family:                                        # one extra step (outside `value`) with events around EVERY convolution-family launch
+        saved = {k: op.events for k, op in family.items()}
+        for op in family.values():
+            op.events = []
+        for e, _ in engs:
+            e._ev = None                              # (the attention events of the timed region stay as they are)
+        _engine.KERNEL_TIMING["on"] = True
+        step()
+        _engine.KERNEL_TIMING["on"] = False
+        torch.cuda.synchronize()
+        for k, op in family.items():
+            fam_events[k] = [a.elapsed_time(b) for a, b in op.events]
+            op.events = saved[k]
 
     n_sampled = len(range(0, args.steps, TIMING_EVERY))                # steps whose launches carried events
     px = T * H * W
     value = (1 if sharded else world) * args.steps * px / elapsed
     ksel = min(5, T)
-    roofs = []
+    roofs, family_roof = [], None
     if not args.no_kernel_timing:
         # ---- memory attention: algorithmic FLOPs of one launch = 4 * n * (ksel * n) * 128 * (clips of this rank)
         tot_flop, tot_ms, n_launch, per_scale = 0.0, 0.0, 0, {}
-        for (e, n_it), sc in zip(engs, (16, 8, 4)):
-            ms = e.attn_times_ms()
+        for (e, n_it), sc, ms in zip(engs, (16, 8, 4), attn_ms):
             fl = 4.0 * e.n * (ksel * e.n) * 128 * Tl
             tot_flop += fl * len(ms)
             tot_ms += sum(ms)
@@ -204,6 +220,25 @@ def main():
                                   launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / n_sampled, 3),
                                   flop_per_launch=c_flop / c_n, per_op=per_op))
         roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first
+        # ---- the whole convolution family of a step, all three scales: every implicit-GEMM launch (large-map and small-map kernels, the
+        # slice-reduce halves, the once-per-scale hoisted shares and q/k projections), the fused per-pixel chains, the depthwise 7x7 -- against
+        # the reference's algorithmic conv FLOPs (14.128 MFLOP per pixel and iteration at 1/4 and 1/8, 17.75 at 1/16)
+        if family:
+            f_ms, f_n, by_scale = 0.0, 0, {}
+            for (sc, name), op in family.items():
+                ms = fam_events.get((sc, name), [])
+                f_ms += sum(ms)
+                f_n += len(ms)
+                by_scale[f"1/{sc}"] = by_scale.get(f"1/{sc}", 0.0) + sum(ms)
+            conv_flop = sum(n_it * Tl * c * e.n for (e, n_it), c in zip(engs, (17.75e6, 14.128e6, 14.128e6)))
+            fach = conv_flop / (f_ms * 1e-3) / 1e12
+            family_roof = dict(bound="mfma", kernel="every convolution-family launch of a step at the three scales (conv5 / conv3 / conv2 kernels incl. K-slice reduces, "
+                                                    "hoisted shares, q/k projection, fused per-pixel chains, depthwise 7x7), event-bracketed in ONE extra step run behind the timed region; algorithmic "
+                                                    "FLOPs = the reference's conv FLOPs of the clip (SURVEY 8d: 8.42 TFLOP at config 2), not the FLOPs executed (the inp "
+                                                    "hoist removes ~13 %); launches of the two streams overlap, so the event sum is an upper bound of the busy time",
+                               achieved=round(fach, 2), peak=round(CONV_BOUND_TFLOPS, 1), unit="TFLOP/s", frac=round(fach / CONV_BOUND_TFLOPS, 4),
+                               traffic=None, launches_per_step=f_n, total_ms_per_step=round(f_ms, 3),
+                               ms_per_step_by_scale={k: round(v, 3) for k, v in by_scale.items()}, algorithmic_tflop_per_step=round(conv_flop / 1e12, 3))
     # the same clip with test_mode=False (the reference's training-style return): every iteration runs the mask head, the convex
     # upsampling and the full-resolution resize of its prediction.  Reported beside the headline number, never as `value`.
     n_all = 3
@@ -218,7 +253,7 @@ def main():
         D.barrier()
         all_ms = D.max_over_ranks(time.perf_counter() - t_all) / n_all * 1e3
     encoders = None
-    if args.with_encoders and rank == 0 and not sharded:
+    if not args.no_encoders and rank == 0 and not sharded and (T, H, W) == (5, 320, 512):
         # SURVEY 8 rows f3-f5 on the same clip geometry: fnet on the 2T images, cnet on the T left images, SST on the 1/16 features
         from ppmstereo_amd.cnet import Feature
         from ppmstereo_amd.encoder import BasicEncoder
@@ -277,7 +312,9 @@ def main():
                                         "of each scale; ms_per_step_all_predictions times the same clip with every iteration's prediction produced)",
                                 T=T, H=H, W=W, iters=iters, parallelism=par),
                    ms_per_step_all_predictions=None if all_ms is None else round(all_ms, 3),
-                   roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None, cpu_baseline=cpu,
+                   roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None,
+                   roofline_3=family_roof if (not args.no_kernel_timing and family) else None, cpu_baseline=cpu,
+                   whole_call_ms=None if not encoders else encoders["whole_call_ms"],
                    library=os.path.relpath(L.lib_path(), ROOT), **({"encoders": encoders} if encoders else {}))
         print(json.dumps(out))
     if world > 1:

@@ -129,17 +129,11 @@ int ppms_conv_gemm2_ysweep(const ppms_conv* desc, const ppms_conv* dev_desc, int
  * stay the true extents. */
 int ppms_conv_gemm3_applicable(const ppms_conv* desc);
 int ppms_conv_gemm3(const ppms_conv* desc, const ppms_conv* dev_desc, void* stream);
-/* Barrier-free k-loop variant for the same convolutions (conv_gemm4.hip): the weights are packed in MFMA-fragment order
- * (ppmstereo_amd/packing.py pack_conv4, sweep-ordered like ppms_conv_gemm3's packs) and go from L2 straight to registers; the
- * activation window holds 16 channels and is double buffered, so the loop synchronises once per window instead of once per
- * k-step.  128 couts x 256 (or 128) pixels per workgroup.  Applicable: M % 128 == 0, kw > 1 or kh > 1 (>= 3 swept taps),
- * segments with c % 16 == 0, a halo'd window of <= 384 pixel rows, >= 256 workgroups. */
-int ppms_conv_gemm4_applicable(const ppms_conv* desc);
-/* tile_px: pixels per workgroup, 0 = let the library choose (256 when that still gives >= 1.5 workgroups per CU, else 128) */
-int ppms_conv_gemm4(const ppms_conv* desc, const ppms_conv* dev_desc, int tile_px, void* stream);
-/* The same k-loop with one 8-wave workgroup per CU that owns ALL couts (M == 256, or M == 128 with the K loop split between two
- * wave groups) of a tile of nbt = 7 or 8 blocks of 32 pixels, split 4 + 3 (4 + 4) so that every SIMD carries the same load
- * (conv_gemm5.hip): 51 200 pixels = 240 tiles of 224 on 256 CUs.  Weights: pack_conv4.  nbt = 0: the library picks. */
+/* Barrier-free k-loop (conv_gemm5.hip): the weights are packed in MFMA-fragment order (ppmstereo_amd/packing.py pack_conv4,
+ * sweep-ordered like ppms_conv_gemm3's packs) and go from L2 straight to registers; the activation window holds 16 channels and is
+ * double buffered, so the loop synchronises once per window instead of once per k-step.  One 8-wave workgroup per CU owns ALL
+ * couts (M == 256, or M == 128 with the K loop split between two wave groups) of a tile of nbt = 7 or 8 blocks of 32 pixels, split
+ * 4 + 3 (4 + 4) so that every SIMD carries the same load: 51 200 pixels = 240 tiles of 224 on 256 CUs.  nbt = 0: the library picks. */
 int ppms_conv_gemm5_applicable(const ppms_conv* desc);
 int ppms_conv_gemm5(const ppms_conv* desc, const ppms_conv* dev_desc, int nbt, void* stream);
 /* K-sliced form of the same kernel for maps with fewer tiles than CUs (the 1/8 and 1/16 scales): nslice workgroups share each

@@ -25,7 +25,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppms.so")
 STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
-SOURCES = ["corr.hip", "conv_gemm2.hip", "conv_gemm3.hip", "conv_gemm4.hip", "conv_gemm5.hip", "small_ops.hip", "encoder_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
+SOURCES = ["corr.hip", "conv_gemm2.hip", "conv_gemm3.hip", "conv_gemm5.hip", "small_ops.hip", "encoder_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
 HEADERS = ["common.h", "conv_epilogue.h", "conv5_asm.h", "attn64_asm.h", os.path.join("..", "..", "include", "ppms.h")]
 # Packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) are disabled (NO_PK).  Measured on MI355X: such an instruction
 # with op_sel:[0,1] (low result = src0.lo op src1.hi -- the compiler picks that form freely, e.g. in the bilinear resize kernel) reads
@@ -34,7 +34,7 @@ HEADERS = ["common.h", "conv_epilogue.h", "conv5_asm.h", "attn64_asm.h", os.path
 # tools/check_no_packed_fp32.py (tests/test_host_logic.py); DESIGN.md section 5.  Sources listed in PACKED_FP32_SOURCES keep the packed forms.
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
-EXTRA = [x for x in os.environ.get("PPMS_BUILD_DEFINES", "").split() if x]        # build-time A/B only, e.g. "-DPPMS_CONV4_PRIO=2"
+EXTRA = [x for x in os.environ.get("PPMS_BUILD_DEFINES", "").split() if x]        # build-time A/B only, e.g. "-DPPMS_CONV5_TIMING"
 PACKED_FP32_SOURCES: tuple = tuple(x for x in os.environ.get("PPMS_BUILD_PACKED_FP32", "").split(",") if x)   # build-time A/B only
 FLAGS = COMMON + NO_PK + EXTRA
 

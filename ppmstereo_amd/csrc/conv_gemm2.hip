@@ -572,7 +572,8 @@ static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hi
     PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15, "conv_gemm2: kernel extents must be odd, kw <= 15");
     PPMS_REQUIRE(d->M > 0 && d->M % 64 == 0 && d->m_split % 64 == 0, "conv_gemm2: M=%d / m_split=%d not multiples of 64", d->M, d->m_split);
     PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm2: weights/bias missing");
-    PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 31) / 512, "conv_gemm2: volume too large for 32-bit pixel offsets");
+    // pixel INDICES are 32-bit inside the kernel (slot offsets, (dt, dy) shifts of up to kt / 2 frames); every byte offset is formed in 64 bits
+    PPMS_REQUIRE((int64_t)(d->T + 2 * d->t_halo + d->kt) * d->H * d->W < (1ll << 30), "conv_gemm2: volume too large for 32-bit pixel indices");
     int nchunk = 0;
     for (int s = 0; s < d->nseg; ++s) {
         PPMS_REQUIRE(d->seg[s].hi && d->seg[s].lo && d->seg[s].c > 0 && d->seg[s].c % BK == 0 && d->seg[s].ld % 8 == 0,

@@ -299,6 +299,7 @@ extern "C" int ppms_conv_gemm3_applicable(const ppms_conv* d) {
         if (!fits) return 0;
     }
     const int64_t P = (int64_t)d->T * d->H * d->W;
+    if (P >= (1ll << 31) / 512) return 0;                    // 32-bit byte offsets inside the kernel (ppms_conv_gemm3 checks the same)
     if (P / 256 * (d->M / 128) < 384) return 0;              // fewer than ~1.5 workgroups per CU: conv_gemm2's smaller tiles fill the chip better
     return 1;
 }

@@ -519,8 +519,12 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = 
 
 // returns 1 when this kernel serves the convolution: M == 256 or 128 (all couts in one workgroup), a spatial sweep of >= 3 taps,
 // 16-channel-aligned segments, a halo'd window that fits, and at least ~a workgroup per CU
+// the packed window slots hold a pixel offset in 22 bits and a row index in 10 (conv5_launch checks the same)
+static bool conv5_volume_fits(const ppms_conv* d) { return (int64_t)d->T * d->H * d->W < (1ll << 22) && d->H < 480; }
+
 extern "C" int ppms_conv_gemm5_applicable(const ppms_conv* d) {
     if (d == nullptr || (d->M != 256 && d->M != 128) || d->m_split % 64 != 0 || d->nseg < 1 || d->nseg > 2) return 0;
+    if (!conv5_volume_fits(d)) return 0;
     for (int s = 0; s < d->nseg; ++s)
         if (d->seg[s].c <= 0 || d->seg[s].c % 16 != 0) return 0;
     Geo5 g;
@@ -545,6 +549,7 @@ static int min_windows5(const ppms_conv* d, const Geo5& g) {
 extern "C" int ppms_conv_gemm5_slices(const ppms_conv* d) {
     if (d == nullptr || (d->M != 256 && d->M != 128) || d->m_split % 64 != 0 || d->nseg < 1 || d->nseg > 2) return 0;
     if (d->kw == 1 && d->kh == 1) return 0;
+    if (!conv5_volume_fits(d)) return 0;
     if (d->epi[0].out_vt != nullptr || (d->m_split < d->M && d->epi[1].out_vt != nullptr)) return 0;   // V^T is written from the accumulators
     for (int s = 0; s < d->nseg; ++s)
         if (d->seg[s].c <= 0 || d->seg[s].c % 16 != 0) return 0;
@@ -590,7 +595,7 @@ static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, 
     PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15 && d->kh <= 15, "conv_gemm5: odd kernel extents <= 15");
     PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm5: weights/bias missing");
     PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm5: t_halo=%d", d->t_halo);
-    PPMS_REQUIRE((int64_t)d->T * d->H * d->W < (1ll << 22) && d->H < 480, "conv_gemm5: volume too large for the packed window slots (< 2^22 pixels, H < 480)");
+    PPMS_REQUIRE(conv5_volume_fits(d), "conv_gemm5: volume too large for the packed window slots (< 2^22 pixels, H < 480)");
     for (int s = 0; s < d->nseg; ++s) {
         PPMS_REQUIRE(d->seg[s].hi && d->seg[s].lo && d->seg[s].c > 0 && d->seg[s].c % 16 == 0 && d->seg[s].ld % 8 == 0,
                      "conv_gemm5: segment %d needs hi/lo planes, c %% 16 == 0 and ld %% 8 == 0", s);

@@ -27,10 +27,16 @@ Two levels of parallelism:
    update_block16 TimeAttnBlock          every iteration (1/16)  all-gather of x = [inp, mf, mfg], f*n*384 (640 pixels per frame)
    ====================================  ======================  ==============================================================
 
-   Contiguous blocks make every halo a nearest-neighbour exchange (one xGMI link each way); the all-gathers are direct
-   (every rank pushes its block to all peers: xGMI is point to point, a ring would be bound by one ~153 GB/s link).  Sizes at
-   320x512, 1/4 scale, 5 frames per GPU: K 13 MB per rank once per scale, V 6.6 MB per rank and iteration, halos 2 x 15.7 MB
-   ([h | x], split-bf16 = 4 B per value) + 2 x 5.2 MB (r*h) + small ones per iteration.
+   Contiguous blocks make every halo a nearest-neighbour exchange (one xGMI link each way).  The per-iteration all-gather is
+   DIRECT (``gather_many``): one grouped batch of point-to-point operations in which every rank sends its block to each of the
+   other ranks and receives theirs straight into place -- xGMI is a full mesh of point-to-point links, so the 7 transfers of a rank
+   travel on 7 different links at once, whereas a ring would be bound by one ~153 GB/s link; one group also carries several tensors
+   (the values V and the frame confidences share one exchange).  The once-per-scale gathers use the library collective
+   (``all_gather``: RCCL picks the algorithm).  Several halo'd tensors likewise share ONE batch (``halo_many``), and an exchange can
+   be left in flight (``async_op``) while the compute stream goes on: RCCL runs it on its own stream, ``wait()`` makes the compute
+   stream wait for it right where the data is read.  Sizes at 320x512, 1/4 scale, 5 frames per GPU: K 13 MB per rank once per
+   scale, V 6.6 MB per rank and iteration, halos 2 x 15.7 MB ([h | x], split-bf16 = 4 B per value) + 2 x 5.2 MB (r*h) + small ones
+   per iteration.  Per-iteration schedule and its latency budget: DESIGN.md section 6.
 """
 from __future__ import annotations
 
@@ -175,19 +181,64 @@ class FrameShard:
         work = dist.all_gather_into_tensor(out, local, group=self.group, async_op=async_op)
         return out, (work if async_op else _Done())
 
+    def gather_many(self, pairs, async_op: bool = False):
+        """Direct all-gather of SEVERAL tensors in one grouped exchange.  pairs: [(local, out)], out = the blocks of all ranks along
+        dimension 0 in rank order (out[rank * len(local):][:len(local)] is written with a local copy).  One batch_isend_irecv: this
+        rank's block of every tensor goes to each peer, the peers' blocks are received straight into their place in ``out``
+        (contiguous slices), i.e. world - 1 sends + world - 1 receives per tensor in ONE group.  Returns a handle; with
+        async_op the caller waits on it right before the gathered data is read."""
+        if self.world == 1:
+            for local, out in pairs:
+                out.copy_(local)
+            return _Done()
+        ops, finish = [], []
+        for local, out in pairs:
+            local = local.contiguous()
+            m = local.shape[0]
+            assert out.shape[0] == self.world * m and out.is_contiguous(), "gather_many: out must hold world blocks along dimension 0"
+            stage = self._stage(local)
+            src = local.cpu() if stage else local
+            for peer in range(self.world):
+                dst = out[peer * m:(peer + 1) * m]
+                if peer == self.rank:
+                    if dst.data_ptr() != local.data_ptr():
+                        dst.copy_(local)
+                    continue
+                ops.append(dist.P2POp(dist.isend, src, peer, group=self.group))
+                if stage:
+                    tmp = torch.empty(dst.shape, dtype=dst.dtype)
+                    ops.append(dist.P2POp(dist.irecv, tmp, peer, group=self.group))
+                    finish.append((dst, tmp))
+                else:
+                    ops.append(dist.P2POp(dist.irecv, dst, peer, group=self.group))
+        works = dist.batch_isend_irecv(ops)
+
+        def done():
+            for w in works:
+                w.wait()
+            for dst, tmp in finish:
+                dst.copy_(tmp)
+
+        if async_op and not finish:
+            return _Staged(done)
+        done()
+        return _Done()
+
     # ------------------------------------------------------------------ halo exchange with the two neighbours
     def halo(self, buf: torch.Tensor, k: int, async_op: bool = False):
-        """buf: (..., HALO + f + HALO frames, ...) viewed as buf[frame_dim]; here the frame axis is dimension 0 of ``buf`` after
-        the caller's reshape: buf[HALO - k:HALO] receives the left neighbour's last k frames, buf[HALO + f:HALO + f + k] the
-        right neighbour's first k frames; rank 0's left and the last rank's right halo are left untouched (zeros = the
-        convolution's zero padding at the window's ends).  Returns a handle (wait() before the halo is read)."""
+        return self.halo_many([(buf, k)], async_op)
+
+    def halo_many(self, bufs, async_op: bool = False):
+        """bufs: [(buf, k)], every buf (HALO + f + HALO frames, ...) with the frame axis as dimension 0: buf[HALO - k:HALO] receives
+        the left neighbour's last k frames, buf[HALO + f:HALO + f + k] the right neighbour's first k frames; rank 0's left and the
+        last rank's right halo are left untouched (zeros = the convolution's zero padding at the window's ends).  All tensors
+        travel in ONE batch of point-to-point operations (<= 4 per tensor).  Returns a handle (wait() before a halo is read)."""
         H, f = self.HALO, self.f
-        assert buf.shape[0] == f + 2 * H and 1 <= k <= H
         if self.world == 1:
             return _Done()
         left, right = self.rank - 1, self.rank + 1
         ops, finish = [], []
-        stage = self._stage(buf)
+        stage = any(self._stage(b) for b, _ in bufs)
 
         def send(src, peer):
             src = src.contiguous()
@@ -205,12 +256,14 @@ class FrameShard:
                 ops.append(dist.P2POp(dist.irecv, tmp, peer, group=self.group))
                 finish.append((dst, tmp))
 
-        if left >= 0:
-            send(buf[H:H + k], left)
-            recv(buf[H - k:H], left)
-        if right < self.world:
-            send(buf[H + f - k:H + f], right)
-            recv(buf[H + f:H + f + k], right)
+        for buf, k in bufs:
+            assert buf.shape[0] == f + 2 * H and 1 <= k <= H
+            if left >= 0:
+                send(buf[H:H + k], left)
+                recv(buf[H - k:H], left)
+            if right < self.world:
+                send(buf[H + f - k:H + f], right)
+                recv(buf[H + f:H + f + k], right)
         if not ops:
             return _Done()
         works = dist.batch_isend_irecv(ops)

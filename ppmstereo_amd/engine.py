@@ -20,7 +20,6 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-import os
 from typing import Dict, List, Optional
 
 import torch
@@ -29,19 +28,20 @@ from . import _lib as L
 from . import packing as _packing
 
 TOP_K = 5
-# tuning switches between HIP code paths of the library (A/B measurements on the GPU box; every setting runs HIP kernels only)
-USE_CONV4 = os.environ.get("PPMS_CONV4", "0") != "0"      # barrier-free k-loop kernel (conv_gemm4.hip): measured equal to conv_gemm3 so far, off
-USE_CONV5 = os.environ.get("PPMS_CONV5", "1") != "0"      # one 8-wave workgroup per CU, 7- / 8-block tiles (conv_gemm5.hip) where it applies
-# conv_gemm5's K-sliced form on the small maps (1/8, 1/16 scales): correct (tests) but measured SLOWER than conv_gemm2's slicing there
-# (1/8-scale iteration 1293 vs 1252 us, 1/16: 1072 vs 1017 us: per-workgroup fixed costs and 5 x the partial-sum traffic), so off
-USE_CONV5_SLICED = os.environ.get("PPMS_CONV5_SLICED", "0") != "0"
-USE_CONV5_GEMM = os.environ.get("PPMS_CONV5_GEMM", "1") != "0"       # its GEMM mode for the convs without a spatial sweep ((5,1,1) GRU pass, 1x1 heads)
-USE_CONV3 = os.environ.get("PPMS_CONV3", "1") != "0"      # large-map kernel (conv_gemm3.hip) where it applies
-USE_PWCHAIN = os.environ.get("PPMS_PWCHAIN", "1") != "0"  # fused per-pixel layer chains of the correlation encoder
-_YS = os.environ.get("PPMS_YSWEEP", "1")                  # conv_gemm2 one-window forms: 0 = off, 1 = y-swept (1, kh, 1) convs (default),
-USE_YSWEEP, USE_WIN2D = _YS != "0", _YS == "2d"            # 2d = also the 2-D window for kh, kw > 1 (measured neutral to slower)
-USE_SLICES = os.environ.get("PPMS_SLICE", "1") != "0"     # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
-HOIST_INP = os.environ.get("PPMS_HOIST", "1") != "0"      # iteration-invariant inp share of the GRU gates computed once per scale
+# Which HIP kernel generation serves a convolution where more than one applies.  These are the measured-best settings (DESIGN.md
+# section 5); tools/ab_switches.py maps PPMS_* environment variables onto this table for A/B runs on the GPU box -- the product itself
+# reads no environment variable.  Every setting runs HIP kernels only.
+TUNING = dict(
+    conv5=True,           # one 8-wave workgroup per CU, 7- / 8-block tiles (conv_gemm5.hip) where it applies
+    conv5_sliced=False,   # its K-sliced form on the 1/8, 1/16 maps: correct (tests) but slower than conv_gemm2's slicing there
+    conv5_gemm=True,      # its GEMM mode for the 256-cout convs without a spatial sweep ((5,1,1) GRU pass, 1x1 heads)
+    conv3=True,           # large-map kernel of round 1 (conv_gemm3.hip) where conv_gemm5 does not apply
+    pwchain=True,         # fused per-pixel layer chains of the correlation encoder
+    ysweep=True,          # conv_gemm2: one y-swept window per (dt, chunk) for (1, kh, 1) convs
+    win2d=False,          # conv_gemm2: 2-D window for kh, kw > 1 (measured neutral to slower)
+    slices=True,          # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
+    hoist=True,           # iteration-invariant inp share of the GRU gates computed once per scale
+)
 
 
 pack_conv = _packing.pack_conv2
@@ -88,7 +88,7 @@ class ConvOp:
         if version == 5 and nslice is not None and nslice > 1:      # conv_gemm5's K-sliced form (same workspace layout as conv_gemm2's)
             self.nslice = int(nslice)
             self.ws = torch.empty(int(L.load().ppms_conv_gemm2_slice_workspace_bytes(C.byref(desc), self.nslice)), dtype=torch.uint8, device=device)
-        if version == 2 and wm_hint == 0 and (nslice is not None or USE_SLICES):
+        if version == 2 and wm_hint == 0 and (nslice is not None or TUNING["slices"]):
             plan = L.load().ppms_conv_gemm2_ysweep_slices if ysweep else L.load().ppms_conv_gemm2_slices
             self.nslice = max(1, int(plan(C.byref(desc)))) if nslice is None else nslice
             if self.nslice > 1:
@@ -118,8 +118,6 @@ class ConvOp:
             L.check(L.load().ppms_conv_gemm5_sliced(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, self.nslice, self.ws.data_ptr(), L.stream_ptr()))
         elif self.version == 5:
             L.check(L.load().ppms_conv_gemm5(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
-        elif self.version == 4:
-            L.check(L.load().ppms_conv_gemm4(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         elif self.ysweep:
             L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
         elif self.nslice > 1:
@@ -148,6 +146,24 @@ def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Opt
     return e
 
 
+class TimedCall:
+    """A small-kernel launch (python callable) that bench.py can bracket with HIP events like a ConvOp."""
+
+    def __init__(self, fn):
+        self.fn, self.events = fn, None
+
+    def __call__(self):
+        ev = self.events if KERNEL_TIMING["on"] else None
+        if ev is not None:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+            self.fn()
+            pair[1].record()
+            ev.append(pair)
+        else:
+            self.fn()
+
+
 class PwChain:
     """One fused per-pixel layer chain launch (pwchain.hip): host parameter block + device copy."""
 
@@ -167,9 +183,17 @@ class PwChain:
             keep += [packed, bias]
         self.pixels, self.keep = pixels, keep
         self.dev = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).clone().to(device)
+        self.events = None
 
     def __call__(self):
+        ev = self.events if KERNEL_TIMING["on"] else None
+        if ev is not None:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
         L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
+        if ev is not None:
+            pair[1].record()
+            ev.append(pair)
 
 
 class PackedBlock:
@@ -179,7 +203,7 @@ class PackedBlock:
         g = lambda k: sd[k].detach().to(device=device, dtype=torch.float32)
         self.w: Dict[str, tuple] = {}
 
-        self.w4: Dict[str, tuple] = {}             # conv_gemm4 packs (MFMA-fragment order, sweep-ordered taps, M padded to 128)
+        self.w4: Dict[str, tuple] = {}             # conv_gemm5 packs (MFMA-fragment order, sweep-ordered taps, M padded to 128)
 
         def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
             self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
@@ -192,9 +216,9 @@ class PackedBlock:
             elif w5.shape[3] > 1:
                 sweep = w5.transpose(3, 4).contiguous()                      # y sweep: kh / kw swapped
             rows = (max(cout_map) + 1) if cout_map is not None else w5.shape[0]
-            if (USE_CONV4 or USE_CONV5) and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
+            if TUNING["conv5"] and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
                 self.w4[name] = _packing.pack_conv4(sweep, bias, segs, seg_pad, cout_map, (rows + 127) // 128 * 128)
-            elif USE_CONV5 and USE_CONV5_GEMM and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith(("_y", "_p")):
+            elif TUNING["conv5"] and TUNING["conv5_gemm"] and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith(("_y", "_p")):
                 # no spatial sweep: conv_gemm5's GEMM mode (windows of 64 channels) when the segments come in such multiples.  Only the
                 # 256-cout convs (GRU pass-T z/r 197 -> 164 us, mask_2d.2 62 -> 46 us at the 1/4 scale): with 128 couts the two K-groups
                 # get 32-channel windows = 2 k-steps per window, too short a DMA lookahead (pass-T q 110 -> 122 us, to_v 44 -> 66 us)
@@ -248,7 +272,7 @@ class PackedBlock:
         # iterations of one scale: its share of every gate pre-activation is computed once per scale ("*_i" packs, with
         # the bias) and added in the epilogue of the per-iteration convs over [h | mf, mfg] ("*_h" packs).  Not for
         # update_block16, whose time / space attention rewrites all of x every iteration.
-        self.hoist = "time_attn.temporal_fc.weight" not in sd and HOIST_INP
+        self.hoist = "time_attn.temporal_fc.weight" not in sd and TUNING["hoist"]
         if self.hoist:
             for name in ("zr1_0", "q1", "zr2", "q2", "zr3", "q3"):
                 if name.startswith("zr"):
@@ -361,7 +385,7 @@ class ScaleEngine:
         self.have_mhs = False
         self.lib = L.load()
         self._ev, self._ev_i = None, 0
-        self._pending = []          # handles of exchanges in flight (waited for right before their data is read)
+        self._xa_halo = None        # handle of x's +-2-frame halo while it is in flight (sharded window)
         # independent branches of an iteration (flow encoder || correlation encoder, r-gate || z-gate, mask head || flow
         # head) run on a second HIP stream, fork/joined with events: they fill each other's launch tails
         self._side = torch.cuda.Stream(device=device)
@@ -369,12 +393,16 @@ class ScaleEngine:
         self._build_descriptors()
 
     # ------------------------------------------------------------------ exchanges of a frame-sharded window (dist.FrameShard)
-    def _halo_sp(self, t: L.SPTensor, k: int):
-        """+-k boundary frames of an SP tensor with the neighbour ranks (both planes)."""
-        if self.shard is not None:
-            fr = self.T + 2 * self.halo
-            for p in (0, 1):
-                self.shard.halo(t.data[p].view(fr, self.n, t.channels), k)
+    def _halo_sp(self, tensors, k: int, async_op: bool = False):
+        """+-k boundary frames of one or several SP tensors with the neighbour ranks: both bf16 planes of every tensor travel in ONE
+        batch of point-to-point operations.  async_op: the exchange stays in flight (RCCL's own stream) and the returned handle is
+        waited for where the halo is read."""
+        if self.shard is None:
+            return None
+        if isinstance(tensors, L.SPTensor):
+            tensors = [tensors]
+        fr = self.T + 2 * self.halo
+        return self.shard.halo_many([(t.data[p].view(fr, self.n, t.channels), k) for t in tensors for p in (0, 1)], async_op)
 
     def _halo_f32(self, full: torch.Tensor, k: int):
         if self.shard is not None:
@@ -403,7 +431,7 @@ class ScaleEngine:
             op = self._try_fragment_kernels(wname, d, m_split, keep)
             if op is not None:
                 return op
-        if USE_CONV3 and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
+        if TUNING["conv3"] and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
             # the large-map kernel wants its k-steps in sweep order: y-swept convs packed with kh / kw swapped ("_y"),
             # 2-D swept ones (kh, kw > 1) with (ky, kx) flattened into x ("_2d"); without such a pack: conv_gemm2
             key = wname + "_2d" if (k3[1] > 1 and k3[2] > 1) else wname + "_y" if (k3[2] == 1 and k3[1] > 1) else wname
@@ -411,19 +439,19 @@ class ScaleEngine:
                 packed3, bias3, _ = self.pk.w[key]
                 d.w, d.bias = packed3.data_ptr(), bias3.data_ptr()
                 return ConvOp(d, [packed3, bias3, *keep], 3, device=self.dev)
-        if USE_YSWEEP and isinstance(wname, str) and k3[1] > 1:
+        if TUNING["ysweep"] and isinstance(wname, str) and k3[1] > 1:
             # kh > 1 on a map the large-map kernel does not take: conv_gemm2 with one window for all taps of a (dt, chunk)
             # (y-swept "_y" pack for kw == 1, 2-D window "_2d" pack otherwise), when the halo'd window fits
             key = wname + ("_y" if k3[2] == 1 else "_2d")
-            if (k3[2] == 1 or USE_WIN2D) and key in self.pk.w and self.lib.ppms_conv_gemm2_ysweep_slices(C.byref(d)) > 0:
+            if (k3[2] == 1 or TUNING["win2d"]) and key in self.pk.w and self.lib.ppms_conv_gemm2_ysweep_slices(C.byref(d)) > 0:
                 packed_y, bias_y, _ = self.pk.w[key]
                 d.w, d.bias = packed_y.data_ptr(), bias_y.data_ptr()
                 return ConvOp(d, [packed_y, bias_y, *keep], 2, ysweep=True, device=self.dev)
         return ConvOp(d, [packed, bias, *keep], version, device=self.dev)
 
     def _try_fragment_kernels(self, wname: str, d: L.Conv, m_split, keep) -> Optional[ConvOp]:
-        """conv_gemm5 / conv_gemm4 (weights in MFMA-fragment order, pack_conv4, couts padded to 128) when one of them serves the conv."""
-        if not (USE_CONV4 or USE_CONV5) or wname not in self.pk.w4:
+        """conv_gemm5 (weights in MFMA-fragment order, pack_conv4, couts padded to 128) when it serves the conv."""
+        if not TUNING["conv5"] or wname not in self.pk.w4:
             return None
         packed4, bias4, meta4 = self.pk.w4[wname]
         d4 = L.Conv.from_buffer_copy(bytes(d))
@@ -431,23 +459,21 @@ class ScaleEngine:
         if m_split is None:
             d4.m_split = meta4["M"]
         real = d4.epi[0].n_valid + (d4.epi[1].n_valid if d4.m_split < d4.M else 0)
-        if USE_CONV5 and 2 * real > meta4["M"] and self.lib.ppms_conv_gemm5_applicable(C.byref(d4)):
+        if TUNING["conv5"] and 2 * real > meta4["M"] and self.lib.ppms_conv_gemm5_applicable(C.byref(d4)):
             return ConvOp(d4, [packed4, bias4, *keep], 5, device=self.dev)
-        if USE_CONV5 and USE_CONV5_SLICED and 2 * real > meta4["M"]:
+        if TUNING["conv5"] and TUNING["conv5_sliced"] and 2 * real > meta4["M"]:
             ns = int(self.lib.ppms_conv_gemm5_slices(C.byref(d4)))
             if ns >= 2:
                 return ConvOp(d4, [packed4, bias4, *keep], 5, nslice=ns, device=self.dev)
-        if USE_CONV4 and self.lib.ppms_conv_gemm4_applicable(C.byref(d4)):
-            return ConvOp(d4, [packed4, bias4, *keep], 4, device=self.dev)
         return None
 
     def _conv_padded(self, wname, *a, **k) -> ConvOp:
         """wname + "_p" (couts padded to a multiple of 128) when the large-map kernel takes it, else the tight pack."""
-        if (USE_CONV4 or USE_CONV5) and wname in self.pk.w4:
+        if TUNING["conv5"] and wname in self.pk.w4:
             op = self._conv(wname, *a, **k)
-            if op.version in (4, 5):
+            if op.version == 5:
                 return op
-        if USE_CONV3 and wname + "_p" in self.pk.w:
+        if TUNING["conv3"] and wname + "_p" in self.pk.w:
             op = self._conv(wname + "_p", *a, **k)
             if op.version == 3:
                 return op
@@ -461,7 +487,7 @@ class ScaleEngine:
         o = self.op
         self._qk_ops: Dict[int, ConvOp] = {}
         o["init0"] = self._conv("init0", [inp], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=self.ZT.view(0, 64)))
-        if USE_PWCHAIN:
+        if TUNING["pwchain"]:
             w = self.pk.w
             (w1, b1, _), _ = self.pk.dw
             dw1 = (w1.reshape(64).contiguous(), b1)
@@ -471,6 +497,9 @@ class ScaleEngine:
             # chain B: x4 = gelu(x3 + pw x3); cor = gelu(ffn2(x4))              C1 -> COR256
             o["chainB"] = PwChain(self.C1.view(), self.COR256.view(), [(w["pw"], 36, True, None), (w["ffn2_0"], 54, False, None),
                                                                        (w["ffn2_2"], 256, False, None)], self.P, [], device=self.dev)
+            (_, _, _), (w7, b7, _) = self.pk.dw
+            o["dw7"] = TimedCall(lambda: L.check(self.lib.ppms_dwconv_gelu(self.C2.view(0, 40), self.C1.view(0, 40), w7.data_ptr(), b7.data_ptr(), 7,
+                                                                            self.T, self.h, self.w, L.stream_ptr())))
         o["ffn1_0"] = self._conv("ffn1_0", [self.CORR.view()], k1, E(act=L.ACT_GELU, n_valid=54, out_sp=self.T1.view()))
         o["ffn1_2"] = self._conv("ffn1_2", [self.T1.view()], k1, E(L.EPI_RESID, L.ACT_GELU, n_valid=36, out_sp=self.C1.view(), aux_sp=self.CORR.view()))
         o["pw"] = self._conv("pw", [self.C1.view()], k1, E(L.EPI_RESID, L.ACT_GELU, n_valid=36, out_sp=self.C2.view(), aux_sp=self.C1.view()))
@@ -664,7 +693,7 @@ class ScaleEngine:
         (w1, b1, _), (w7, b7, _) = self.pk.dw
         if "chainA" in o:                          # fused per-pixel chains around the depthwise 7x7 (pwchain.hip)
             o["chainA"]()
-            L.check(self.lib.ppms_dwconv_gelu(self.C2.view(0, 40), self.C1.view(0, 40), w7.data_ptr(), b7.data_ptr(), 7, self.T, self.h, self.w, s))
+            o["dw7"]()
             o["chainB"]()
         else:
             o["ffn1_0"]()
@@ -684,10 +713,12 @@ class ScaleEngine:
         self.op["unc0"]()
         L.check(self.lib.ppms_unc_tail(self.U1.view(), self.pk.unc2_w.data_ptr(), self.pk.unc2_b, self.UNC.data_ptr(), self.PART.data_ptr(),
                                        self.T, self.n, self._s()))
-        if self.shard is not None:                  # every rank scores all T x T frame pairs from the same gathered confidences
-            self.shard.all_gather(self.PART, out=self.PARTG)
 
     def pick(self):
+        if self.shard is not None:
+            # ONE direct exchange per iteration for the memory read-out: the values of every frame (bf16, as the reference casts them;
+            # new every iteration) and the frames' confidence sums -- every rank then scores all T x T frame pairs from the same numbers
+            self.shard.gather_many([(self.VT, self.VTG), (self.PART, self.PARTG)])
         L.check(self.lib.ppms_qam_select(self.SIM.data_ptr(), self.STRIVE.data_ptr(), self.PARTG.data_ptr(), self.nblk, self.n, self.SEL.data_ptr(),
                                          self.SHAT.data_ptr(), self.SCORE.data_ptr(), self.Tg, self._s()))
 
@@ -698,8 +729,7 @@ class ScaleEngine:
         if self.shard is None:
             key, key_ld = self.QK.data_ptr() + 128 * 4, 256
         else:
-            key, key_ld = self.KG.data_ptr(), 128
-            self.shard.all_gather(self.VT, out=self.VTG)               # the values of every frame, new every iteration (bf16, as the reference casts them)
+            key, key_ld = self.KG.data_ptr(), 128                      # (the values of every frame arrived with the confidences: pick())
         L.check(self.lib.ppms_attn_prep_k(key, key_ld, self.PE.data_ptr(), sel, shat, self.KB.data_ptr(), self.T, self.ksel, self.n, s))
         ev = None
         if KERNEL_TIMING["on"] and self._ev is not None and self._ev_i < len(self._ev):
@@ -711,10 +741,21 @@ class ScaleEngine:
                                        self.ATT_WS.data_ptr(), s))
         if ev is not None:
             ev[1].record()
+        if self.shard is not None and self.pk.attn is None:
+            # x = [inp | mf, mfg] is final here: its +-2 frames (read by the temporal GRU pass at the END of update()) start travelling
+            # now and arrive under the W and H passes
+            self._xa_halo = self._halo_sp(self.XA, 2, async_op=True)
 
     def conv_ops(self, version: Optional[int] = None):
         """name -> ConvOp of every implicit-GEMM launch of an iteration (version 3: only the large-map kernel's)."""
         return {k: v for k, v in self.op.items() if isinstance(v, ConvOp) and (version is None or v.version == version)}
+
+    def conv_family_ops(self):
+        """name -> launch object of EVERY convolution-family launch of this scale: implicit-GEMM convs (with their slice-reduce halves),
+        the once-per-scale hoisted-share and q/k projections, the fused per-pixel chains and the depthwise 7x7."""
+        fam = {k: v for k, v in self.op.items() if isinstance(v, (ConvOp, PwChain, TimedCall))}
+        fam.update({f"to_qk_{i}": v for i, v in enumerate(self._qk_ops.values())})
+        return fam
 
     def enable_attn_timing(self, launches: int):
         """HIP events (on the stream the kernel is launched on) around the next `launches` mem_attn launches."""
@@ -731,9 +772,8 @@ class ScaleEngine:
         o, s, lib, ln = self.op, self._s(), self.lib, self.pk.ln
         none_sp = L.SP(None, None, 0, 0)
         # TimeAttnBlock: x + fc(proj(attn_T(LN(x))))                                      ppmtereo_update.py:603-618
-        if self.shard is not None:                  # attention over the T frames of a pixel: x of every frame of the window
-            for pl in (0, 1):
-                self.shard.all_gather(self.X.own()[pl], out=self.XG.data[pl])
+        if self.shard is not None:                  # attention over the T frames of a pixel: x of every frame of the window (both planes, one exchange)
+            self.shard.gather_many([(self.X.own()[pl].view(self.T, self.n, 384), self.XG.data[pl].view(self.Tg, self.n, 384)) for pl in (0, 1)])
         L.check(lib.ppms_time_attn(self.XG.view(all_rows=True), ln["ta"][0].data_ptr(), ln["ta"][1].data_ptr(), self.O1.view(all_rows=True),
                                    self.Tg, self.n, 8, s))
         o["ta_proj"]()
@@ -755,6 +795,8 @@ class ScaleEngine:
         o = self.op
         if self.pk.attn is not None:
             self.block16_attention()
+            if self.shard is not None:              # (update_block16 rewrites x: its halo starts here, behind the space attention)
+                self._xa_halo = self._halo_sp(self.XA, 2, async_op=True)
         if self.pk.hoist and self._pre_pending:
             torch.cuda.current_stream().wait_event(self._ev_pre)
             self._pre_pending = False
@@ -766,8 +808,13 @@ class ScaleEngine:
         for k in ("q1", "zr2", "q2"):
             o[k]()
         # GRU pass along T, (5,1,1) convs (ppmtereo_update.py:305-310): +-2 frames of [h | mf, mfg], then of r*h
-        self._halo_sp(self.XA, 2)
-        self._halo_sp(self.Hb[2], 2)
+        if self.shard is not None:
+            self._halo_sp(self.Hb[2], 2)            # h after the H pass: needed at once
+            if self._xa_halo is not None:           # x's halo has been in flight since attend() / the block16 attention
+                self._xa_halo.wait()
+                self._xa_halo = None
+            else:                                   # (update() driven without attend(): the module-level forward())
+                self._halo_sp(self.XA, 2)
         o["zr3"]()
         self._halo_sp(self.RH, 2)
         o["q3"]()

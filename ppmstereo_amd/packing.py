@@ -74,7 +74,7 @@ def pack_conv2(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
 def pack_conv4(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
                seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
                m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:
-    """Layout of the barrier-free kernel (ppmstereo_amd/csrc/conv_gemm4.hip): the weights in MFMA-fragment order, so that a
+    """Layout of the barrier-free kernel (ppmstereo_amd/csrc/conv_gemm5.hip): the weights in MFMA-fragment order, so that a
     wave loads its A operands straight from global memory into registers with coalesced 1 KiB loads:
         bf16 [k16-step][M/64][frag = 2*mb + plane][lane = 32*h + r][8]
              = W[cout = 64*blk + 32*mb + r][cin = 16*chunk + 8*h + j] of tap (row-step, s), plane 0 = hi, 1 = lo,

@@ -164,6 +164,8 @@ class PPMStereoHotPath(nn.Module):
         2-channel flow passes through an NCHW resize.  feats: f1_s, f2_s, net_s, inp_s for s in (16, 8, 4) on the GPU
         (with ``shard``: this rank's frames only).  test_mode: only the final prediction is produced (ppmstereo.py:801-804).
         Returns (flow_up (T,1,H,W), uncertainty (T,1,H,W)) = predictions[-1], uncertainties[-1]."""
+        if iters < 2:
+            raise ValueError(f"cascade: iters={iters}; the 1/16 and 1/8 scales run iters // 2 iterations each (ppmstereo.py:708,744) and need at least one")
         preds = [] if predictions is None else predictions
         uncs = [] if uncertainties is None else uncertainties
         dev = feats["f1_16"].device
@@ -213,26 +215,27 @@ def position_encoding_sine(d_model: int, h: int, w: int) -> torch.Tensor:
 
 
 class InputPadder:
-    """models/core/utils/utils.py:19-44 (mode "sintel"): replicate-pads H, W to multiples of ``divis_by``, split evenly."""
+    """Replicate-pads the last two dimensions up to multiples of ``divis_by`` and crops results back (the reference's helper,
+    models/core/utils/utils.py:19-44).  "sintel" mode centres the image (the extra row / column of an odd pad goes to the bottom /
+    right); any other mode pads the height at the bottom only."""
 
     def __init__(self, dims, mode: str = "sintel", divis_by: int = 8):
-        self.ht, self.wd = dims[-2:]
-        pad_ht = (((self.ht // divis_by) + 1) * divis_by - self.ht) % divis_by
-        pad_wd = (((self.wd // divis_by) + 1) * divis_by - self.wd) % divis_by
-        if mode == "sintel":
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, pad_ht // 2, pad_ht - pad_ht // 2]
-        else:
-            self._pad = [pad_wd // 2, pad_wd - pad_wd // 2, 0, pad_ht]
+        self.ht, self.wd = int(dims[-2]), int(dims[-1])
+        extra_h, extra_w = -self.ht % divis_by, -self.wd % divis_by
+        left, top = extra_w // 2, (extra_h // 2 if mode == "sintel" else 0)
+        self._pad = [left, extra_w - left, top, extra_h - top]          # F.pad order: left, right, top, bottom
 
     def pad(self, *inputs):
-        assert all((x.ndim == 4) for x in inputs)
+        for x in inputs:
+            if x.ndim != 4:
+                raise ValueError(f"InputPadder.pad: 4-D tensors expected, got {tuple(x.shape)}")
         return [torch.nn.functional.pad(x, self._pad, mode="replicate") for x in inputs]
 
     def unpad(self, x):
-        assert x.ndim == 4
-        ht, wd = x.shape[-2:]
-        c = [self._pad[2], ht - self._pad[3], self._pad[0], wd - self._pad[1]]
-        return x[..., c[0]:c[1], c[2]:c[3]]
+        if x.ndim != 4:
+            raise ValueError(f"InputPadder.unpad: 4-D tensor expected, got {tuple(x.shape)}")
+        left, right, top, bottom = self._pad
+        return x[..., top:x.shape[-2] - bottom, left:x.shape[-1] - right]
 
 
 class PPMStereo(PPMStereoHotPath):
@@ -247,9 +250,13 @@ class PPMStereo(PPMStereoHotPath):
     ``None`` = the ``attention_type=None`` behaviour (positional encoding only); or any callable ``(f1_16, f2_16, T)``.
     Everything between the images (minus cnet) and the returned disparity runs on the gfx950 kernels."""
 
-    def __init__(self, *args, fnet=None, cnet=None, sst="auto", **kwargs):
-        super().__init__(*args, **kwargs)
-        at = kwargs.get("attention_type", args[3] if len(args) > 3 else "self_stereo_temporal_update_time_update_space")
+    def __init__(self, max_disp: int = 192, mixed_precision: bool = False, num_frames: int = 5,
+                 attention_type: Optional[str] = "self_stereo_temporal_update_time_update_space", use_3d_update_block: bool = True,
+                 different_update_blocks: bool = True, use_convex_3d: bool = False, init_flow: bool = False, *, fnet=None, cnet=None, sst="auto"):
+        """Parameter names and order of the reference's constructor (ppmstereo.py:45-55); the defaults are the values its wrapper passes
+        (models/ppm_stereo_model.py:27-33) -- the reference's own defaults select the 2-D update block, which its forward cannot drive."""
+        super().__init__(max_disp, mixed_precision, num_frames, attention_type, use_3d_update_block, different_update_blocks, use_convex_3d, init_flow)
+        at = attention_type
         if isinstance(sst, str) and sst == "auto":
             sst = None
             if at is not None and ("self_stereo" in at or "temporal" in at):

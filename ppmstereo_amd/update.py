@@ -200,7 +200,7 @@ class SequenceUpdateBlock3D(nn.Module):
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (T, h, w, str(device), None if shard is None else (shard.rank, shard.world, shard.T))
+        key = (T, h, w, str(device), None if shard is None else (shard.rank, shard.world, shard.T, id(shard.group)))
         pk = self.packed(device)
         if key not in self._engines:
             while len(self._engines) >= self.MAX_ENGINES:
@@ -208,7 +208,10 @@ class SequenceUpdateBlock3D(nn.Module):
             with torch.cuda.device(device):
                 self._engines[key] = ScaleEngine(pk, T, h, w, device, shard)
         self._engines.move_to_end(key)
-        return self._engines[key]
+        eng = self._engines[key]
+        if shard is not None and eng.shard is not None:
+            eng.shard = shard                      # same geometry and group: the caller's object (a new one per window is fine)
+        return eng
 
     # ------------------------------------------------------------------ reference methods (NCHW in / NCHW out)
     def get_motion_and_value(self, flow, corr, motion_hidden_state, inp):

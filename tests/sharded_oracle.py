@@ -20,6 +20,18 @@ def _ext(shard, x, k):
     return buf
 
 
+def _ext_many(shard, xs, k):
+    """Several tensors through ONE batched halo exchange (the engine sends both bf16 planes of a tensor, or two tensors, in one batch)."""
+    bufs = []
+    for x in xs:
+        f = x.shape[0]
+        buf = torch.zeros((f + 2 * HALO,) + tuple(x.shape[1:]), dtype=x.dtype)
+        buf[HALO:HALO + f] = x
+        bufs.append(buf)
+    shard.halo_many([(b, k) for b in bufs])
+    return bufs
+
+
 def _conv_t(W, name, x_ext, kt):
     """temporal conv (kt,1,1) of the reference on the halo'd block: zero padding beyond the halo, crop to the own frames."""
     x5 = x_ext.permute(1, 0, 2, 3)[None]                                   # (1,C,f+2H,h,w)
@@ -44,7 +56,7 @@ def gru3d_sharded(shard, W, h, x):
     r = torch.sigmoid(c3(g + "convr2", hx, (0, 2, 0)))
     q = torch.tanh(c3(g + "convq2", torch.cat([r * h, x], 1), (0, 2, 0)))
     h = (1 - z) * h + z * q
-    x_ext, h_ext = _ext(shard, x, 2), _ext(shard, h, 2)                      # exchange 1: [h | x]
+    x_ext, h_ext = _ext_many(shard, [x, h], 2)                               # exchange 1: [h | x], one batch
     hx = torch.cat([h_ext, x_ext], 1)
     z = torch.sigmoid(_conv_t(W, g + "convz3", hx, 5))
     r = torch.sigmoid(_conv_t(W, g + "convr3", hx, 5))
@@ -62,7 +74,8 @@ def update_block_sharded(shard, W, net, inp, mf, mfg, with_attention):
     """SequenceUpdateBlock3D.forward (ppmtereo_update.py:971-1003) on this rank's frames."""
     x = torch.cat([inp, mf, mfg], 1)
     if with_attention:                                                      # TimeAttnBlock: all T frames of a pixel
-        xg, _ = shard.all_gather(x)
+        xg = torch.empty((shard.T,) + tuple(x.shape[1:]))
+        shard.gather_many([(x, xg)])                                        # direct all-gather (one grouped P2P batch)
         x = O.time_attn(W, xg, shard.T)[shard.lo:shard.hi]
         x = O.space_attn(W, x)                                              # per frame
     net = gru3d_sharded(shard, W, net, x)
@@ -103,9 +116,10 @@ def forward_update_block_sharded(shard, Wb, Watt, pyr, flow, net, inp, mhs, iter
         out_corrs = O.corr_lookup(pyr, flow)
         mf, mhs, value = O.get_motion_and_value(Wb, flow, out_corrs, mhs, inp)
         unc = O.get_uncertainty(Wb, torch.cat([net, value], 1))
-        conf, _ = shard.all_gather(unc.reshape(f, -1).mean(-1))             # T confidences
+        # ONE direct exchange: the T confidences and the values of every frame (the reference casts V to bf16, :550)
+        conf, value_all = torch.empty(T), torch.empty((T,) + tuple(value.shape[1:]), dtype=torch.bfloat16)
+        shard.gather_many([(value.to(torch.bfloat16), value_all), (unc.reshape(f, -1).mean(-1), conf)])
         score, mask, strive = O.qam_select(sim, strive, conf)
-        value_all, _ = shard.all_gather(value.to(torch.bfloat16))           # the reference casts V to bf16 (:550)
         value_all = value_all.float()
         mfg = torch.empty_like(mf)
         for li in range(f):

@@ -53,3 +53,23 @@ def test_product_package_never_imports_the_oracle():
         if f.endswith(".py"):
             text = open(os.path.join(pkg, f)).read()
             assert "oracle" not in re.sub(r'""".*?"""', "", text, flags=re.S).replace("# oracle", ""), f
+
+
+def test_reference_import_path_and_signatures():
+    """``models.core.*`` (the reference's import path, models/ppm_stereo_model.py:12, models/core/ppmstereo.py:17-33) resolves to this
+    package without a GPU, with the reference's parameter names (ppmstereo.py:45-55, 238, 426-441, 601; corr.py:56; ppmtereo_update.py:881)."""
+    import inspect
+
+    from models.core.corr import CorrBlock1D
+    from models.core.ppmstereo import PPMStereo
+    from models.core.ppmtereo_update import SequenceUpdateBlock3D
+    names = lambda f: list(inspect.signature(f).parameters)
+    assert names(PPMStereo.__init__)[1:9] == ["max_disp", "mixed_precision", "num_frames", "attention_type", "use_3d_update_block",
+                                             "different_update_blocks", "use_convex_3d", "init_flow"]
+    assert names(PPMStereo.forward)[1:6] == ["image1", "image2", "flow_init", "iters", "test_mode"]
+    assert names(PPMStereo.forward_batch_test)[1:4] == ["batch_dict", "kernel_size", "iters"]
+    assert names(PPMStereo.forward_update_block)[1:] == ["image1", "update_block", "corr_fn", "flow", "net", "inp", "motion_hidden_state", "attn_block",
+                                                         "predictions", "uncertainties", "iters", "interp_scale", "t"]
+    assert names(CorrBlock1D.__init__)[1:] == ["fmap1", "fmap2", "num_levels", "radius"]
+    assert names(SequenceUpdateBlock3D.__init__)[1:] == ["hidden_dim", "cor_planes", "mask_size", "use_convex_3d", "attention_type"]
+    assert names(SequenceUpdateBlock3D.forward)[1:] == ["net", "inp", "motion_features", "motion_features_global", "t"]

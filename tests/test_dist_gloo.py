@@ -3,6 +3,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -50,11 +51,11 @@ def test_window_sharding_two_ranks(tmp_path):
     assert res["t"] == 2.0 and res["tot"] == 20.0
 
 
-def _shard_worker(rank, world, port, out, c3d, drop=None):
+def _shard_worker(rank, world, port, out, c3d, drop=None, T=8, blocks=None):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    torch.set_num_threads(4)
+    torch.set_num_threads(max(1, 8 // world))
     from oracle import ppm_oracle as O
     from ppmstereo_amd import dist as D
     from ppmstereo_amd import weights as Wm
@@ -63,11 +64,13 @@ def _shard_worker(rank, world, port, out, c3d, drop=None):
     from sharded_oracle import forward_update_block_sharded
     sharded_oracle.DROP = drop                              # fault injection: skip one exchange (the test must then fail)
     r, w, _ = D.init_from_env("gloo")
-    T, h, wd, iters = 8, 8, 32, 2
+    h, wd, iters = 8, 32, 2
     shard = D.FrameShard(rank, world, T)
     W = Wm.hot_path_weights(use_convex_3d=c3d)
     res = {}
     for tag, ai, isc, attn, mh in (("update_block04", 2, 1, False, True), ("update_block16", 0, 4, True, False)):
+        if blocks is not None and tag not in blocks:
+            continue
         d = synth_scale_inputs(T, h, wd, seed=77, with_mhs=mh, frame_contrast=1.0)
         sl = slice(shard.lo, shard.hi)
         pyr = O.corr_pyramid(d["fmap1"][sl], d["fmap2"][sl])                  # per frame: built from the local frames only
@@ -110,6 +113,42 @@ def test_frame_sharded_loop_equals_unsharded(tmp_path):
                     err = (p_[tag][key] - ref[sl]).abs().max().item()
                     tol = {"fo": 3e-4, "pred": 3e-4 * isc, "net": 6e-4, "mhs": 2e-4, "unc": 5e-5}[key]
                     assert err <= tol, (c3d, tag, key, err)
+
+
+def _check_against_unsharded(parts, T, c3d, blocks):
+    from oracle import ppm_oracle as O
+    from ppmstereo_amd import weights as Wm
+    from ppmstereo_amd.synth import synth_scale_inputs
+    W = Wm.hot_path_weights(use_convex_3d=c3d)
+    h, wd, iters = 8, 32, 2
+    for tag, ai, isc, attn, mh in (("update_block04", 2, 1, False, True), ("update_block16", 0, 4, True, False)):
+        if tag not in blocks:
+            continue
+        d = synth_scale_inputs(T, h, wd, seed=77, with_mhs=mh, frame_contrast=1.0)
+        rp, ru = [], []
+        rfo, rnet, rmhs = O.forward_update_block(W[tag], W[f"att.{ai}"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"], d["inp"],
+                                                 d["mhs"], iters, isc, T, attn, rp, ru)
+        covered = []
+        for p_ in parts:
+            sl = slice(p_[tag]["lo"], p_[tag]["hi"])
+            covered += list(range(sl.start, sl.stop))
+            for key, ref in (("fo", rfo), ("net", rnet), ("mhs", rmhs), ("pred", rp[-1]), ("unc", ru[-1])):
+                err = (p_[tag][key] - ref[sl]).abs().max().item()
+                tol = {"fo": 3e-4, "pred": 3e-4 * isc, "net": 6e-4, "mhs": 2e-4, "unc": 5e-5}[key]
+                assert err <= tol, (T, len(parts), c3d, tag, key, p_[tag]["lo"], err)
+        assert covered == list(range(T))
+
+
+@pytest.mark.parametrize("T,c3d,blocks", [(8, False, ("update_block04", "update_block16")), (8, True, ("update_block04",)),
+                                          (20, False, ("update_block04",))])
+def test_frame_sharded_loop_four_ranks(tmp_path, T, c3d, blocks):
+    """World size 4: the INTERIOR ranks have a left and a right neighbour (four point-to-point operations per halo'd tensor in one
+    batch, dist.FrameShard.halo_many), every rank exchanges with three peers in the direct all-gather (gather_many).  T = 8: f = 2
+    frames per rank = HALO, i.e. a rank's whole block is its neighbours' halo; T = 20: f = 5, BASELINE config 4's share (T = 40 over
+    8 GPUs).  Oracle math per rank (tests/sharded_oracle.py), every rank's block against the unsharded loop."""
+    out = str(tmp_path / "s4.pt")
+    mp.spawn(_shard_worker, args=(4, _free_port(), out, c3d, None, T, blocks), nprocs=4, join=True)
+    _check_against_unsharded([torch.load(out + f".{r}") for r in range(4)], T, c3d, blocks)
 
 
 def test_sharded_check_detects_a_dropped_exchange(tmp_path):

@@ -89,3 +89,42 @@ def test_encoders_config3_geometry_properties(fnet):
     assert c4.shape == (T, 256, H // 4, W // 4) and c8.shape == (T, 256, H // 8, W // 8) and c16.shape == (T, 256, H // 16, W // 16)
     assert all(torch.isfinite(t).all() for t in (c4, c8, c16))
     assert torch.equal(c4, d4) and torch.equal(c8, d8) and torch.equal(c16, d16)
+
+
+def test_large_batches_run_and_match_small_ones(fnet):
+    """The reference's evaluation default forward_batch_test(kernel_size=20) hands the encoders 2 x 20 = 40 images at once (ppmstereo.py:
+    277-294, 614-618): at 544 x 960 the half-resolution stem is 40 x 272 x 480 = 5.2 M pixels, beyond the 2^22-pixel limit the implicit-GEMM
+    kernel used to have.  fnet's InstanceNorm and every other layer are per image, so the features of an image must not depend on the
+    batch it travels in: the last frames of the 40-image call against a 4-image call (size-independent property; the launch plans --
+    K slices, tile counts -- differ between the two, hence a tolerance).  Then forward_batch_test itself on the 20-frame video."""
+    m = fnet
+    N, H, W = 20, 544, 960
+    i1, i2 = Wm.hash_uniform((N, 3, H, W), 650).to(DEV), Wm.hash_uniform((N, 3, H, W), 651).to(DEV)
+    f1, f2 = m([i1, i2])
+    assert f1.shape == (N, 256, H // 4, W // 4) and torch.isfinite(f1).all() and torch.isfinite(f2).all()
+    g1, g2 = m([i1[-2:], i2[-2:]])
+    scale = f1[-2:].abs().max().item()
+    assert (f1[-2:] - g1).abs().max().item() < 2e-4 * scale and (f2[-2:] - g2).abs().max().item() < 2e-4 * scale
+    del f1, f2, g1, g2
+    from ppmstereo_amd.cnet import Feature
+    c = Feature("tiny", 256)
+    c.load_state_dict(Wm.cnet_weights(), strict=True)
+    c = c.to(DEV).eval()
+    a4, a8, a16 = c(i1)
+    b4, b8, b16 = c(i1[-2:])
+    for a, b in ((a4, b4), (a8, b8), (a16, b16)):
+        assert torch.isfinite(a).all() and (a[-2:] - b).abs().max().item() < 5e-4 * a[-2:].abs().max().item()
+    del a4, a8, a16, b4, b8, b16, c
+    torch.cuda.empty_cache()
+    from ppmstereo_amd.ppmstereo import PPMStereo
+    whole = PPMStereo()
+    whole.load_hot_path_weights(Wm.hot_path_weights())
+    whole.fnet.load_state_dict(Wm.fnet_weights(), strict=True), whole.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
+    sd = whole.state_dict()
+    sd.update(Wm.sst_weights())
+    whole.load_state_dict(sd, strict=True)
+    whole = whole.to(DEV).eval()
+    video = torch.stack([(i1.cpu() + 1) * 127.5, (i2.cpu() + 1) * 127.5], 1)               # (20, 2, 3, H, W) in [0, 255]
+    out = whole.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=2)      # windows [0, 20) and [10, 20): 40 and 20 images
+    assert tuple(out["disparity"].shape) == (N, 1, H, W) and torch.isfinite(out["disparity"]).all()
+    assert (out["uncertainties"] > 0).all() and (out["uncertainties"] < 1).all()

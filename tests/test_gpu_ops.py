@@ -76,11 +76,9 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     from ppmstereo_amd.engine import ConvOp, epilogue
     from ppmstereo_amd.packing import pack_conv2, pack_conv4
     tile_px = 0
-    if version in (4, 4128, 4256):                                         # conv_gemm4; 4128 / 4256 force the pixel tile
-        tile_px, version = (0 if version == 4 else version - 4000), 4
     if version in (5, 5007, 5008):                                         # conv_gemm5; 5007 / 5008 force the blocks per tile
         tile_px, version = (0 if version == 5 else version - 5000), 5
-    pack_conv = pack_conv4 if version in (4, 5) else pack_conv2
+    pack_conv = pack_conv4 if version == 5 else pack_conv2
     P = T * H * W
     segs, keep = [], []
     seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
@@ -90,9 +88,9 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
         segs.append(t.view())
         keep.append(t)
     wpack = weight
-    if (version in (3, 4, 5) or ysweep) and k3[2] == 1 and k3[1] > 1:       # y-swept kernels: pack with kh / kw swapped
+    if (version in (3, 5) or ysweep) and k3[2] == 1 and k3[1] > 1:       # y-swept kernels: pack with kh / kw swapped
         wpack = (weight if weight.dim() == 5 else weight[:, :, None]).transpose(3, 4).contiguous()
-    if (version in (3, 4, 5) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
+    if (version in (3, 5) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
         w5 = weight if weight.dim() == 5 else weight[:, :, None]
         wpack = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, k3[1] * k3[2]).contiguous()
     packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad)
@@ -126,7 +124,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     if version == 5 and nslice is not None and nslice < 0:                 # -1: let the library plan the slices (must find some)
         nslice = int(L.load().ppms_conv_gemm5_slices(C.byref(d)))
         assert nslice >= 2, nslice
-    ConvOp(d, keep, version, tile_px if version in (4, 5) else wm, nslice=nslice if nslice is not None else 1, ysweep=ysweep)()
+    ConvOp(d, keep, version, tile_px if version == 5 else wm, nslice=nslice if nslice is not None else 1, ysweep=ysweep)()
     torch.cuda.synchronize()
     sp = out.to_f32()[:, :cout].cpu()
     assert (sp - outf[:, :cout].cpu()).abs().max() < 2e-5 * (1 + sp.abs().max()), "SP and fp32 outputs of one launch disagree"
@@ -227,26 +225,6 @@ def test_conv_gemm3_vs_torch(lib, name, T, H, W, segs, cout, k3):
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
-@pytest.mark.parametrize("tile", [4128, 4256])
-@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV3_CASES + [("3x3_ragged_m256", 2, 13, 45, [48, 16], 190, (1, 3, 3)), ("x15_w24", 1, 9, 24, [32], 64, (1, 1, 15))])
-def test_conv_gemm4_vs_torch(lib, name, T, H, W, segs, cout, k3, tile):
-    """Barrier-free k-loop kernel (weights from L2 to registers in fragment order, double-buffered 16-channel windows), both
-    pixel-tile sizes, x / y / 2-D sweeps, temporal taps, two segments, couts padded to 128, ragged maps -- vs torch conv3d."""
-    P = T * H * W
-    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
-    cin = sum(segs)
-    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
-    bs = hash_normal((cout,), 201) * 0.1
-    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
-    seg_pad = [((c + 15) // 16) * 16 for c in segs]
-    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=tile, seg_pad=seg_pad)
-    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
-    aux = hash_normal((P, cout), 303)
-    z = torch.sigmoid(hash_normal((P, cout), 304))
-    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=tile, seg_pad=seg_pad, kind=lib.EPI_GRU, aux=aux, z=z)
-    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
-
-
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3,nslice", [
     ("x15_scale8", 5, 40, 64, [128, 256], 256, (1, 1, 15), -1), ("x15_scale16", 5, 20, 32, [128, 256], 256, (1, 1, 15), -1),
     ("y5_m128", 5, 20, 32, [128, 256], 128, (1, 5, 1), 4), ("3x3_m128_uneven", 2, 24, 40, [64, 32], 100, (1, 3, 3), 2),
@@ -337,22 +315,7 @@ def test_conv_gemm5_full_map(lib):
         assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), (segs, k3)
 
 
-def test_conv_gemm4_full_map(lib):
-    """The shapes the 1/4 scale of BASELINE config 2 really runs (5 x 80 x 128 pixels): GRU (1,1,15) conv with 384 + 128 input
-    channels to 256 couts, and a 3x3 conv, through the library's own tile choice (256-pixel tiles, 400 workgroups)."""
-    T, H, W = 5, 80, 128
-    P = T * H * W
-    for segs, cout, k3 in (([128, 256], 256, (1, 1, 15)), ([128], 256, (1, 3, 3))):
-        xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
-        cin = sum(segs)
-        wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
-        bs = hash_normal((cout,), 201) * 0.1
-        ref = _ref_conv(xs, wt, bs, k3, T, H, W)
-        got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=4)
-        assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), (segs, k3)
-
-
-@pytest.mark.parametrize("version", [5, 4, 3, 2])
+@pytest.mark.parametrize("version", [5, 3, 2])
 def test_conv_gemm_hoisted_input_share(lib, version):
     """conv([h | inp | rest]) == conv_h_rest([h | rest]) + pre, pre = conv_inp(inp) + bias computed by another launch
     (the engine hoists the inp share of the GRU gates out of the iteration loop): every epilogue adds pre_f32 to

@@ -51,17 +51,18 @@ def _worker(rank, world, port, out, c3d):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("c3d", [False, True])
-def test_sharded_cascade_equals_unsharded_on_the_gpu(tmp_path, c3d):
+@pytest.mark.parametrize("world,c3d", [(2, False), (2, True), (4, False)])
+def test_sharded_cascade_equals_unsharded_on_the_gpu(tmp_path, world, c3d):
     """All three scales (update_block16 with its temporal attention gather, 08, 04), 2 / 2 / 4 iterations, K / V / confidence
     all-gathers and every temporal halo, against the same cascade on one rank.  The kernels compute every pixel from the same
     operands whichever rank holds it (zero halos stand for the window's zero padding); what differs is the launch plan -- a rank
     with half the frames has half the tiles, so the K-sliced convolutions of the small scales split their sums differently -- i.e.
     fp32 summation order, which the loop amplifies like any other rounding (measured 2.5e-4 px after 8 predictions).  A missing
-    exchange shows as 0.1-1 px (tests/test_dist_gloo.py has the fault-injection twin)."""
+    exchange shows as 0.1-1 px (tests/test_dist_gloo.py has the fault-injection twin).
+    world = 4: two frames per rank (= the halo depth), interior ranks with two neighbours, three peers in the direct all-gather."""
     out = str(tmp_path / "sh.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out, c3d), nprocs=2, join=True)
-    for r in range(2):
+    mp.spawn(_worker, args=(world, _free_port(), out, c3d), nprocs=world, join=True)
+    for r in range(world):
         res = torch.load(out + f".{r}")
         assert res["finite"] and res["npred"] == 8
         assert res["disp"] <= 5e-5 * max(1.0, res["scale"]), res

@@ -58,7 +58,7 @@ def test_packing_reproduces_the_convolution(segs, cout, k3):
 
 @pytest.mark.parametrize("segs,cout,k3", [([128, 384], 256, (1, 1, 15)), ([48, 16], 190, (1, 3, 3)), ([128], 256, (3, 3, 3)), ([64], 128, (1, 5, 1))])
 def test_fragment_order_packing_reproduces_the_convolution(segs, cout, k3):
-    """pack_conv4 (conv_gemm4.hip: weights in MFMA-fragment order, 16-channel k-steps, taps in sweep order) unpacks to the same
+    """pack_conv4 (conv_gemm5.hip: weights in MFMA-fragment order, 16-channel k-steps, taps in sweep order) unpacks to the same
     weight matrix: checked against F.conv3d, with the sweep-axis conventions the engine uses (y sweep: kh / kw swapped; 2-D
     sweep: (ky, kx) flattened into x)."""
     T, H, W = 2, 5, 6
@@ -269,7 +269,7 @@ def test_library_holds_no_packed_fp32_arithmetic():
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
     n_obj, n_ins, n_mfma, hits = chk.scan(os.path.join(root, "ppmstereo_amd", "libppms.so"))
-    assert n_obj >= 10 and n_ins > 100000 and n_mfma > 500, (n_obj, n_ins, n_mfma)       # the scan really saw the device code
+    assert n_obj >= 9 and n_ins > 100000 and n_mfma > 500, (n_obj, n_ins, n_mfma)       # the scan really saw the device code
     assert hits == [], hits[:5]
 
 

@@ -1,0 +1,23 @@
+"""A/B switches for measurements on the GPU box: maps PPMS_* environment variables onto ppmstereo_amd.engine.TUNING (the product reads
+no environment variable itself).  Import this module before the first engine is built:
+
+    PPMS_CONV5=0 PPMS_SLICE=0 python -c "import tools.ab_switches; ..."      or      import ab_switches  (from tools/)
+
+    PPMS_CONV5, PPMS_CONV5_SLICED, PPMS_CONV5_GEMM, PPMS_CONV3, PPMS_PWCHAIN, PPMS_SLICE, PPMS_HOIST: 0 / 1
+    PPMS_YSWEEP: 0 = off, 1 = y-swept (1, kh, 1) convs, 2d = also the 2-D window for kh, kw > 1
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ppmstereo_amd import engine as _engine  # noqa: E402
+
+_MAP = dict(PPMS_CONV5="conv5", PPMS_CONV5_SLICED="conv5_sliced", PPMS_CONV5_GEMM="conv5_gemm", PPMS_CONV3="conv3", PPMS_PWCHAIN="pwchain",
+            PPMS_SLICE="slices", PPMS_HOIST="hoist")
+for _env, _key in _MAP.items():
+    if _env in os.environ:
+        _engine.TUNING[_key] = os.environ[_env] != "0"
+if "PPMS_YSWEEP" in os.environ:
+    _engine.TUNING["ysweep"] = os.environ["PPMS_YSWEEP"] != "0"
+    _engine.TUNING["win2d"] = os.environ["PPMS_YSWEEP"] == "2d"
+print("[ab_switches]", _engine.TUNING, file=sys.stderr)
