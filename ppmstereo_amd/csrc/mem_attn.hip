@@ -465,6 +465,11 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     // the hand-scheduled loop (attn64_asm.h, generated by tools/gen_attn_asm.py): 2 substeps = one 64-key tile.  The O += V P group
     // of a sub-tile's second key half runs one substep late, so the first substep multiplies zeros by zeros
     u32x4 ring[ATT_RING], vh1[4] = {}, pf0[2] = {}, pf1[2] = {};
+    // the softmax denominator from the matrix pipe: l^T[d][query] += 1 * P over the keys of every PV step (A operand = all ones, so every
+    // row d of the 32 x 32 result holds the same sum): exactly the bf16-rounded probabilities the numerator uses, accumulated the same way
+    f32x16 lacc[QB] = {(f32x16){0}, (f32x16){0}};
+    u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+v"(ones));
     f32x2 pt2[2], tt2[2];
     const f32x2 scale2 = {scale_log2, scale_log2};
     attn64_prime(sa, ring, pt2, tt2, negm2, scale2, kaddr);
@@ -473,8 +478,8 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         const bool more3 = j + 3 < nt;
         if (more3) issue_tile(j + 3);
         const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
-        attn64_substep<0>(sa, sb, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, negm2, scale2, kaddr, vaddr, delta);
-        attn64_substep<1>(sb, sa, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, negm2, scale2, kaddr, vaddr, delta);
+        attn64_substep<0>(sa, sb, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, lacc, ones, negm2, scale2, kaddr, vaddr, delta);
+        attn64_substep<1>(sb, sa, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, lacc, ones, negm2, scale2, kaddr, vaddr, delta);
         if (more3)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
@@ -486,12 +491,21 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     }
     attn64_tail();
     ATTN_STAMP(2)
-    const float lsum[QB] = {lsum2[0][0] + lsum2[0][1], lsum2[1][0] + lsum2[1][1]};
 #pragma unroll
     for (int dblk = 0; dblk < 4; ++dblk)          // O += V P for keys 16..31 of the last sub-tile
 #pragma unroll
         for (int b = 0; b < QB; ++b)
             o[dblk][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vh1[dblk]), __builtin_bit_cast(bf16x8, pf1[b]), o[dblk][b], 0, 0, 0);
+    float lsum[QB];                               // per lane: the sum over the keys seen by this lane's half (add form) / by the wave (MFMA form)
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        if (ATT_LSUM_MFMA) {
+            lacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf1[b]), lacc[b], 0, 0, 0);
+            lsum[b] = lacc[b][0];                 // every row of l^T is the same sum; register 0 of lane (r, h) = column r = this lane's query
+        } else {
+            lsum[b] = lsum2[b][0] + lsum2[b][1];
+        }
+    }
     // a score more than 2^60 above the reference (or a NaN) anywhere shows in the sum: the fix-up pass redoes the tile
     const bool bail = !(lsum[0] <= 0x1p60f) || !(lsum[1] <= 0x1p60f);
 
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         const int qi = q0 + b * 32 + r;
-        const float l_tot = lsum[b] + __shfl_xor(lsum[b], 32);
+        const float l_tot = ATT_LSUM_MFMA ? lsum[b] : lsum[b] + __shfl_xor(lsum[b], 32);
         if (qi >= n) continue;
         const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
         float* po = part_o + row * D;

@@ -53,3 +53,31 @@ def synth_cascade_feats(T: int, H: int, W: int, seed: int = 7) -> Dict[str, torc
         feats[f"f1_{s}"], feats[f"f2_{s}"] = d["fmap1"], d["fmap2"]
         feats[f"net_{s}"], feats[f"inp_{s}"] = d["net"], d["inp"]
     return feats
+
+
+def synthetic_disparity(T: int, H: int, W: int) -> torch.Tensor:
+    """The smooth disparity field of ``stereo_video``: d(x, y, t) = 8 + 6 sin(2 pi x / W + 0.3 t) cos(2 pi y / H)
+    pixels, (T, H, W)."""
+    import math
+    t = torch.arange(T, dtype=torch.float32)[:, None, None]
+    y = torch.arange(H, dtype=torch.float32)[None, :, None]
+    x = torch.arange(W, dtype=torch.float32)[None, None, :]
+    return 8.0 + 6.0 * torch.sin(2 * math.pi * x / W + 0.3 * t) * torch.cos(2 * math.pi * y / H)
+
+
+def stereo_video(T: int, H: int, W: int, seed: int = 7, noise: float = 0.02) -> torch.Tensor:
+    """SURVEY.md section 8(d)'s image-level input: float32 (T, 2, 3, H, W) in [0, 255], as the reference's data loader hands frames to
+    ``forward_batch_test`` (datasets/dynamic_stereo_datasets.py:578-590).  Left view: integer-valued uniform hash noise (a counter hash
+    of (seed, index), not torch's RNG: identical on every box); right view: the left one resampled along the epipolar line at
+    x + d(x, y, t) with the smooth ``synthetic_disparity`` (a left pixel x shows at x - d in the right image; linear interpolation,
+    replicated border) plus ``noise`` * 255 of hash noise -- so the correlation volume has real peaks at a known disparity."""
+    from .weights import hash_uniform
+    left = hash_uniform((T, 3, H, W), seed * 8 + 1, 0.0, 256.0).floor().clamp_(0.0, 255.0)
+    d = synthetic_disparity(T, H, W)
+    pos = (torch.arange(W, dtype=torch.float32)[None, None, :] + d).clamp_(0.0, W - 1.0)          # (T, H, W) sample position in the left view
+    x0 = pos.floor().long().clamp_(0, W - 2)
+    a = (pos - x0.float())[:, None]
+    idx0 = x0[:, None].expand(T, 3, H, W)
+    right = (1.0 - a) * torch.gather(left, 3, idx0) + a * torch.gather(left, 3, idx0 + 1)
+    right = (right + noise * 255.0 * hash_uniform((T, 3, H, W), seed * 8 + 2)).clamp_(0.0, 255.0)
+    return torch.stack([left, right], 1).contiguous()

@@ -214,6 +214,45 @@ def test_forward_with_hip_encoders_and_sst_vs_oracle():
     assert maxdiff(u, ru) < 1e-2
 
 
+def test_whole_model_parity_decomposition_on_structured_video():
+    """Which stage moves the whole-model result?  SURVEY.md section 8(d)'s structured ``stereo_video`` (left = hash-integer frames, right =
+    left shifted by a smooth disparity + 2 % noise: real correlation peaks) through PPMStereo.forward with the encoders swapped ONE at a
+    time: all three from the oracle (-> the hot path's own error from identical inputs), then the HIP fnet, the HIP cnet or the HIP SST
+    block alone, then all three HIP -- each against the oracle's whole forward (ppmstereo.py:601-682 glue + extractor.py:348-423 etc.)."""
+    from ppmstereo_amd.cnet import Feature
+    from ppmstereo_amd.encoder import BasicEncoder
+    from ppmstereo_amd.ppmstereo import PPMStereo
+    from ppmstereo_amd.sst import SSTBlock
+    from ppmstereo_amd.synth import stereo_video
+    T, H, Wd, iters = 3, 64, 256, 4
+    video = stereo_video(T, H, Wd)
+    img1, img2 = video[None, :, 0].contiguous(), video[None, :, 1].contiguous()
+    Wf, Ws, Wc = Wm.fnet_weights(), Wm.sst_weights(), Wm.cnet_weights()
+    torch.set_num_threads(16)
+    rd, ru = O.forward(W, lambda x: O.basic_encoder(Wf, x), lambda im: O.feature_cnet(Wc, im), img1, img2, iters, sst_fn=lambda a, b: O.sst_block(Ws, a, b, T))
+    dev = torch.device(DEV)
+    o_fnet = lambda x: tuple(t.to(dev) for t in O.basic_encoder(Wf, [x[0].cpu(), x[1].cpu()]))
+    o_cnet = lambda im: tuple(t.to(dev) for t in O.feature_cnet(Wc, im.cpu()))
+    o_sst = lambda a, b, t: tuple(x.to(dev) for x in O.sst_block(Ws, a.cpu(), b.cpu(), t))
+    h_fnet = BasicEncoder(256, "instance")
+    h_fnet.load_state_dict(Wf, strict=True)
+    h_cnet = Feature("tiny", 256)
+    h_cnet.load_state_dict(Wc, strict=True)
+    h_sst = SSTBlock()
+    h_sst.load_state_dict(Ws, strict=True)
+    h_fnet, h_cnet, h_sst = h_fnet.to(dev).eval(), h_cnet.to(dev).eval(), h_sst.to(dev).eval()
+    epe = {}
+    for tag, fn, cn, ss in (("oracle encoders", o_fnet, o_cnet, o_sst), ("HIP fnet", h_fnet, o_cnet, o_sst), ("HIP cnet", o_fnet, h_cnet, o_sst),
+                            ("HIP SST", o_fnet, o_cnet, h_sst), ("all HIP", h_fnet, h_cnet, h_sst)):
+        m = PPMStereo(fnet=fn, cnet=cn, sst=ss).load_hot_path_weights(W).to(dev).eval()
+        d, u = m.forward(img1.to(dev), img2.to(dev), iters=iters, test_mode=True)
+        err = (d.cpu() - rd).abs()
+        epe[tag] = err.mean().item()
+        print(f"structured video, {tag:16s}: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px (mean |disparity| {rd.abs().mean().item():.2f} px)")
+    assert epe["oracle encoders"] < 1e-3, "hot path from identical inputs: the north-star budget"
+    assert all(v < 3e-3 for v in epe.values()), epe
+
+
 def test_forward_batch_test_whole_model():
     """The reference's evaluation entry point on the whole HIP model (ppmstereo.py:238-320 with nothing stubbed): 7 frames of 60 x 250
     (padded to 64 x 256 by InputPadder, one window since kernel_size > num_ims), fnet + cnet + SST block + the 3-scale cascade, against the

@@ -34,6 +34,13 @@ PAIRWAIT = RING >= 6
 # two fp32 adds) -- correct (15 tests) but measured SLOWER on gfx950 (1.32 vs 1.25 ms: like the packed fp32 ops, the dot op does not
 # hide behind the MFMAs), so it stays off
 DOT = int(os.environ.get("PPMS_ATTN_DOT", "0"))
+# Softmax denominator.  "mfma" (default since round 3): l comes out of the matrix pipe -- one more MFMA per (16 keys, query block) whose A
+# operand is all ones, so l = sum of exactly the bf16-rounded probabilities the PV product uses (numerator and denominator then carry the
+# SAME rounding and the same accumulation: the rounding error of P cancels to first order wherever the values of a channel share a sign;
+# measured on the reference's iters=10 fixture: EPE 7.9e-4 -> see DESIGN.md section 4), and the 32 fp32 adds per substep leave the VALU
+# stream.  "add": fp32 adds of the unrounded probabilities (flash-attention's form; rounds 1-2).
+LSUM = os.environ.get("PPMS_ATTN_LSUM", "mfma")
+assert LSUM in ("mfma", "add")
 ABL = int(os.environ.get("PPMS_ATTN_ABL", "0"))     # timing experiments only (wrong results): 1 drops the softmax VALU work, 2 the LDS
                                                     # requests and waits, 4 the MFMAs, 8 the address upkeep
 
@@ -101,9 +108,13 @@ def substep(par):
         elif s < 16:
             dblk = (s - 8) >> 1
             E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{dblk}][{b}]")], [("a", "v", f"vh1[{dblk}]"), ("b", "v", f"pf1[{b}]")])
+            if LSUM == "mfma" and s >= 14:      # behind the group's last two MFMAs: l += 1 * P over the same 16 keys (one per query block)
+                E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"lacc[{b}]")], [("a", "v", "ones"), ("b", "v", f"pf1[{b}]")])
         else:
             u = 8 + ((s - 24) >> 1)
             E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{u - 8}][{b}]")], [("a", "v", f"ring[{u % RING}]"), ("b", "v", f"pf0[{b}]")])
+            if LSUM == "mfma" and s >= 30:
+                E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"lacc[{b}]")], [("a", "v", "ones"), ("b", "v", f"pf0[{b}]")])
         # ---- LDS requests behind the second MFMA of a fragment (the dedicated V^T fragments first: they stay older than every
         #      request made for the next substep) -------------------------------------------------------------------------------------
         if s in (17, 19, 21, 23):
@@ -132,8 +143,8 @@ def substep(par):
             E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[{(p + 1) & 1}][0]")], [("t", "v", f"tt2[{(p + 1) & 1}][0]")])
             if PK:
                 E.asm("v_pk_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum2[{pb}]")], [("p", "v", f"pt2[{p & 1}]")])
-            elif DOT:
-                pass                                   # (the pair is summed from its packed bf16 form, odd slot)
+            elif DOT or LSUM == "mfma":
+                pass                                   # (the pair is summed from its packed bf16 form: odd slot / the matrix pipe)
             else:
                 for j in range(2):
                     E.asm("v_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum2[{pb}][{j}]")], [("p", "v", f"pt2[{p & 1}][{j}]")])
@@ -161,15 +172,16 @@ def substep(par):
 
 
 SIG = ("f32x16 (&cur)[2], f32x16 (&nxt)[2], const bf16x8 (&qf)[2][8], f32x16 (&o)[4][2], u32x4 (&ring)[ATT_RING], u32x4 (&vh1)[4],\n"
-       "        u32x4 (&pf0)[2], u32x4 (&pf1)[2], f32x2 (&pt2)[2], f32x2 (&tt2)[2], f32x2 (&lsum2)[2], const f32x2 (&negm2)[2], f32x2 scale2,\n"
-       "        unsigned (&kaddr)[8], unsigned (&vaddr)[4], int delta")
+       "        u32x4 (&pf0)[2], u32x4 (&pf1)[2], f32x2 (&pt2)[2], f32x2 (&tt2)[2], f32x2 (&lsum2)[2], f32x16 (&lacc)[2], const u32x4& ones,\n"
+       "        const f32x2 (&negm2)[2], f32x2 scale2, unsigned (&kaddr)[8], unsigned (&vaddr)[4], int delta")
 
 
 def gen():
     out = ['''// GENERATED by tools/gen_attn_asm.py -- do not edit.  (Schedule and register roles: see the generator's docstring.)
 #pragma once
 constexpr int ATT_RING = %d;        // K / V^T fragment buffers in registers
-''' % RING]
+constexpr bool ATT_LSUM_MFMA = %s;  // the softmax denominator comes out of the matrix pipe (lacc), not from fp32 adds (lsum2)
+''' % (RING, "true" if LSUM == "mfma" else "false")]
     out.append(f"template <int PAR>\n__device__ __forceinline__ void attn64_substep({SIG}) {{")
     out.append("    if constexpr (PAR == 0) {\n" + substep(0) + "\n    } else {\n" + substep(1) + "\n    }\n}\n")
     # prime: ring units 0..2 of substep 0 (S of sub-tile 1: tile 0, keys 32..63), arguments of pairs 0 and 1, exps of pair 0
