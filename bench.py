@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--no-encoders", action="store_true", help="skip the encoder / whole-call timings (fnet + cnet + SST block and "
                     "PPMStereo.forward_batch_test on a host video: once per clip, outside `value`, reported under `encoders` / `whole_call_ms`)")
     ap.add_argument("--with-encoders", action="store_true", help=argparse.SUPPRESS)        # (the default since round 3)
+    ap.add_argument("--no-pipeline", action="store_true", help="run the clips strictly one after the other (no overlap of clip k + 1's small scales with clip k's "
+                    "1/4 scale: ppmstereo_amd.ppmstereo.ClipPipeline); the un-overlapped time of one clip is reported either way (latency_ms_per_clip)")
     ap.add_argument("--replicas", action="store_true", help="N > 1: force clip replicas even when T divides over the ranks")
     args = ap.parse_args()
 
@@ -109,13 +111,23 @@ def main():
         feats = {k: v[shard.lo:shard.hi] for k, v in feats.items()}
     feats = {k: v.to(dev) for k, v in feats.items()}
 
+    from ppmstereo_amd.ppmstereo import ClipPipeline
+    # consecutive steps are independent clips (as the sliding windows of a video are): their small, latency-bound scales are enqueued on a second
+    # stream and run under the previous clip's 1/4 scale.  Same kernels, same results (tests/test_gpu_block.py); not with a frame-sharded window
+    # (its exchanges are ordered on one stream)
+    pipe = ClipPipeline(dev) if not (args.no_pipeline or sharded) else None
+    if pipe is not None:
+        pipe.record_done = True
+
     def step():
-        return model.cascade(feats, iters, T, shard=shard, test_mode=True)
+        return model.cascade(feats, iters, T, shard=shard, test_mode=True, pipeline=pipe)
 
     for _ in range(max(1, args.warmup)):
         disp, _ = step()
     torch.cuda.synchronize()
     assert torch.isfinite(disp).all()
+    if pipe is not None:
+        pipe.done_events.clear()
 
     # HIP events around every launch (in the sampled steps: TIMING_EVERY) of the two dominant kernel families (memory attention; the large-map implicit-GEMM
     # convolution kernels conv5_kernel / conv3_kernel -- whichever the engine picked per conv), on the stream each is launched on
@@ -141,6 +153,8 @@ def main():
         # the per-launch HIP events of the roofline entries are recorded in every TIMING_EVERY-th step of the timed region only (steps 0, 10,
         # ...): ~330 event pairs per clip cost ~2 ms of the clip's 43, and `value` is the time of ALL steps
         _engine.KERNEL_TIMING["on"] = (not args.no_kernel_timing) and i % TIMING_EVERY == 0
+        if pipe is not None:      # the steps whose launches carry events run un-overlapped (their durations are then the kernels' own): neither
+            pipe.serial = _engine.KERNEL_TIMING["on"] or ((not args.no_kernel_timing) and i > 0 and (i - 1) % TIMING_EVERY == 0)   # the step nor its successor overlaps it
         a.record()
         step()
         b.record()
@@ -149,6 +163,9 @@ def main():
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
     step_ms = [a.elapsed_time(b) for a, b in step_ev]
+    if pipe is not None and len(pipe.done_events) == args.steps and args.steps > 1:      # pipelined: a step's time = completion to completion
+        step_ms = [pipe.done_events[i - 1].elapsed_time(pipe.done_events[i]) for i in range(1, args.steps)]
+        pipe.serial, pipe.record_done = False, False
     attn_ms = [e.attn_times_ms() for e, _ in engs] if not args.no_kernel_timing else []
     fam_events = {}
     if family:                                        # one extra step (outside `value`) with events around EVERY convolution-family launch
@@ -242,7 +259,16 @@ def main():
     # the same clip with test_mode=False (the reference's training-style return): every iteration runs the mask head, the convex
     # upsampling and the full-resolution resize of its prediction.  Reported beside the headline number, never as `value`.
     n_all = 3
-    all_ms = None
+    all_ms = lat_ms = None
+    if not sharded:                                # one clip at a time, nothing overlapped: the latency of a clip
+        torch.cuda.synchronize()
+        D.barrier()
+        t_lat = time.perf_counter()
+        for _ in range(n_all):
+            model.cascade(feats, iters, T, shard=shard, test_mode=True)
+            torch.cuda.synchronize()
+        D.barrier()
+        lat_ms = D.max_over_ranks(time.perf_counter() - t_lat) / n_all * 1e3
     if not sharded:                                # (replicas: every rank times its own clip; the frame-sharded mode reports `value` only)
         torch.cuda.synchronize()
         D.barrier()
@@ -312,6 +338,9 @@ def main():
                                         "of each scale; ms_per_step_all_predictions times the same clip with every iteration's prediction produced)",
                                 T=T, H=H, W=W, iters=iters, parallelism=par),
                    ms_per_step_all_predictions=None if all_ms is None else round(all_ms, 3),
+                   latency_ms_per_clip=None if lat_ms is None else round(lat_ms, 3),
+                   pipeline=("consecutive clips overlap: 1/16 + 1/8 scales of clip k + 1 on a second stream under the 1/4 scale of clip k (ClipPipeline); "
+                             "latency_ms_per_clip = one clip alone" if pipe is not None else "off: clips strictly one after the other"),
                    roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None,
                    roofline_3=family_roof if (not args.no_kernel_timing and family) else None, cpu_baseline=cpu,
                    whole_call_ms=None if not encoders else encoders["whole_call_ms"],

@@ -113,6 +113,39 @@ def forward_update_block(self, image1, update_block: SequenceUpdateBlock3D, corr
         return flow_out.clone(), eng.get_net(), eng.get_mhs()
 
 
+class ClipPipeline:
+    """Software pipeline over CONSECUTIVE clips / sliding windows (independent units, ppmstereo.py:277-307): the 1/16 and 1/8 scales of
+    a clip are latency bound (~70 small launches per iteration, a quarter of a clip's time for 7 % of its FLOPs) and leave most of the
+    chip idle, the 1/4 scale is throughput bound.  With the scales on two HIP streams -- ``small`` (1/16, 1/8) and ``large`` (1/4) --
+    the small scales of clip k + 1 run under the 1/4 scale of clip k.  Results are the same bits as the unpipelined cascade; what is
+    shared between the two stages of consecutive clips (the 1/8 engine's state, read by the 1/4 scale's prologue) is guarded by events.
+
+        pipe = ClipPipeline(device)
+        for feats in clips:
+            disp, unc = model.cascade(feats, iters, T, test_mode=True, pipeline=pipe)     # enqueues; the result is valid after ...
+            ...
+        pipe.wait()                                                                        # ... the caller's stream has waited here
+
+    ``cascade`` returns tensors produced on ``large``; ``wait()`` makes the current stream wait for everything enqueued so far (no host
+    synchronisation), ``wait(handle)`` for one clip (``handle`` = ``pipe.last``: the completion event of the clip just enqueued)."""
+
+    def __init__(self, device=None, small_priority: int = 0):
+        device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.device = device
+        self.small = torch.cuda.Stream(device=device, priority=small_priority)
+        self.large = torch.cuda.Stream(device=device)
+        self.consumed: Optional[torch.cuda.Event] = None      # the previous clip's 1/4-scale prologue has read the 1/8 engine's state
+        self.last: Optional[torch.cuda.Event] = None          # completion of the clip enqueued last
+        self.serial = False                                   # True: no overlap between clips (per-launch timing runs of bench.py)
+        self.done_events: List[torch.cuda.Event] = []         # (timing: one per clip when ``record_done`` is set)
+        self.record_done = False
+
+    def wait(self, handle: Optional[torch.cuda.Event] = None):
+        ev = self.last if handle is None else handle
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
+
+
 class PPMStereoHotPath(nn.Module):
     """The part of PPMStereo that lives on the hot path (ppmstereo.py:82-117 modules, :426-594 loop, :696-804
     cascade), from the encoder / SST outputs on.  Attribute names follow the reference."""
@@ -158,11 +191,13 @@ class PPMStereoHotPath(nn.Module):
 
     @torch.no_grad()
     def cascade(self, feats: Dict[str, torch.Tensor], iters: int, t: int, predictions: Optional[list] = None,
-                uncertainties: Optional[list] = None, shard=None, test_mode: bool = False):
+                uncertainties: Optional[list] = None, shard=None, test_mode: bool = False, pipeline: Optional[ClipPipeline] = None):
         """The 1/16 -> 1/8 -> 1/4 cascade of PPMStereo.forward (ppmstereo.py:696-804), device resident: the state handed from
         scale to scale (hidden state, motion hidden state) stays in the engines' SP buffers (ppms_sp_resize_blend), only the
         2-channel flow passes through an NCHW resize.  feats: f1_s, f2_s, net_s, inp_s for s in (16, 8, 4) on the GPU
         (with ``shard``: this rank's frames only).  test_mode: only the final prediction is produced (ppmstereo.py:801-804).
+        pipeline: a ``ClipPipeline`` -- the small scales and the 1/4 scale are enqueued on its two streams so that consecutive clips
+        overlap (same results; see the class).
         Returns (flow_up (T,1,H,W), uncertainty (T,1,H,W)) = predictions[-1], uncertainties[-1]."""
         if iters < 2:
             raise ValueError(f"cascade: iters={iters}; the 1/16 and 1/8 scales run iters // 2 iterations each (ppmstereo.py:708,744) and need at least one")
@@ -176,27 +211,49 @@ class PPMStereoHotPath(nn.Module):
             warnings.warn("PPMStereo with a single frame produces NaN disparities (reference behaviour, T must be >= 2)")
         lib = L.load()
         with torch.cuda.device(dev):
+            caller = torch.cuda.current_stream()
+            if pipeline is not None:
+                pipeline.small.wait_stream(caller)        # the inputs were produced on the caller's stream
+                if pipeline.serial and pipeline.last is not None:
+                    pipeline.small.wait_event(pipeline.last)
             prev, fo = None, None
             for s_, blk, ai, n_it, isc in ((16, self.update_block16, 0, iters // 2, 4), (8, self.update_block08, 1, iters // 2, 2),
                                           (4, self.update_block04, 2, iters, 1)):
                 f1, f2 = feats[f"f1_{s_}"], feats[f"f2_{s_}"]
                 h, w = f1.shape[2:]
-                eng = blk.engine(tl, h, w, dev, shard)
-                eng.set_inp(feats[f"inp_{s_}"])
-                eng.set_net(feats[f"net_{s_}"])
-                if prev is None:
-                    eng.set_flow(self.zero_init(f1))                                                  # :231-236, :695
-                    eng.set_mhs(None)
-                else:
-                    ph, pw = prev.h, prev.w
-                    eng.set_flow(bilinear(fo, (h, w), True, -(h / fo.shape[2])))                      # :724-725, :760-761 (sign flip kept)
-                    eng.parity, eng.have_mhs = 0, True                                                # :726-727, :763-764: mhs x2
-                    L.check(lib.ppms_sp_resize_blend(prev.mhs_view(), eng.mhs_view(), tl, ph, pw, 2 * ph, 2 * pw, 0.0, 1.0, L.stream_ptr()))
-                    # :729-732, :765-767: net = (net_s + interp(net_2s)) / 2
-                    L.check(lib.ppms_sp_resize_blend(prev.net_view(), eng.net_view(), tl, ph, pw, 2 * ph, 2 * pw, 0.5, 0.5, L.stream_ptr()))
-                eng.begin(CorrBlock1D(f1, f2).levels, self.att[ai].packed(dev))
-                fo = _run_iterations(eng, n_it, isc, tl, h, w, preds, uncs, "all" if not test_mode else ("last" if s_ == 4 else "none"))
-                prev = eng
+                stream = caller if pipeline is None else (pipeline.large if s_ == 4 else pipeline.small)
+                if pipeline is not None:
+                    if s_ == 8 and pipeline.consumed is not None:
+                        stream.wait_event(pipeline.consumed)      # the previous clip's 1/4 scale still reads this engine's state in its prologue
+                    if s_ == 4:
+                        stream.wait_stream(pipeline.small)        # this clip's 1/16 and 1/8 scales
+                    for k in (f"f1_{s_}", f"f2_{s_}", f"net_{s_}", f"inp_{s_}"):
+                        feats[k].record_stream(stream)            # (allocated on the caller's stream: keep the allocator from recycling them early)
+                with torch.cuda.stream(stream):
+                    eng = blk.engine(tl, h, w, dev, shard)
+                    eng.set_inp(feats[f"inp_{s_}"])
+                    eng.set_net(feats[f"net_{s_}"])
+                    if prev is None:
+                        eng.set_flow(self.zero_init(f1))                                                  # :231-236, :695
+                        eng.set_mhs(None)
+                    else:
+                        ph, pw = prev.h, prev.w
+                        eng.set_flow(bilinear(fo, (h, w), True, -(h / fo.shape[2])))                      # :724-725, :760-761 (sign flip kept)
+                        eng.parity, eng.have_mhs = 0, True                                                # :726-727, :763-764: mhs x2
+                        L.check(lib.ppms_sp_resize_blend(prev.mhs_view(), eng.mhs_view(), tl, ph, pw, 2 * ph, 2 * pw, 0.0, 1.0, L.stream_ptr()))
+                        # :729-732, :765-767: net = (net_s + interp(net_2s)) / 2
+                        L.check(lib.ppms_sp_resize_blend(prev.net_view(), eng.net_view(), tl, ph, pw, 2 * ph, 2 * pw, 0.5, 0.5, L.stream_ptr()))
+                    if pipeline is not None and s_ == 4:
+                        pipeline.consumed = torch.cuda.Event()
+                        pipeline.consumed.record()                # the 1/8 engine's flow / hidden states have been read: the next clip may overwrite them
+                    eng.begin(CorrBlock1D(f1, f2).levels, self.att[ai].packed(dev))
+                    fo = _run_iterations(eng, n_it, isc, tl, h, w, preds, uncs, "all" if not test_mode else ("last" if s_ == 4 else "none"))
+                    prev = eng
+            if pipeline is not None:
+                pipeline.last = torch.cuda.Event(enable_timing=pipeline.record_done)
+                pipeline.last.record(pipeline.large)
+                if pipeline.record_done:
+                    pipeline.done_events.append(pipeline.last)
             return preds[-1], uncs[-1]
 
 
@@ -341,9 +398,10 @@ class PPMStereo(PPMStereoHotPath):
         return feats
 
     @torch.no_grad()
-    def forward(self, image1: torch.Tensor, image2: torch.Tensor, flow_init=None, iters: int = 10, test_mode: bool = False):
+    def forward(self, image1: torch.Tensor, image2: torch.Tensor, flow_init=None, iters: int = 10, test_mode: bool = False, pipeline=None):
         """PPMStereo.forward (ppmstereo.py:601-804): image (b, T, 3, H, W) in [0, 255], H, W multiples of 32, b = 1.
-        test_mode: (flow_up, uncertainty), each (b, T, 1, H, W); else (predictions (D, b, T, 1, H, W), uncertainties)."""
+        test_mode: (flow_up, uncertainty), each (b, T, 1, H, W); else (predictions (D, b, T, 1, H, W), uncertainties).
+        pipeline (test_mode only): a ``ClipPipeline`` -- the result is valid once ``pipeline.wait()`` has been called."""
         if flow_init is not None:
             raise NotImplementedError("flow_init: the reference's own path for it reads undefined state (ppmstereo.py:691-693, 763)")
         if self.fnet is None or self.cnet is None:
@@ -358,7 +416,7 @@ class PPMStereo(PPMStereoHotPath):
             c4, c8, c16 = self.cnet(im1)
             feats = self.pre_loop(fmap1, fmap2, c4, c8, c16, T)
             preds, uncs = [], []
-            self.cascade(feats, iters, T, preds, uncs, test_mode=test_mode)
+            self.cascade(feats, iters, T, preds, uncs, test_mode=test_mode, pipeline=pipeline if test_mode else None)
             if test_mode:
                 return preds[-1][None], uncs[-1][None]
             return torch.stack(preds)[:, None], torch.stack(uncs)[:, None]
@@ -397,15 +455,31 @@ class PPMStereo(PPMStereoHotPath):
             disp = D.gather_kept_frames(mine_d, num_ims, H0, W0)
             unc = D.gather_kept_frames(mine_u, num_ims, H0, W0)
             return {"disparity": disp.cpu(), "uncertainties": unc.cpu()}
-        for start, stop, keep_from, keep_to in plan:
-            left, right = video[start:stop, 0], video[start:stop, 1]
-            padder = InputPadder(left.shape, divis_by=32)
-            left, right = padder.pad(left, right)
-            d, u = self.forward(left[None].to(dev), right[None].to(dev), iters=iters, test_mode=True)      # host -> device: once per window
+        # several windows: independent units -> software pipeline (ClipPipeline): window k + 1's encoders and small scales are enqueued
+        # before window k's result is collected, and run under window k's 1/4 scale
+        pipe = ClipPipeline(dev) if len(plan) > 1 else None
+        pending = None
+
+        def collect(item):
+            d, u, handle, padder, keep_from, keep_to = item
+            if pipe is not None:
+                pipe.wait(handle)
             d = padder.unpad(d[0])[:, None].cpu()                                                           # device -> host
             u = padder.unpad(u[0])[:, None].cpu()
             disp_preds.append(d[keep_from:keep_to])
             uncertainties.append(u[keep_from:keep_to])
+
+        with torch.cuda.device(dev):
+            for start, stop, keep_from, keep_to in plan:
+                left, right = video[start:stop, 0], video[start:stop, 1]
+                padder = InputPadder(left.shape, divis_by=32)
+                left, right = padder.pad(left, right)
+                d, u = self.forward(left[None].to(dev), right[None].to(dev), iters=iters, test_mode=True, pipeline=pipe)      # host -> device: once per window
+                item = (d, u, None if pipe is None else pipe.last, padder, keep_from, keep_to)
+                if pending is not None:
+                    collect(pending)
+                pending = item
+            collect(pending)
         return {"disparity": torch.cat(disp_preds).squeeze(1).abs()[:, :1], "uncertainties": torch.cat(uncertainties).squeeze(1).abs()[:, :1]}
 
 
