@@ -86,8 +86,9 @@ def main():
     ap.add_argument("--no-encoders", action="store_true", help="skip the encoder / whole-call timings (fnet + cnet + SST block and "
                     "PPMStereo.forward_batch_test on a host video: once per clip, outside `value`, reported under `encoders` / `whole_call_ms`)")
     ap.add_argument("--with-encoders", action="store_true", help=argparse.SUPPRESS)        # (the default since round 3)
-    ap.add_argument("--no-pipeline", action="store_true", help="run the clips strictly one after the other (no overlap of clip k + 1's small scales with clip k's "
-                    "1/4 scale: ppmstereo_amd.ppmstereo.ClipPipeline); the un-overlapped time of one clip is reported either way (latency_ms_per_clip)")
+    ap.add_argument("--pipeline", action="store_true", help="overlap consecutive clips (clip k + 1's small scales on a second stream under clip k's 1/4 scale: "
+                    "ppmstereo_amd.ppmstereo.ClipPipeline; measured 40.8 vs 41.8 ms per clip -- the 1/4 scale leaves ~16 CUs to the second stream); off by "
+                    "default: the headline number is one clip after the other.  latency_ms_per_clip (one clip alone) is reported either way")
     ap.add_argument("--replicas", action="store_true", help="N > 1: force clip replicas even when T divides over the ranks")
     args = ap.parse_args()
 
@@ -115,7 +116,7 @@ def main():
     # consecutive steps are independent clips (as the sliding windows of a video are): their small, latency-bound scales are enqueued on a second
     # stream and run under the previous clip's 1/4 scale.  Same kernels, same results (tests/test_gpu_block.py); not with a frame-sharded window
     # (its exchanges are ordered on one stream)
-    pipe = ClipPipeline(dev) if not (args.no_pipeline or sharded) else None
+    pipe = ClipPipeline(dev) if (args.pipeline and not sharded) else None
     if pipe is not None:
         pipe.record_done = True
 
