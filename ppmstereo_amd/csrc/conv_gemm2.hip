@@ -336,11 +336,14 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
         constexpr int CLS = decltype(cls_tag)::value, G = decltype(grp_tag)::value;
     #pragma unroll 1
         for (int nb = 0; nb < 2; ++nb) {
-            if (CLS == EPI_CLS_ANY && e.out_vt != nullptr) {                                   // pixel-major V^T straight from the accumulator layout
+            // pixel-major V^T (the attention's value operand, bf16 [frame][cout][H*W]).  Fast form: from the staged patch below, a lane takes
+            // ONE cout and 8 consecutive pixels per step: 16-byte stores (the accumulator layout gave 2-byte stores, 64 per lane: the epilogue
+            // of the 128 -> 128 to_v GEMM cost 25-30 us at every scale, more than its K loop).  Needs rows of 8 aligned pixels.
+            const bool vt_fast = !g.ysweep && F >= 8 && (W & 7) == 0 && (HW & 7) == 0;
+            if (CLS == EPI_CLS_ANY && e.out_vt != nullptr && !vt_fast) {                       // (any geometry) straight from the accumulator layout
                 const int pid = wn * 64 + nb * 32 + r;
                 const int pf_ = pid & (F - 1), ps_ = pid >> g.logF;
                 const int px = x0 + (g.ysweep ? ps_ : pf_), py = y0 + (g.ysweep ? pf_ : ps_);
-                const int64_t pix = (int64_t)(tf * H + py) * W + px;
     #pragma unroll
                 for (int mb = 0; mb < 2; ++mb)
     #pragma unroll
@@ -363,6 +366,24 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
                     stage_write32(stg, r, h, mb, gq, a4);
                 }
             __builtin_amdgcn_wave_barrier();
+            if (CLS == EPI_CLS_ANY && e.out_vt != nullptr && vt_fast) {
+                const int cl = cbase + lane;                    // this lane's cout (of the epilogue half)
+                const float bc = gld<float>(p.bias + cblock + lane);
+                bf16_t* vrow = (bf16_t*)e.out_vt + ((int64_t)tf * e.n_valid + cl) * HW;
+    #pragma unroll
+                for (int k8 = 0; k8 < 4; ++k8) {
+                    const int pid = wn * 64 + nb * 32 + 8 * k8;
+                    const int px = x0 + (pid & (F - 1)), py = y0 + (pid >> g.logF);
+                    float y[8];
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) y[j] = stg[(8 * k8 + j) * STG_LD + lane] + bc;
+                    apply_act_n<8>(y, e.act, e.scale);
+                    bf16x8 o8;
+    #pragma unroll
+                    for (int j = 0; j < 8; ++j) o8[j] = (bf16_t)y[j];
+                    if (px < W && py < H && cl < e.n_valid) gst<bf16x8>(vrow + (int64_t)py * W + px, o8);
+                }
+            }
     #pragma unroll 1
             for (int it0 = 0; it0 < 4; it0 += G) {          // groups of G 8-row steps: operands first, then the stores (conv_epilogue.h)
                 row8_aux aux[G];

@@ -181,17 +181,24 @@ __global__ __launch_bounds__(256) void unc_tail_kernel(ppms_sp x, const float* _
     float wv[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) wv[j] = w[sub * 8 + j];
+    // all 16 pixels of a lane group are requested before the first is consumed (the loop used to wait out one memory round trip per pixel:
+    // 16 us per launch at every scale); the sums keep their order (per pixel: lanes by shuffle; per block: pixel order), so the
+    // confidences are the same bits as before
+    bf16x8 h8[16], l8[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int pin = blk * 256 + it * 16 + grp;
+        const int64_t pix = (int64_t)frame * HW + (pin < HW ? pin : HW - 1);
+        h8[it] = gld<bf16x8>((const bf16_t*)x.hi + pix * x.ld + sub * 8);
+        l8[it] = gld<bf16x8>((const bf16_t*)x.lo + pix * x.ld + sub * 8);
+    }
     float local = 0.0f;
+#pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int pin = blk * 256 + it * 16 + grp;
         float s = 0.0f;
-        if (pin < HW) {
-            const int64_t pix = (int64_t)frame * HW + pin;
-            const bf16x8 h8 = *(const bf16x8*)((const bf16_t*)x.hi + pix * x.ld + sub * 8);
-            const bf16x8 l8 = *(const bf16x8*)((const bf16_t*)x.lo + pix * x.ld + sub * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += wv[j] * join_bf16(h8[j], l8[j]);
-        }
+        for (int j = 0; j < 8; ++j) s += wv[j] * join_bf16(h8[it][j], l8[it][j]);
         s += __shfl_xor(s, 1);
         s += __shfl_xor(s, 2);
         s += __shfl_xor(s, 4);
@@ -693,10 +700,15 @@ __global__ __launch_bounds__(64) void qam_select_kernel(const float* __restrict_
                                                         float* __restrict__ shat, float* __restrict__ score_out, int T) {
     __shared__ float conf[64];
     const int i = threadIdx.x;
-    if (i < T) {
+    // frame confidences = mean of the uncertainty map: the block sums of frame f are added by all 64 lanes (lane l takes blocks l, l + 64,
+    // ...; then a butterfly) -- a fixed order, the same on every rank of a sharded window; one lane per frame walking nblk sums in a
+    // dependent chain cost most of this kernel's 11 us
+    for (int f = 0; f < T; ++f) {
         float s = 0.0f;
-        for (int b = 0; b < nblk; ++b) s += partial[i * nblk + b];
-        conf[i] = s / (float)HW;
+        for (int b = i; b < nblk; b += 64) s += partial[f * nblk + b];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+        if (i == 0) conf[f] = s / (float)HW;
     }
     __syncthreads();
     if (i >= T) return;
