@@ -467,8 +467,14 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     u32x4 ring[ATT_RING], vh1[4] = {}, pf0[2] = {}, pf1[2] = {};
     // the softmax denominator from the matrix pipe: l^T[d][query] += 1 * P over the keys of every PV step (A operand = all ones, so every
     // row d of the 32 x 32 result holds the same sum): exactly the bf16-rounded probabilities the numerator uses, accumulated the same way
+    // ATT_LSUM == 2: one 16x16x32 MFMA instead (half the matrix-pipe time): read as that shape's B operand, this lane's fragment is
+    // column r & 15, k-block 2 h + (r >> 4); A = ones on (row 0, k-blocks 0 and 2) and (row 1, k-blocks 1 and 3), i.e. in lanes 0, 32, 17,
+    // 49: row 0 of the 16 x 16 result = the sums of queries 0..15, row 1 = queries 16..31 (registers 0, 1 of lanes 0..15)
     f32x16 lacc[QB] = {(f32x16){0}, (f32x16){0}};
-    u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    f32x4 lacc4[QB] = {(f32x4){0}, (f32x4){0}};
+    const bool sel_lane = (ATT_LSUM == 2) ? (lane == 0 || lane == 32 || lane == 17 || lane == 49) : true;
+    const unsigned one2 = sel_lane ? 0x3f803f80u : 0u;
+    u32x4 ones = {one2, one2, one2, one2};
     asm volatile("" : "+v"(ones));
     f32x2 pt2[2], tt2[2];
     const f32x2 scale2 = {scale_log2, scale_log2};
@@ -478,8 +484,8 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         const bool more3 = j + 3 < nt;
         if (more3) issue_tile(j + 3);
         const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
-        attn64_substep<0>(sa, sb, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, lacc, ones, negm2, scale2, kaddr, vaddr, delta);
-        attn64_substep<1>(sb, sa, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, lacc, ones, negm2, scale2, kaddr, vaddr, delta);
+        attn64_substep<0>(sa, sb, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, lacc, lacc4, ones, negm2, scale2, kaddr, vaddr, delta);
+        attn64_substep<1>(sb, sa, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, lacc, lacc4, ones, negm2, scale2, kaddr, vaddr, delta);
         if (more3)
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else
@@ -499,9 +505,13 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     float lsum[QB];                               // per lane: the sum over the keys seen by this lane's half (add form) / by the wave (MFMA form)
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-        if (ATT_LSUM_MFMA) {
+        if (ATT_LSUM == 1) {
             lacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf1[b]), lacc[b], 0, 0, 0);
             lsum[b] = lacc[b][0];                 // every row of l^T is the same sum; register 0 of lane (r, h) = column r = this lane's query
+        } else if (ATT_LSUM == 2) {
+            lacc4[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf1[b]), lacc4[b], 0, 0, 0);
+            const float lo16 = __shfl(lacc4[b][0], r & 15), hi16 = __shfl(lacc4[b][1], r & 15);      // rows 0 / 1 live in lanes 0..15
+            lsum[b] = (r & 16) ? hi16 : lo16;
         } else {
             lsum[b] = lsum2[b][0] + lsum2[b][1];
         }
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
         const int qi = q0 + b * 32 + r;
-        const float l_tot = ATT_LSUM_MFMA ? lsum[b] : lsum[b] + __shfl_xor(lsum[b], 32);
+        const float l_tot = ATT_LSUM != 0 ? lsum[b] : lsum[b] + __shfl_xor(lsum[b], 32);
         if (qi >= n) continue;
         const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
         float* po = part_o + row * D;

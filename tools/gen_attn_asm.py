@@ -39,8 +39,13 @@ DOT = int(os.environ.get("PPMS_ATTN_DOT", "0"))
 # SAME rounding and the same accumulation: the rounding error of P cancels to first order wherever the values of a channel share a sign;
 # measured on the reference's iters=10 fixture: EPE 7.9e-4 -> see DESIGN.md section 4), and the 32 fp32 adds per substep leave the VALU
 # stream.  "add": fp32 adds of the unrounded probabilities (flash-attention's form; rounds 1-2).
-LSUM = os.environ.get("PPMS_ATTN_LSUM", "mfma")
-assert LSUM in ("mfma", "add")
+# "mfma16" (default): the same sum from ONE 16x16x32 MFMA per (16 keys, query block) -- half the matrix-pipe time of the 32x32x16 form.
+# The P fragment (32x32x16 B layout: lane (r, h) = query r, keys 8h..8h+7) read as a 16x16x32 B operand is column r & 15, k-block
+# 2 h + (r >> 4); with the constant A operand (row 0: ones on k-blocks 0 and 2, row 1: ones on k-blocks 1 and 3, other rows zero)
+# the result's row 0 is the sum over all 16 keys for queries 0..15, row 1 for queries 16..31 (registers 0 and 1 of lanes 0..15).
+LSUM = os.environ.get("PPMS_ATTN_LSUM", "mfma16")
+assert LSUM in ("mfma", "mfma16", "add")
+MF16 = "v_mfma_f32_16x16x32_bf16"
 ABL = int(os.environ.get("PPMS_ATTN_ABL", "0"))     # timing experiments only (wrong results): 1 drops the softmax VALU work, 2 the LDS
                                                     # requests and waits, 4 the MFMAs, 8 the address upkeep
 
@@ -110,11 +115,15 @@ def substep(par):
             E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{dblk}][{b}]")], [("a", "v", f"vh1[{dblk}]"), ("b", "v", f"pf1[{b}]")])
             if LSUM == "mfma" and s >= 14:      # behind the group's last two MFMAs: l += 1 * P over the same 16 keys (one per query block)
                 E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"lacc[{b}]")], [("a", "v", "ones"), ("b", "v", f"pf1[{b}]")])
+            if LSUM == "mfma16" and s >= 14:
+                E.asm(f"{MF16} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"lacc4[{b}]")], [("a", "v", "ones"), ("b", "v", f"pf1[{b}]")])
         else:
             u = 8 + ((s - 24) >> 1)
             E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{u - 8}][{b}]")], [("a", "v", f"ring[{u % RING}]"), ("b", "v", f"pf0[{b}]")])
             if LSUM == "mfma" and s >= 30:
                 E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"lacc[{b}]")], [("a", "v", "ones"), ("b", "v", f"pf0[{b}]")])
+            if LSUM == "mfma16" and s >= 30:
+                E.asm(f"{MF16} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"lacc4[{b}]")], [("a", "v", "ones"), ("b", "v", f"pf0[{b}]")])
         # ---- LDS requests behind the second MFMA of a fragment (the dedicated V^T fragments first: they stay older than every
         #      request made for the next substep) -------------------------------------------------------------------------------------
         if s in (17, 19, 21, 23):
@@ -143,7 +152,7 @@ def substep(par):
             E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[{(p + 1) & 1}][0]")], [("t", "v", f"tt2[{(p + 1) & 1}][0]")])
             if PK:
                 E.asm("v_pk_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum2[{pb}]")], [("p", "v", f"pt2[{p & 1}]")])
-            elif DOT or LSUM == "mfma":
+            elif DOT or LSUM != "add":
                 pass                                   # (the pair is summed from its packed bf16 form: odd slot / the matrix pipe)
             else:
                 for j in range(2):
@@ -172,7 +181,7 @@ def substep(par):
 
 
 SIG = ("f32x16 (&cur)[2], f32x16 (&nxt)[2], const bf16x8 (&qf)[2][8], f32x16 (&o)[4][2], u32x4 (&ring)[ATT_RING], u32x4 (&vh1)[4],\n"
-       "        u32x4 (&pf0)[2], u32x4 (&pf1)[2], f32x2 (&pt2)[2], f32x2 (&tt2)[2], f32x2 (&lsum2)[2], f32x16 (&lacc)[2], const u32x4& ones,\n"
+       "        u32x4 (&pf0)[2], u32x4 (&pf1)[2], f32x2 (&pt2)[2], f32x2 (&tt2)[2], f32x2 (&lsum2)[2], f32x16 (&lacc)[2], f32x4 (&lacc4)[2], const u32x4& ones,\n"
        "        const f32x2 (&negm2)[2], f32x2 scale2, unsigned (&kaddr)[8], unsigned (&vaddr)[4], int delta")
 
 
@@ -180,8 +189,8 @@ def gen():
     out = ['''// GENERATED by tools/gen_attn_asm.py -- do not edit.  (Schedule and register roles: see the generator's docstring.)
 #pragma once
 constexpr int ATT_RING = %d;        // K / V^T fragment buffers in registers
-constexpr bool ATT_LSUM_MFMA = %s;  // the softmax denominator comes out of the matrix pipe (lacc), not from fp32 adds (lsum2)
-''' % (RING, "true" if LSUM == "mfma" else "false")]
+constexpr int ATT_LSUM = %d;        // softmax denominator: 0 = fp32 adds (lsum2), 1 = 32x32x16 ones-row MFMA (lacc), 2 = 16x16x32 selector MFMA (lacc4)
+''' % (RING, {"add": 0, "mfma": 1, "mfma16": 2}[LSUM])]
     out.append(f"template <int PAR>\n__device__ __forceinline__ void attn64_substep({SIG}) {{")
     out.append("    if constexpr (PAR == 0) {\n" + substep(0) + "\n    } else {\n" + substep(1) + "\n    }\n}\n")
     # prime: ring units 0..2 of substep 0 (S of sub-tile 1: tile 0, keys 32..63), arguments of pairs 0 and 1, exps of pair 0
