@@ -305,8 +305,9 @@ class PackedBlock:
             ta, sa = "time_attn.", "space_attn.encoder_layer."
             put("ta_proj", lin(ta + "temporal_attn.proj.weight"), g(ta + "temporal_attn.proj.bias"), [384])
             put("ta_fc", lin(ta + "temporal_fc.weight"), g(ta + "temporal_fc.bias"), [384])
-            put("sa_qk", torch.cat([lin(sa + "q_proj.weight"), lin(sa + "k_proj.weight")], 0), None, [384])
-            put("sa_v", lin(sa + "v_proj.weight"), None, [384])
+            # q, k and v projections of the linear attention read the same x: ONE launch with two epilogue halves (rows 0..767: elu + 1 for q | k,
+            # rows 768..1151: v / n)
+            put("sa_qkv", torch.cat([lin(sa + "q_proj.weight"), lin(sa + "k_proj.weight"), lin(sa + "v_proj.weight")], 0), None, [384])
             put("sa_merge", lin(sa + "merge.weight"), None, [384])
             put("sa_mlp0", lin(sa + "mlp.0.weight"), None, [384, 384])
             put("sa_mlp2", lin(sa + "mlp.2.weight"), None, [768])
@@ -519,8 +520,8 @@ class ScaleEngine:
         if self.pk.attn is not None:                 # update_block16: time / space attention on x = [inp, mf, mfg]
             o["ta_proj"] = self._conv("ta_proj", [self.O1.view()], k1, E(n_valid=384, out_sp=self.O2.view()))
             o["ta_fc"] = self._conv("ta_fc", [self.O2.view()], k1, E(L.EPI_RESID, n_valid=384, out_sp=self.XT.view(), aux_sp=X.view()))
-            o["sa_qk"] = self._conv("sa_qk", [self.XT.view()], k1, E(act=L.ACT_ELU1, n_valid=768, out_f32=self.QKF, out_f32_ld=768))
-            o["sa_v"] = self._conv("sa_v", [self.XT.view()], k1, E(scale=1.0 / self.n, n_valid=384, out_f32=self.VF, out_f32_ld=384))
+            o["sa_qkv"] = self._conv("sa_qkv", [self.XT.view()], k1, E(act=L.ACT_ELU1, n_valid=768, out_f32=self.QKF, out_f32_ld=768),
+                                     E(scale=1.0 / self.n, n_valid=384, out_f32=self.VF, out_f32_ld=384), m_split=768)
             o["sa_merge"] = self._conv("sa_merge", [self.MSG.view()], k1, E(n_valid=384, out_f32=self.M2, out_f32_ld=384))
             o["sa_mlp0"] = self._conv("sa_mlp0", [self.XT.view(), self.MSGN.view()], k1, E(act=L.ACT_RELU, n_valid=768, out_sp=self.H1.view()))
             o["sa_mlp2"] = self._conv("sa_mlp2", [self.H1.view()], k1, E(n_valid=384, out_f32=self.M3, out_f32_ld=384))
@@ -780,8 +781,7 @@ class ScaleEngine:
         o["ta_proj"]()
         o["ta_fc"]()
         # SpaceAttnBlock = LoFTR encoder layer with linear attention, x = source                 attention.py:164-190
-        o["sa_qk"]()
-        o["sa_v"]()
+        o["sa_qkv"]()
         L.check(lib.ppms_linear_attention(self.QKF.data_ptr(), 768, self.QKF.data_ptr() + 384 * 4, 768, self.VF.data_ptr(), 384,
                                           self.KVWS.data_ptr(), self.MSG.view(), self.T, self.n, 8, 48, s))
         o["sa_merge"]()
