@@ -111,88 +111,46 @@ __device__ __forceinline__ float lookup_tap(const float* __restrict__ L, int Wl,
     return (1.0f - a) * v0 + a * v1;
 }
 
-// fast path: channel-last SP output (36 real + 28 zero channels).  One wave owns LK_PX consecutive pixels (all their loads are in flight
-// together: with one pixel per wave the kernel was two dependent memory round trips deep and 6 rounds of waves long).  Per pixel the four
-// pyramid rows are touched once: lanes (level = lane / 16, j = lane % 16, j < 12) fetch the 12-float window around x / 2^level that
-// contains every tap of the level, and the 36 tap lanes pick their two neighbours out of the wave with shuffles (north_star: window
-// staging + wavefront shuffles instead of two uncoalesced loads per tap).  The interpolation position of a tap is still the
-// reference's own fp32 op sequence (lookup_tap); a tap whose cell falls outside the staged window (never, short of rounding at huge
-// |flow|) loads directly.
-constexpr int LK_PX = 4;
+// fast path: 4 pixels x 64 channel slots per block, channel-last SP output (36 real + 28 zero channels).
+// One wave per pixel, lane = output channel, two loads per tap (neighbouring lanes of a level hit the same cache lines).  Round 3 tried
+// north_star's literal prescription -- a 12-float window per (pixel, level) staged by 48 lanes, taps picked with wave shuffles, 4 pixels
+// per wave for memory-level parallelism: 20.2 us against 16.4 us at the 1/4 scale of config 2 (8.9 / 7.4, 6.4 / 4.4 at 1/8, 1/16): the
+// kernel is bound by its store stream (128 B per plane and pixel) and by wave count, not by the tap loads, so this form stays.
 __global__ __launch_bounds__(256) void corr_lookup_sp_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
                                                              const float* __restrict__ l2, const float* __restrict__ l3,
                                                              const float* __restrict__ flow, int flow_nhwc, bf16_t* __restrict__ ohi,
                                                              bf16_t* __restrict__ olo, int out_ld, bf16_t* __restrict__ fhi,
                                                              bf16_t* __restrict__ flo, int f_ld, int H, int W, int64_t P) {
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int ch = threadIdx.x & 63;
-    const int64_t p0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * LK_PX;
-    if (p0 >= P) return;                                   // (wave-uniform)
+    if (p >= P) return;
+    const int x = (int)(p % W);
     const int64_t hw = (int64_t)H * W;
-    const int wl_lvl = ch >> 4, wl_j = ch & 15;            // window-loader role of this lane
-    const int WlL = W >> wl_lvl;
-    const float* LL = wl_lvl == 0 ? l0 : wl_lvl == 1 ? l1 : wl_lvl == 2 ? l2 : l3;
-    const int t_lvl = ch < 36 ? ch / 9 : 0, t_kk = ch < 36 ? ch - (ch / 9) * 9 : 0;      // tap role
-    const int WlT = W >> t_lvl;
-    const float* LT = t_lvl == 0 ? l0 : t_lvl == 1 ? l1 : t_lvl == 2 ? l2 : l3;
-    float fx[LK_PX], fy[LK_PX], win[LK_PX];
-    int wbase[LK_PX];
-#pragma unroll
-    for (int q = 0; q < LK_PX; ++q) {
-        const int64_t p = p0 + q < P ? p0 + q : P - 1;
-        if (flow_nhwc) {
-            fx[q] = flow[p * 2];
-            fy[q] = flow[p * 2 + 1];
-        } else {
-            const int64_t frame = p / hw, rem = p - frame * hw;
-            fx[q] = flow[frame * 2 * hw + rem];
-            fy[q] = flow[(frame * 2 + 1) * hw + rem];
-        }
+    const int64_t frame = p / hw;
+    const int64_t rem = p - frame * hw;
+    float fx, fy;
+    if (flow_nhwc) {
+        fx = flow[p * 2];
+        fy = flow[p * 2 + 1];
+    } else {
+        fx = flow[frame * 2 * hw + rem];
+        fy = flow[(frame * 2 + 1) * hw + rem];
     }
-#pragma unroll
-    for (int q = 0; q < LK_PX; ++q) {
-        const int64_t p = p0 + q < P ? p0 + q : P - 1;
-        const float xs = (float)(int)(p % W) + fx[q];
-        // window of level wl_lvl: cells floor(xs / 2^l) - 5 ... + 6 (taps reach -4 ... +5; one cell of slack on both sides)
-        float c = floorf(xs / (float)(1 << wl_lvl));
-        c = c < -1.0e6f ? -1.0e6f : (c > 1.0e6f ? 1.0e6f : c);                   // (NaN / huge flows: every tap is out of range anyway)
-        const int wb = (int)c - 5;
-        const int cell = wb + wl_j;
-        win[q] = (wl_j < 12 && cell >= 0 && cell < WlL) ? LL[p * WlL + cell] : 0.0f;
-        // the tap lanes need the base of THEIR level's window: recompute it (same arithmetic, wave-uniform per level)
-        float ct = floorf(xs / (float)(1 << t_lvl));
-        ct = ct < -1.0e6f ? -1.0e6f : (ct > 1.0e6f ? 1.0e6f : ct);
-        wbase[q] = (int)ct - 5;
+    float v = 0.0f;
+    if (ch < 36) {
+        const int lvl = ch / 9, kk = ch - lvl * 9;
+        const int Wl = W >> lvl;
+        const float* L = (lvl == 0 ? l0 : lvl == 1 ? l1 : lvl == 2 ? l2 : l3) + p * Wl;
+        v = lookup_tap(L, Wl, (float)x + fx, lvl, kk);
     }
-#pragma unroll
-    for (int q = 0; q < LK_PX; ++q) {
-        const int64_t p = p0 + q;
-        const float xs = (float)(int)((p < P ? p : P - 1) % W) + fx[q];
-        // the reference's op sequence for the sampling position (lookup_tap)
-        const float pos = (float)(t_kk - 4) + xs / (float)(1 << t_lvl);
-        const float wm1 = (float)(WlT - 1);
-        const float g = 2.0f * pos / wm1 - 1.0f;
-        const float pp = ((g + 1.0f) / 2.0f) * wm1;
-        const float pf = floorf(pp);
-        const float a = pp - pf;
-        const bool inr = pf >= -1.0f && pf <= (float)WlT;
-        const int i0 = inr ? (int)pf : 0;
-        const int o0 = i0 - wbase[q], o1 = o0 + 1;
-        const float s0 = __shfl(win[q], t_lvl * 16 + (o0 & 15)), s1 = __shfl(win[q], t_lvl * 16 + (o1 & 15));     // (all lanes take part)
-        float v0 = s0, v1 = s1;
-        if (o0 < 0 || o0 > 11) v0 = (i0 >= 0 && i0 < WlT && p < P) ? LT[p * WlT + i0] : 0.0f;                     // outside the staged window
-        if (o1 < 0 || o1 > 11) v1 = (i0 + 1 >= 0 && i0 + 1 < WlT && p < P) ? LT[p * WlT + i0 + 1] : 0.0f;
-        float v = (ch < 36 && inr) ? (1.0f - a) * v0 + a * v1 : 0.0f;
-        if (p < P) {
-            bf16_t h, l;
-            split_bf16(v, h, l);
-            ohi[p * out_ld + ch] = h;
-            olo[p * out_ld + ch] = l;
-            if (fhi != nullptr && (ch == 36 || ch == 37)) {
-                split_bf16(ch == 36 ? fx[q] : fy[q], h, l);
-                fhi[p * f_ld + (ch - 36)] = h;
-                flo[p * f_ld + (ch - 36)] = l;
-            }
-        }
+    bf16_t h, l;
+    split_bf16(v, h, l);
+    ohi[p * out_ld + ch] = h;
+    olo[p * out_ld + ch] = l;
+    if (fhi != nullptr && (ch == 36 || ch == 37)) {
+        split_bf16(ch == 36 ? fx : fy, h, l);
+        fhi[p * f_ld + (ch - 36)] = h;
+        flo[p * f_ld + (ch - 36)] = l;
     }
 }
 
@@ -224,7 +182,7 @@ extern "C" int ppms_corr_lookup(const float* const pyr[4], const float* flow, in
     const int64_t P = (int64_t)B * H * W;
     if (out_hi != nullptr) {
         PPMS_REQUIRE(out_lo != nullptr && out_ld >= 64, "corr_lookup: SP output needs lo plane and ld >= 64");
-        hipLaunchKernelGGL(corr_lookup_sp_kernel, dim3(ceil_div(P, 4 * LK_PX)), dim3(256), 0, (hipStream_t)stream, pyr[0], pyr[1], pyr[2], pyr[3],
+        hipLaunchKernelGGL(corr_lookup_sp_kernel, dim3(ceil_div(P, 4)), dim3(256), 0, (hipStream_t)stream, pyr[0], pyr[1], pyr[2], pyr[3],
                            flow, flow_nhwc, (bf16_t*)out_hi, (bf16_t*)out_lo, out_ld, (bf16_t*)flow_sp_hi, (bf16_t*)flow_sp_lo,
                            flow_sp_ld, H, W, P);
     }
