@@ -41,7 +41,8 @@ TUNING = dict(
     win2d=False,          # conv_gemm2: 2-D window for kh, kw > 1 (measured neutral to slower)
     slices=True,          # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
     hoist=True,           # iteration-invariant inp share of the GRU gates computed once per scale
-    conv5_pad2x=True,     # conv_gemm5 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128)
+    conv5_pad2x=False,    # conv_gemm5 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 78 us instead of 65 + 143 us
+                          # of the K-sliced form, but on the side stream it then competes with convc2 for whole CUs: clip time unchanged, 40.8 ms)
 )
 
 
@@ -461,7 +462,6 @@ class ScaleEngine:
         if m_split is None:
             d4.m_split = meta4["M"]
         real = d4.epi[0].n_valid + (d4.epi[1].n_valid if d4.m_split < d4.M else 0)
-        # (couts padded up to 2x are still worth it: convf2's 64 couts on 128 rows run in 55 us against 65 + 143 us of the K-sliced small-map form)
         if TUNING["conv5"] and (2 * real > meta4["M"] or (TUNING["conv5_pad2x"] and 2 * real == meta4["M"])) and self.lib.ppms_conv_gemm5_applicable(C.byref(d4)):
             return ConvOp(d4, [packed4, bias4, *keep], 5, device=self.dev)
         if TUNING["conv5"] and TUNING["conv5_sliced"] and 2 * real > meta4["M"]:
