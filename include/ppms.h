@@ -24,7 +24,7 @@ extern "C" {
 #define PPMS_ELAUNCH (-2)  /* HIP launch error */
 #define PPMS_ENODEV (-3)   /* no gfx950 device */
 
-#define PPMS_ABI_VERSION 2
+#define PPMS_ABI_VERSION 3
 
 int ppms_version(void);
 const char* ppms_last_error(void);

@@ -129,7 +129,7 @@ def load() -> C.CDLL:
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.ppms_version() != 2:
+    if lib.ppms_version() != 3:
         raise RuntimeError("ppmstereo_amd: libppms.so ABI version mismatch")
     a, b, c = c_int(), c_int(), c_int()
     lib.ppms_struct_sizes(C.byref(a), C.byref(b), C.byref(c))
