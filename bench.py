@@ -280,7 +280,7 @@ def main():
         D.barrier()
         all_ms = D.max_over_ranks(time.perf_counter() - t_all) / n_all * 1e3
     encoders = None
-    if not args.no_encoders and rank == 0 and not sharded and (T, H, W) == (5, 320, 512):
+    if not args.no_encoders and world == 1 and (T, H, W) == (5, 320, 512):      # (N > 1: the ranks time their clips only)
         # SURVEY 8 rows f3-f5 on the same clip geometry: fnet on the 2T images, cnet on the T left images, SST on the 1/16 features
         from ppmstereo_amd.cnet import Feature
         from ppmstereo_amd.encoder import BasicEncoder
