@@ -41,6 +41,7 @@ TUNING = dict(
     win2d=False,          # conv_gemm2: 2-D window for kh, kw > 1 (measured neutral to slower)
     slices=True,          # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
     hoist=True,           # iteration-invariant inp share of the GRU gates computed once per scale
+    gemm1=True,           # thin-GEMM kernel (gemm1.hip) for the 1x1 convolutions / Linear layers it serves
     conv5_pad2x=False,    # conv_gemm5 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 78 us instead of 65 + 143 us
                           # of the K-sliced form, but on the side stream it then competes with convc2 for whole CUs: clip time unchanged, 40.8 ms)
 )
@@ -120,6 +121,8 @@ class ConvOp:
             L.check(L.load().ppms_conv_gemm5_sliced(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, self.nslice, self.ws.data_ptr(), L.stream_ptr()))
         elif self.version == 5:
             L.check(L.load().ppms_conv_gemm5(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
+        elif self.version == 6:
+            L.check(L.load().ppms_gemm1(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
         elif self.ysweep:
             L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
         elif self.nslice > 1:
@@ -206,10 +209,15 @@ class PackedBlock:
         self.w: Dict[str, tuple] = {}
 
         self.w4: Dict[str, tuple] = {}             # conv_gemm5 packs (MFMA-fragment order, sweep-ordered taps, M padded to 128)
+        self.w1: Dict[str, tuple] = {}             # gemm1 packs of the 1x1 convolutions (MFMA A-operand images per 32 couts x 16 channels)
 
         def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
             self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
             w5 = weight if weight.dim() == 5 else weight[:, :, None]
+            if TUNING["gemm1"] and tuple(w5.shape[2:]) == (1, 1, 1) and not name.endswith(("_y", "_p")):
+                meta2 = self.w[name][2]
+                if sum(meta2["seg_padded"]) % 64 == 0:
+                    self.w1[name] = _packing.pack_gemm1(weight, bias, segs, meta2["seg_padded"], cout_map, meta2["M"])
             sweep = w5                                                     # x sweep: natural order
             if w5.shape[3] > 1 and w5.shape[4] > 1:
                 # k-step order of the 2-D window sweep: (ky, kx) flattened into the x axis
@@ -430,6 +438,12 @@ class ScaleEngine:
         if epi1 is not None:
             d.epi[1] = epi1
         version = 2
+        if TUNING["gemm1"] and isinstance(wname, str) and tuple(k3) == (1, 1, 1) and wname in self.pk.w1:
+            packed1, bias1, _ = self.pk.w1[wname]
+            d1 = L.Conv.from_buffer_copy(bytes(d))
+            d1.w, d1.bias = packed1.data_ptr(), bias1.data_ptr()
+            if self.lib.ppms_gemm1_applicable(C.byref(d1)):
+                return ConvOp(d1, [packed1, bias1, *keep], 6, device=self.dev)
         if isinstance(wname, str):
             op = self._try_fragment_kernels(wname, d, m_split, keep)
             if op is not None:

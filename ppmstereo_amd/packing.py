@@ -114,6 +114,51 @@ def pack_conv4(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
     return packed.reshape(-1), b, meta
 
 
+def pack_gemm1(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
+               seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
+               m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+    """Layout of the thin-GEMM kernel for 1x1 convolutions (ppmstereo_amd/csrc/gemm1.hip): per (32-cout block, k16-step, plane) the
+    1 KiB MFMA A-operand image, so that a wave loads every fragment of its K slice with one 16-byte request per lane:
+        bf16 [M/32][K/16][plane (hi, lo)][lane = 32*h + r][8] = W[cout = 32*blk + r][k = 16*step + 8*h + j].
+    The input segments are concatenated along K, each zero-padded to a multiple of 16 channels."""
+    w = weight.detach().float()
+    w = w.reshape(w.shape[0], w.shape[1], -1)
+    assert w.shape[2] == 1, "pack_gemm1: 1x1 kernels only"
+    w = w[:, :, 0]
+    cout, cin = w.shape
+    assert sum(seg_channels) == cin, (seg_channels, cin)
+    seg_padded = [_pad_to(c, 16) for c in seg_channels] if seg_padded is None else list(seg_padded)
+    assert all(p % 16 == 0 and p >= c for p, c in zip(seg_padded, seg_channels))
+    cpad = sum(seg_padded)
+    rows = list(range(cout)) if cout_map is None else list(cout_map)
+    M = _pad_to(max(rows) + 1, 32) if m_pad is None else m_pad
+    assert M % 32 == 0 and max(rows) < M
+    full = torch.zeros(M, cpad, dtype=torch.float32, device=w.device)
+    ridx = torch.tensor(rows, device=w.device)
+    src = dst = 0
+    for c, p in zip(seg_channels, seg_padded):
+        full[ridx, dst:dst + c] = w[:, src:src + c]
+        src += c
+        dst += p
+    nk = cpad // 16
+    t = full.reshape(M // 32, 32, nk, 2, 8).permute(0, 2, 3, 1, 4).contiguous()          # [blk][step][h][r][j]
+    t = t.reshape(M // 32, nk, 64, 8)
+    hi, lo = split_bf16(t)
+    packed = torch.stack([hi, lo], dim=2).contiguous()                                   # [blk][step][plane][lane][8]
+    b = torch.zeros(M, dtype=torch.float32, device=w.device)
+    if bias is not None:
+        b[ridx] = bias.detach().float()
+    meta = dict(M=M, nk=nk, taps=(1, 1, 1), cpad=cpad, seg_padded=seg_padded, version=6)
+    return packed.reshape(-1), b, meta
+
+
+def unpack_gemm1_reference(packed: torch.Tensor, M: int, nk: int) -> torch.Tensor:
+    """Inverse of pack_gemm1 -> fp32 [M][K], for the host-logic tests."""
+    t = packed.reshape(M // 32, nk, 2, 2, 32, 8).float()                                 # [blk][step][plane][h][r][j]
+    t = t[:, :, 0] + t[:, :, 1]                                                           # [blk][step][h][r][j]
+    return t.permute(0, 3, 1, 2, 4).reshape(M, nk * 16)
+
+
 def unpack_conv4_reference(packed: torch.Tensor, M: int, nk: int, taps, nchunk: int) -> torch.Tensor:
     """Inverse of pack_conv4 -> fp32 [M][K] in the plain K order (k = tap*Cpad + ci), for the host-logic tests."""
     kt, kh, kw = taps

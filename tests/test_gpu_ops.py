@@ -78,7 +78,8 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     tile_px = 0
     if version in (5, 5007, 5008):                                         # conv_gemm5; 5007 / 5008 force the blocks per tile
         tile_px, version = (0 if version == 5 else version - 5000), 5
-    pack_conv = pack_conv4 if version == 5 else pack_conv2
+    from ppmstereo_amd.packing import pack_gemm1
+    pack_conv = pack_conv4 if version == 5 else pack_gemm1 if version == 6 else pack_conv2
     P = T * H * W
     segs, keep = [], []
     seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
@@ -223,6 +224,89 @@ def test_conv_gemm3_vs_torch(lib, name, T, H, W, segs, cout, k3):
     z = torch.sigmoid(hash_normal((P, cout), 304))
     got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=3, kind=lib.EPI_GRU, aux=aux, z=z)
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
+GEMM1_CASES = [
+    # name, T,H,W, segs, cout, M-pad
+    ("to_v_like", 2, 8, 32, [128], 128),
+    ("fh2_like_54_of_64", 3, 5, 40, [256], 54),
+    ("block16_384", 5, 20, 32, [384], 384),
+    ("two_segments_768", 2, 6, 10, [384, 384], 768),
+    ("k768_to_384", 1, 7, 9, [768], 384),
+    ("ragged_pixels", 1, 3, 11, [128], 96),
+    ("mask_tail_144", 2, 8, 16, [256], 144),
+]
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout", GEMM1_CASES)
+def test_gemm1_vs_torch(lib, name, T, H, W, segs, cout):
+    """The thin-GEMM kernel of the 1x1 convolutions (gemm1.hip: K split over the four waves of a workgroup, operands straight to registers,
+    LDS reduction in wave order, shared row epilogue) against torch: one and two segments, every K it serves, padded / ragged couts, pixel
+    counts that are not multiples of the 32-pixel tile, the epilogue kinds, and bit-identical results from run to run."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, 1, 1, 1), 200) / math.sqrt(cin)
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, (1, 1, 1), T, H, W)
+    got = _run_conv(lib, xs, wt, bs, (1, 1, 1), T, H, W, version=6)
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    assert torch.equal(got, _run_conv(lib, xs, wt, bs, (1, 1, 1), T, H, W, version=6))
+    assert maxdiff(got, _run_conv(lib, xs, wt, bs, (1, 1, 1), T, H, W, version=2)) < 2e-5 * max(1.0, ref.abs().max().item())
+    aux = hash_normal((P, cout), 303)
+    L = lib
+    assert maxdiff(_run_conv(L, xs, wt, bs, (1, 1, 1), T, H, W, version=6, kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + ref)) < 5e-5 * max(1.0, ref.abs().max().item())
+    assert maxdiff(_run_conv(L, xs, wt, bs, (1, 1, 1), T, H, W, version=6, act=L.ACT_ELU1), F.elu(ref) + 1) < 5e-5 * max(1.0, ref.abs().max().item())
+    assert maxdiff(_run_conv(L, xs, wt, None, (1, 1, 1), T, H, W, version=6, scale=0.25), 0.25 * (ref - bs)) < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("T,H,W", [(2, 8, 32), (3, 23, 40), (1, 5, 7)])
+def test_gemm1_two_halves_and_transposed_v(lib, T, H, W):
+    """Two epilogue halves in one launch (the linear attention's q | k and v projections: rows 0..767 elu + 1 -> fp32, rows 768..1151
+    scaled -> fp32) and the attention's transposed bf16 V operand (to_v: SP output + V^T [frame][128][H*W], with H*W a multiple of 32 --
+    16-byte row pieces -- and not)."""
+    from ppmstereo_amd.engine import ConvOp, epilogue
+    from ppmstereo_amd.packing import pack_gemm1
+    L = lib
+    P = T * H * W
+    x = hash_normal((P, 384), 410)
+    xt = L.SPTensor(P, 384, DEV)
+    xt.set_f32(x.to(DEV))
+    wq = hash_normal((1152, 384, 1, 1), 411) / math.sqrt(384)
+    packed, b, meta = pack_gemm1(wq.to(DEV), None, [384])
+    qkf, vf = torch.zeros(P, 768, device=DEV), torch.zeros(P, 384, device=DEV)
+    d = L.Conv()
+    d.seg[0] = xt.view()
+    d.nseg, d.w, d.bias = 1, packed.data_ptr(), b.data_ptr()
+    d.T, d.H, d.W, d.kt, d.kh, d.kw = T, H, W, 1, 1, 1
+    d.M, d.m_split = 1152, 768
+    d.epi[0] = epilogue(act=L.ACT_ELU1, n_valid=768, out_f32=qkf, out_f32_ld=768)
+    d.epi[1] = epilogue(scale=0.5, n_valid=384, out_f32=vf, out_f32_ld=384)
+    assert L.load().ppms_gemm1_applicable(C.byref(d)) == 1
+    ConvOp(d, [xt, packed, b, qkf, vf], 6)()
+    torch.cuda.synchronize()
+    ref = x @ wq[:, :, 0, 0].t()
+    assert maxdiff(qkf, F.elu(ref[:, :768]) + 1) < 5e-5 * ref.abs().max().item() and maxdiff(vf, 0.5 * ref[:, 768:]) < 5e-5 * ref.abs().max().item()
+    # to_v: SP + V^T
+    x2 = hash_normal((P, 128), 420)
+    x2t = L.SPTensor(P, 128, DEV)
+    x2t.set_f32(x2.to(DEV))
+    wv = hash_normal((128, 128, 1, 1), 421) / math.sqrt(128)
+    packed, b, meta = pack_gemm1(wv.to(DEV), None, [128])
+    out = L.SPTensor(P, 128, DEV)
+    vt = torch.zeros(T, 128, H * W, dtype=torch.bfloat16, device=DEV)
+    d = L.Conv()
+    d.seg[0] = x2t.view()
+    d.nseg, d.w, d.bias = 1, packed.data_ptr(), b.data_ptr()
+    d.T, d.H, d.W, d.kt, d.kh, d.kw = T, H, W, 1, 1, 1
+    d.M = d.m_split = 128
+    d.epi[0] = epilogue(n_valid=128, out_sp=out.view(), out_vt=vt)
+    ConvOp(d, [x2t, packed, b, out, vt], 6)()
+    torch.cuda.synchronize()
+    y = out.to_f32()
+    assert maxdiff(y, x2 @ wv[:, :, 0, 0].t()) < 3e-5 * 4
+    want = y.to(torch.bfloat16).reshape(T, H * W, 128).permute(0, 2, 1)
+    assert torch.equal(vt, want), "V^T must be the bf16 rounding of the SP output, transposed"
 
 
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3,nslice", [

@@ -294,3 +294,23 @@ def test_corr_build_workgroup_order_is_a_bijection():
     for ntx in (1, 2, 3, 4, 5, 8, 10, 40):
         for nrow in (1, 7, 8, 9, 15, 16, 100, 230, 400):
             remap(ntx, nrow)
+
+
+def test_pack_gemm1_round_trip():
+    """pack_gemm1 (gemm1.hip: [M/32][K/16][hi, lo][lane][8], the MFMA A-operand image) unpacks to the same [M][K] matrix as the weights it was
+    given: two segments with padding, a cout map, padded rows."""
+    from ppmstereo_amd.packing import pack_gemm1, unpack_gemm1_reference
+    from ppmstereo_amd.weights import hash_normal
+    w = hash_normal((54, 36 + 100, 1, 1), 77)
+    packed, b, meta = pack_gemm1(w, hash_normal((54,), 78), [36, 100], [48, 112], None, 64)
+    assert meta["M"] == 64 and meta["nk"] == 10 and packed.numel() == 2 * 64 * 160
+    full = unpack_gemm1_reference(packed, 64, 10)
+    want = torch.zeros(64, 160)
+    want[:54, :36] = w[:, :36, 0, 0]
+    want[:54, 48:148] = w[:, 36:, 0, 0]
+    assert (full - want).abs().max() < 2e-5 * want.abs().max()          # hi + lo of a bf16 split: 16 mantissa bits
+    assert b.shape == (64,) and (b[54:] == 0).all()
+    rows = list(range(0, 40, 2))
+    packed, b, meta = pack_gemm1(hash_normal((20, 64, 1, 1), 79), None, [64], None, rows)
+    full = unpack_gemm1_reference(packed, meta["M"], meta["nk"])
+    assert meta["M"] == 64 and (full[1::2][:20] == 0).all() and full[0::2][:20].abs().max() > 0
