@@ -60,7 +60,7 @@ _SIGS = {
     "ppms_conv_gemm3_applicable": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm3": (c_int, [C.POINTER(Conv), c_void_p, c_void_p]),
     "ppms_gemm1_applicable": (c_int, [C.POINTER(Conv)]),
-    "ppms_gemm1": (c_int, [C.POINTER(Conv), c_void_p, c_void_p]),
+    "ppms_gemm1": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
     "ppms_conv_gemm5_applicable": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm5": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
     "ppms_conv_gemm5_slices": (c_int, [C.POINTER(Conv)]),

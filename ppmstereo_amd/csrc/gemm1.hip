@@ -171,7 +171,7 @@ struct Plan1 {
 // K = 64 NS with NS in {2, 4, 6, 12}; CB in {4, 2, 1}: the largest that divides the cout blocks, keeps a workgroup inside one epilogue
 // half, fits the register budget (CB NS <= 16) and still leaves >= 512 workgroups (small maps want parallelism, large maps want the
 // activations read once)
-bool plan1(const ppms_conv* d, Plan1& pl) {
+bool plan1(const ppms_conv* d, Plan1& pl, int cb_hint = 0) {
     if (d == nullptr || d->kt != 1 || d->kh != 1 || d->kw != 1 || d->nseg < 1 || d->nseg > 2) return false;
     if (d->M <= 0 || d->M % 32 != 0 || d->w == nullptr || d->bias == nullptr) return false;
     int K = 0;
@@ -182,7 +182,9 @@ bool plan1(const ppms_conv* d, Plan1& pl) {
     }
     if (K % 64 != 0) return false;
     const int ns = K / 64;
-    if (ns != 2 && ns != 4 && ns != 6 && ns != 12) return false;
+    // (K = 768, i.e. 12 steps per wave, was built and measured: 48 operand requests per lane cost the occupancy that hides them -- the
+    // 768 -> 768 Linear of update_block16 took 48 us against 45 us for the K-sliced implicit GEMM + reduce -- so such layers stay there)
+    if (ns != 2 && ns != 4 && ns != 6) return false;
     const bool two = d->m_split < d->M;
     if (two && d->m_split % 32 != 0) return false;
     const int64_t P = (int64_t)d->T * d->H * d->W;
@@ -194,7 +196,7 @@ bool plan1(const ppms_conv* d, Plan1& pl) {
         if (mblocks % cb || cb * ns > 16) continue;
         if (two && d->m_split % (32 * cb)) continue;
         best = cb;                                             // legal; keep shrinking while that leaves too few workgroups
-        if (tiles * (mblocks / cb) >= 512) break;
+        if (cb_hint > 0 ? cb <= cb_hint : tiles * (mblocks / cb) >= 512) break;
     }
     if (best == 0) return false;
     for (int hlf = 0; hlf < 2; ++hlf) {
@@ -227,15 +229,16 @@ extern "C" int ppms_gemm1_applicable(const ppms_conv* d) {
     return plan1(d, pl) ? 1 : 0;
 }
 
-extern "C" int ppms_gemm1(const ppms_conv* d, const ppms_conv* dev_desc, void* stream) {
+extern "C" int ppms_gemm1(const ppms_conv* d, const ppms_conv* dev_desc, int cb_hint, void* stream) {
     (void)dev_desc;
     Plan1 pl;
-    PPMS_REQUIRE(plan1(d, pl), "gemm1: not a 1x1 convolution this kernel serves (K = 128 / 256 / 384 / 768 in 16-channel-aligned segments, M %% 32 == 0, "
+    PPMS_REQUIRE(cb_hint == 0 || cb_hint == 1 || cb_hint == 2 || cb_hint == 4, "gemm1: cb_hint must be 0 (choose), 1, 2 or 4");
+    PPMS_REQUIRE(plan1(d, pl, cb_hint), "gemm1: not a 1x1 convolution this kernel serves (K = 128 / 256 / 384 in 16-channel-aligned segments, M %% 32 == 0, "
                                "pack_gemm1 weights, aligned SP operands; ppms_gemm1_applicable tells)");
     hipStream_t st = (hipStream_t)stream;
 #define G1_CASE(CBV, NSV) \
     if (pl.cb == CBV && pl.ns == NSV) return launch1<CBV, NSV>(d, pl, st);
-    G1_CASE(4, 2) G1_CASE(4, 4) G1_CASE(2, 2) G1_CASE(2, 4) G1_CASE(2, 6) G1_CASE(1, 2) G1_CASE(1, 4) G1_CASE(1, 6) G1_CASE(1, 12)
+    G1_CASE(4, 2) G1_CASE(4, 4) G1_CASE(2, 2) G1_CASE(2, 4) G1_CASE(2, 6) G1_CASE(1, 2) G1_CASE(1, 4) G1_CASE(1, 6)
 #undef G1_CASE
     ppms_set_error("gemm1: no instantiation for CB=%d NS=%d", pl.cb, pl.ns);
     return PPMS_EINVAL;

@@ -122,7 +122,7 @@ class ConvOp:
         elif self.version == 5:
             L.check(L.load().ppms_conv_gemm5(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         elif self.version == 6:
-            L.check(L.load().ppms_gemm1(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
+            L.check(L.load().ppms_gemm1(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         elif self.ysweep:
             L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
         elif self.nslice > 1:

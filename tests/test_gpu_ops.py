@@ -231,8 +231,7 @@ GEMM1_CASES = [
     ("to_v_like", 2, 8, 32, [128], 128),
     ("fh2_like_54_of_64", 3, 5, 40, [256], 54),
     ("block16_384", 5, 20, 32, [384], 384),
-    ("two_segments_768", 2, 6, 10, [384, 384], 768),
-    ("k768_to_384", 1, 7, 9, [768], 384),
+    ("two_segments_384", 2, 6, 10, [256, 128], 768),
     ("ragged_pixels", 1, 3, 11, [128], 96),
     ("mask_tail_144", 2, 8, 16, [256], 144),
 ]
