@@ -146,6 +146,7 @@ int ppms_conv_gemm5_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int
  * 16-channel-aligned segments, M % 32 == 0, weights in the pack_gemm1 layout ([M/32][K/16][hi, lo][lane][8]: the MFMA A-operand image).
  * One workgroup = four waves that split K between them, both operands straight to registers, partial tiles summed through LDS in wave
  * order, the shared row epilogue (every kind but ADDF32; out_vt with a STORE epilogue): one memory round trip deep, no slices. */
+/* 0: not served; 1: served and the faster choice (maps of <= 16 384 pixels, or <= 64 couts); 2: served, the implicit GEMM is as fast */
 int ppms_gemm1_applicable(const ppms_conv* desc);
 /* cb_hint: 32-cout blocks per workgroup (1, 2, 4), 0 = let the library choose from the grid size */
 int ppms_gemm1(const ppms_conv* desc, const ppms_conv* dev_desc, int cb_hint, void* stream);

@@ -168,9 +168,8 @@ struct Plan1 {
     int cb, ns, nk;
 };
 
-// K = 64 NS with NS in {2, 4, 6, 12}; CB in {4, 2, 1}: the largest that divides the cout blocks, keeps a workgroup inside one epilogue
-// half, fits the register budget (CB NS <= 16) and still leaves >= 512 workgroups (small maps want parallelism, large maps want the
-// activations read once)
+// K = 64 NS with NS in {2, 4, 6}; CB (32-cout blocks per workgroup): 2 when that divides the cout blocks and keeps a workgroup inside
+// one epilogue half, else 1 (measured at config 2's sizes, tools/gemm1_probe.py: 2 is best or tied everywhere, 4 gains nothing).
 bool plan1(const ppms_conv* d, Plan1& pl, int cb_hint = 0) {
     if (d == nullptr || d->kt != 1 || d->kh != 1 || d->kw != 1 || d->nseg < 1 || d->nseg > 2) return false;
     if (d->M <= 0 || d->M % 32 != 0 || d->w == nullptr || d->bias == nullptr) return false;
@@ -191,12 +190,13 @@ bool plan1(const ppms_conv* d, Plan1& pl, int cb_hint = 0) {
     if (P <= 0 || P >= (1ll << 31)) return false;
     const int64_t tiles = (P + 31) / 32;
     const int mblocks = d->M / 32;
+    (void)tiles;
     int best = 0;
-    for (int cb = 4; cb >= 1; cb >>= 1) {
+    for (int cb = (cb_hint > 0 ? cb_hint : 2); cb >= 1; cb >>= 1) {
         if (mblocks % cb || cb * ns > 16) continue;
         if (two && d->m_split % (32 * cb)) continue;
-        best = cb;                                             // legal; keep shrinking while that leaves too few workgroups
-        if (cb_hint > 0 ? cb <= cb_hint : tiles * (mblocks / cb) >= 512) break;
+        best = cb;
+        break;
     }
     if (best == 0) return false;
     for (int hlf = 0; hlf < 2; ++hlf) {
@@ -224,9 +224,16 @@ int launch1(const ppms_conv* d, const Plan1& pl, hipStream_t st) {
 
 }  // namespace
 
+// 1: this kernel serves the convolution AND is the faster choice.  Measured (tools/gemm1_probe.py, profiles/r03_gemm1_probe.txt): on maps of
+// <= 16 384 pixels (the 1/8 and 1/16 scales of every BASELINE configuration at 320x512, the 1/16 scale at 736x1280) it halves the launch
+// (to_v 16 -> 8 us, 15 -> 7 us; 384 -> 384 Linear 17.5 -> 10.7 us; 384 -> 1152 38.8 -> 24.1 us incl. the slice reduce it makes unnecessary);
+// on the 51 200-pixel map it ties with the implicit GEMM (to_v 25.5 / 25.6 us, convf1 19.7 / 19.2) except for narrow outputs (the flow head's
+// 256 -> 54: 21 against 37 us) and loses on wide ones (256 -> 144: 46 against 42 us).  2: it serves it but the implicit GEMM is as fast.
 extern "C" int ppms_gemm1_applicable(const ppms_conv* d) {
     Plan1 pl;
-    return plan1(d, pl) ? 1 : 0;
+    if (!plan1(d, pl)) return 0;
+    const int64_t P = (int64_t)d->T * d->H * d->W;
+    return (P <= 16384 || d->M <= 64) ? 1 : 2;
 }
 
 extern "C" int ppms_gemm1(const ppms_conv* d, const ppms_conv* dev_desc, int cb_hint, void* stream) {

@@ -442,7 +442,7 @@ class ScaleEngine:
             packed1, bias1, _ = self.pk.w1[wname]
             d1 = L.Conv.from_buffer_copy(bytes(d))
             d1.w, d1.bias = packed1.data_ptr(), bias1.data_ptr()
-            if self.lib.ppms_gemm1_applicable(C.byref(d1)):
+            if self.lib.ppms_gemm1_applicable(C.byref(d1)) == 1:          # (2: served, but the implicit GEMM is as fast on a map this large)
                 return ConvOp(d1, [packed1, bias1, *keep], 6, device=self.dev)
         if isinstance(wname, str):
             op = self._try_fragment_kernels(wname, d, m_split, keep)

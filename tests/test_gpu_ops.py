@@ -281,7 +281,7 @@ def test_gemm1_two_halves_and_transposed_v(lib, T, H, W):
     d.M, d.m_split = 1152, 768
     d.epi[0] = epilogue(act=L.ACT_ELU1, n_valid=768, out_f32=qkf, out_f32_ld=768)
     d.epi[1] = epilogue(scale=0.5, n_valid=384, out_f32=vf, out_f32_ld=384)
-    assert L.load().ppms_gemm1_applicable(C.byref(d)) == 1
+    assert L.load().ppms_gemm1_applicable(C.byref(d)) in (1, 2)
     ConvOp(d, [xt, packed, b, qkf, vf], 6)()
     torch.cuda.synchronize()
     ref = x @ wq[:, :, 0, 0].t()
