@@ -142,7 +142,7 @@ int ppms_conv_gemm5(const ppms_conv* desc, const ppms_conv* dev_desc, int nbt, v
  * epilogue (bit-reproducible).  ppms_conv_gemm5_slices: the slice count that fills the chip in one round, 0 = not applicable. */
 int ppms_conv_gemm5_slices(const ppms_conv* desc);
 int ppms_conv_gemm5_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int nbt, int nslice, void* workspace, void* stream);
-/* Thin GEMM for 1x1 convolutions / Linear layers (gemm1.hip): kt = kh = kw = 1, K = 128 / 256 / 384 input channels in one or two
+/* Thin GEMM for 1x1 convolutions / Linear layers (gemm1.hip): kt = kh = kw = 1, K = 128 / 192 / 256 / 384 / 512 input channels in one or two
  * 16-channel-aligned segments, M % 32 == 0, weights in the pack_gemm1 layout ([M/32][K/16][hi, lo][lane][8]: the MFMA A-operand image).
  * One workgroup = four waves that split K between them, both operands straight to registers, partial tiles summed through LDS in wave
  * order, the shared row epilogue (every kind but ADDF32; out_vt with a STORE epilogue): one memory round trip deep, no slices. */

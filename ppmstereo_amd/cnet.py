@@ -14,6 +14,7 @@ nearest upsampling and InstanceNorm are small kernels of encoder_ops.hip.  108 b
 from __future__ import annotations
 
 from collections import OrderedDict
+import ctypes as C
 from typing import Dict, List, Optional
 
 import torch
@@ -106,6 +107,8 @@ class Feature(nn.Module):
                 w4 = w4[:, :, None, None]
             packed, bias, meta = _packing.pack_conv2(w4, b.detach().to(device), segs, pads if pads is not None else [((c + 31) // 32) * 32 for c in segs])
             pk[name] = (packed, bias, meta, tuple(w4.shape[2:]))
+            if tuple(w4.shape[2:]) == (1, 1) and sum(meta["seg_padded"]) % 64 == 0:          # 1x1 layers the thin-GEMM kernel may serve (gemm1.hip)
+                pk[name + "@1"] = _packing.pack_gemm1(w4, b.detach().to(device), segs, meta["seg_padded"], None, meta["M"])
 
         def v(name, t):
             vec[name] = t.detach().float().reshape(-1).to(device).contiguous()
@@ -199,6 +202,13 @@ class _CnetEngine:
             dd.M = dd.m_split = meta["M"]
             assert [t.c for t in segs] == list(meta["seg_padded"]), (name, [t.c for t in segs], meta["seg_padded"])
             dd.epi[0] = e0
+            if name + "@1" in pk:
+                p1, b1, _ = pk[name + "@1"]
+                d1 = L.Conv.from_buffer_copy(bytes(dd))
+                d1.w, d1.bias = p1.data_ptr(), b1.data_ptr()
+                if lib.ppms_gemm1_applicable(C.byref(d1)) == 1:
+                    self.steps.append(ConvOp(d1, [p1, b1], 6, device=device))
+                    return
             self.steps.append(ConvOp(dd, [packed_w, bias], 2, device=device))
 
         def call(fn):

@@ -168,7 +168,7 @@ struct Plan1 {
     int cb, ns, nk;
 };
 
-// K = 64 NS with NS in {2, 4, 6}; CB (32-cout blocks per workgroup): 2 when that divides the cout blocks and keeps a workgroup inside
+// K = 64 NS with NS in {2, 3, 4, 6, 8}; CB (32-cout blocks per workgroup): 2 when that divides the cout blocks and keeps a workgroup inside
 // one epilogue half, else 1 (measured at config 2's sizes, tools/gemm1_probe.py: 2 is best or tied everywhere, 4 gains nothing).
 bool plan1(const ppms_conv* d, Plan1& pl, int cb_hint = 0) {
     if (d == nullptr || d->kt != 1 || d->kh != 1 || d->kw != 1 || d->nseg < 1 || d->nseg > 2) return false;
@@ -183,7 +183,7 @@ bool plan1(const ppms_conv* d, Plan1& pl, int cb_hint = 0) {
     const int ns = K / 64;
     // (K = 768, i.e. 12 steps per wave, was built and measured: 48 operand requests per lane cost the occupancy that hides them -- the
     // 768 -> 768 Linear of update_block16 took 48 us against 45 us for the K-sliced implicit GEMM + reduce -- so such layers stay there)
-    if (ns != 2 && ns != 4 && ns != 6) return false;
+    if (ns != 2 && ns != 3 && ns != 4 && ns != 6 && ns != 8) return false;
     const bool two = d->m_split < d->M;
     if (two && d->m_split % 32 != 0) return false;
     const int64_t P = (int64_t)d->T * d->H * d->W;
@@ -240,12 +240,13 @@ extern "C" int ppms_gemm1(const ppms_conv* d, const ppms_conv* dev_desc, int cb_
     (void)dev_desc;
     Plan1 pl;
     PPMS_REQUIRE(cb_hint == 0 || cb_hint == 1 || cb_hint == 2 || cb_hint == 4, "gemm1: cb_hint must be 0 (choose), 1, 2 or 4");
-    PPMS_REQUIRE(plan1(d, pl, cb_hint), "gemm1: not a 1x1 convolution this kernel serves (K = 128 / 256 / 384 in 16-channel-aligned segments, M %% 32 == 0, "
+    PPMS_REQUIRE(plan1(d, pl, cb_hint), "gemm1: not a 1x1 convolution this kernel serves (K = 128 / 192 / 256 / 384 / 512 in 16-channel-aligned segments, M %% 32 == 0, "
                                "pack_gemm1 weights, aligned SP operands; ppms_gemm1_applicable tells)");
     hipStream_t st = (hipStream_t)stream;
 #define G1_CASE(CBV, NSV) \
     if (pl.cb == CBV && pl.ns == NSV) return launch1<CBV, NSV>(d, pl, st);
-    G1_CASE(4, 2) G1_CASE(4, 4) G1_CASE(2, 2) G1_CASE(2, 4) G1_CASE(2, 6) G1_CASE(1, 2) G1_CASE(1, 4) G1_CASE(1, 6)
+    G1_CASE(4, 2) G1_CASE(4, 4) G1_CASE(2, 2) G1_CASE(2, 3) G1_CASE(2, 4) G1_CASE(2, 6) G1_CASE(2, 8) G1_CASE(1, 2) G1_CASE(1, 3) G1_CASE(1, 4) G1_CASE(1, 6)
+    G1_CASE(1, 8)
 #undef G1_CASE
     ppms_set_error("gemm1: no instantiation for CB=%d NS=%d", pl.cb, pl.ns);
     return PPMS_EINVAL;

@@ -103,6 +103,8 @@ class SSTBlock(nn.Module):
             w4 = w.detach().to(device)[:, :, None, None]
             packed, bias, meta = _packing.pack_conv2(w4, None if b is None else b.detach().to(device), segs, segs)
             pk[name] = (packed, bias, meta)
+            # every layer of the block is a 1x1 GEMM on 640 ... 3 680 pixels per frame: the thin-GEMM kernel's packs beside the implicit GEMM's
+            pk[name + "@1"] = _packing.pack_gemm1(w4, None if b is None else b.detach().to(device), segs, segs, None, meta["M"])
 
         ln: Dict[str, tuple] = {}
         for i in range(DEPTH):
@@ -178,7 +180,13 @@ class _SstEngine:
             d.epi[0] = e0
             if e1 is not None:
                 d.epi[1] = e1
-            op = ConvOp(d, list(segs) + [packed_w, bias], 2, device=device)
+            p1, b1, _ = pk[name + "@1"]
+            d1 = L.Conv.from_buffer_copy(bytes(d))
+            d1.w, d1.bias = p1.data_ptr(), b1.data_ptr()
+            if lib.ppms_gemm1_applicable(C.byref(d1)) == 1:           # (one memory round trip deep, no K slices: gemm1.hip)
+                op = ConvOp(d1, list(segs) + [p1, b1], 6, device=device)
+            else:
+                op = ConvOp(d, list(segs) + [packed_w, bias], 2, device=device)
             self.steps.append(op)
 
         def call(fn):
