@@ -89,11 +89,15 @@ def forward_update_block(self, image1, update_block: SequenceUpdateBlock3D, corr
     """Same contract as PPMStereo.forward_update_block (ppmstereo.py:426-594): runs ``iters`` refinement
     iterations at one scale, appends one full-resolution prediction and uncertainty per iteration and returns
     (flow_out (BT,2,4h,4w), net (BT,128,h,w), motion_hidden_state (BT,64,h,w)).  ``image1`` is unused (as in the
-    reference).  Batch size 1 (inference) only."""
+    reference).  BT = b * t: batch elements are independent except for the normaliser of the frame scores (:533), see
+    ``_forward_update_block_batched``; b = 1 (inference) is the device-resident fast path."""
     L.require_gpu(flow, net, inp)
     bt, c, h, w = inp.shape
+    if bt % t:
+        raise RuntimeError(f"forward_update_block: {bt} frames do not divide into clips of t = {t}")
     if bt != t:
-        raise NotImplementedError("forward_update_block: batch size 1 only (bt == t)")
+        return _forward_update_block_batched(update_block, corr_fn, flow, net, inp, motion_hidden_state, attn_block, predictions, uncertainties,
+                                             iters, interp_scale, t)
     if c != 128:
         raise RuntimeError("forward_update_block: 128 context channels expected")
     if int(interp_scale) not in (1, 2, 4):
@@ -111,6 +115,50 @@ def forward_update_block(self, image1, update_block: SequenceUpdateBlock3D, corr
         eng.begin(corr_fn.levels, attn_block.packed(inp.device))
         flow_out = _run_iterations(eng, iters, isc, t, h, w, predictions, uncertainties)
         return flow_out.clone(), eng.get_net(), eng.get_mhs()
+
+
+def _forward_update_block_batched(update_block, corr_fn, flow, net, inp, motion_hidden_state, attn_block, predictions, uncertainties, iters,
+                                  interp_scale, t: int):
+    """forward_update_block for b > 1 clips in one call (ppmstereo.py:443-449: frame index = bi * t + ti).  Everything is per batch element
+    -- the 3-D convolutions, the frame similarity, the top-5 pick and the attention all see one clip -- except ONE scalar per clip index:
+    ``selected_score.mean()`` at :533 averages the picked frames' scores over the batch as well, so the key modulation s_hat of clip i is
+    its score divided by the mean over all b elements.  One engine per element; the stages run element by element, the normaliser is
+    fixed between the pick and the attention."""
+    bt, c, h, w = inp.shape
+    b = bt // t
+    if c != 128 or int(interp_scale) not in (1, 2, 4):
+        raise RuntimeError("forward_update_block: 128 context channels and interp_scale 4, 2 or 1 expected")
+    if t == 1:
+        warnings.warn("PPMStereo with a single frame produces NaN disparities (reference behaviour, T must be >= 2)")
+    isc, dev = int(interp_scale), inp.device
+    rows = t * h * w
+    with torch.cuda.device(dev):
+        engs = []
+        for bi in range(b):
+            sl = slice(bi * t, (bi + 1) * t)
+            eng = update_block.engine(t, h, w, dev, slot=bi)
+            eng.set_inp(inp[sl]), eng.set_net(net[sl]), eng.set_flow(flow[sl])
+            eng.set_mhs(None if motion_hidden_state is None else motion_hidden_state[sl])
+            eng.begin([lv[bi * rows:(bi + 1) * rows] for lv in corr_fn.levels], attn_block.packed(dev))      # the pyramid is per frame: row slices
+            engs.append(eng)
+        k = engs[0].ksel
+        flow_out = None
+        for _ in range(iters):
+            for eng in engs:
+                eng.lookup(), eng.motion_and_value(), eng.uncertainty(), eng.pick()
+            picked = [eng.SCORE.gather(1, eng.SEL[:, :k].long()) for eng in engs]                            # (t, k) scores of the picked frames
+            mean_all = torch.stack([x.sum(1) for x in picked]).sum(0) / float(b * k)                           # :533: the mean runs over the batch too
+            outs, uncs = [], []
+            for eng, x in zip(engs, picked):
+                eng.SHAT[:, :k] = x / mean_all[:, None]
+                eng.attend(), eng.update(need_mask=True)
+                outs.append(eng.upsample().clone())
+                uncs.append(eng.UNC_local().view(t, 1, h, w).clone())
+            flow_out = torch.cat(outs)
+            unc = torch.cat(uncs)
+            uncertainties.append(bilinear(unc, (4 * isc * h, 4 * isc * w), False))
+            predictions.append(bilinear(flow_out[:, :1], (isc * 4 * h, isc * 4 * w), True, float(isc)) if isc > 1 else flow_out[:, :1].clone())
+        return flow_out, torch.cat([e.get_net() for e in engs]), torch.cat([e.get_mhs() for e in engs])
 
 
 class ClipPipeline:

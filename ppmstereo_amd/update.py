@@ -196,14 +196,15 @@ class SequenceUpdateBlock3D(nn.Module):
             self._engines = OrderedDict()
         return self._pk
 
-    def engine(self, T: int, h: int, w: int, device, shard=None) -> ScaleEngine:
+    def engine(self, T: int, h: int, w: int, device, shard=None, slot: int = 0) -> ScaleEngine:
+        """slot: which batch element the engine serves (forward_update_block with b > 1 keeps one engine per element)."""
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (T, h, w, str(device), None if shard is None else (shard.rank, shard.world, shard.T, id(shard.group)))
+        key = (T, h, w, str(device), None if shard is None else (shard.rank, shard.world, shard.T, id(shard.group)), slot)
         pk = self.packed(device)
         if key not in self._engines:
-            while len(self._engines) >= self.MAX_ENGINES:
+            while len(self._engines) >= max(self.MAX_ENGINES, slot + 1):
                 self._engines.popitem(last=False)
             with torch.cuda.device(device):
                 self._engines[key] = ScaleEngine(pk, T, h, w, device, shard)

@@ -97,6 +97,32 @@ def test_forward_update_block(model, name, tag, ai, T, h, w, iters, isc, mh):
     gd.check("preds", torch.stack(preds), 1e-3 * isc), gd.check("uncs", torch.stack(uncs), 2e-4)
 
 
+@pytest.mark.parametrize("tag,ai,isc,mh", [("update_block04", 2, 1, True), ("update_block16", 0, 4, False)])
+def test_forward_update_block_batch_of_two(model, tag, ai, isc, mh):
+    """b = 2 clips in one forward_update_block call (ppmstereo.py:443-449; training-style batches): per element everything is independent
+    except the normaliser of the picked frames' scores, which the reference averages over the batch as well (:533) -- against the oracle,
+    which generalises to b > 1 the way the reference does; and the two elements must differ from their b = 1 results exactly through that."""
+    from ppmstereo_amd.corr import CorrBlock1D
+    b, T, h, w, iters = 2, 3, 8, 32, 2
+    ds = [synth_scale_inputs(T, h, w, seed=870 + i, with_mhs=mh, frame_contrast=0.5) for i in range(b)]
+    cat = lambda k: None if ds[0][k] is None else torch.cat([d[k] for d in ds])
+    d = {k: cat(k) for k in ds[0]}
+    preds, uncs, rp, ru = [], [], [], []
+    fo, net, mhs = model.forward_update_block(None, getattr(model, tag), CorrBlock1D(g(d["fmap1"]), g(d["fmap2"])), g(d["flow"]), g(d["net"]), g(d["inp"]),
+                                              g(d["mhs"]), model.att[ai], preds, uncs, iters, isc, T)
+    rfo, rnet, rmhs = O.forward_update_block(W[tag], W[f"att.{ai}"], O.corr_pyramid(d["fmap1"], d["fmap2"]), d["flow"], d["net"], d["inp"], d["mhs"],
+                                             iters, isc, T, tag == "update_block16", rp, ru)
+    assert fo.shape == rfo.shape and len(preds) == iters and preds[-1].shape == rp[-1].shape
+    assert (fo[:, 0].cpu() - rfo[:, 0]).abs().mean().item() < 2e-4 and maxdiff(fo, rfo) < 1e-3
+    assert maxdiff(net, rnet) < 2e-3 and maxdiff(mhs, rmhs) < 1e-3 and maxdiff(torch.stack(uncs), torch.stack(ru)) < 2e-4
+    # b = 1 on the first clip alone: a different normaliser, hence a (slightly) different result
+    p1, u1 = [], []
+    d0 = ds[0]
+    fo1, _, _ = model.forward_update_block(None, getattr(model, tag), CorrBlock1D(g(d0["fmap1"]), g(d0["fmap2"])), g(d0["flow"]), g(d0["net"]), g(d0["inp"]),
+                                           g(d0["mhs"]), model.att[ai], p1, u1, iters, isc, T)
+    assert 0 < (fo1 - fo[:T]).abs().max().item() < 0.5
+
+
 def test_cascade_golden(model):
     """Three-scale cascade vs the reference's PPMStereo.forward output (stub encoders) -- the 1e-3 EPE gate."""
     T, H, Wd = 3, 64, 256
