@@ -236,7 +236,8 @@ def test_forward_with_hip_encoders_and_sst_vs_oracle():
     rd, ru = O.forward(W, lambda x: O.basic_encoder(Wf, x), lambda im: O.feature_cnet(Wc, im), img1, img2, 4, sst_fn=lambda a, b: O.sst_block(Ws, a, b, T))
     err = (d.cpu() - rd).abs()
     print(f"forward with HIP fnet + cnet + SST: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px")
-    assert tuple(d.shape) == (1, T, 1, H, Wd) and err.mean().item() < 5e-3 and err.max().item() < 5e-2
+    # measured 1.6e-3 / 8.7e-3: the loop's own sensitivity on these inputs (see the decomposition test below: the encoders add nothing measurable)
+    assert tuple(d.shape) == (1, T, 1, H, Wd) and err.mean().item() < 3e-3 and err.max().item() < 3e-2
     assert maxdiff(u, ru) < 1e-2
 
 
@@ -301,7 +302,7 @@ def test_forward_batch_test_whole_model():
                                sst_fn=lambda a, b: O.sst_block(Ws, a, b, N))
     err = (out["disparity"] - ref["disparity"]).abs()
     print(f"forward_batch_test, whole model: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px")
-    assert torch.isfinite(out["disparity"]).all() and err.mean().item() < 5e-3 and err.max().item() < 1e-1
+    assert torch.isfinite(out["disparity"]).all() and err.mean().item() < 3e-3 and err.max().item() < 3e-2          # measured 1.4e-3 / 9.1e-3
     assert (out["uncertainties"] - ref["uncertainties"]).abs().max().item() < 2e-2
 
 
