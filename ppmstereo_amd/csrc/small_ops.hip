@@ -364,14 +364,47 @@ __global__ __launch_bounds__(256) void tap_gather_sum_kernel(const float* __rest
     out[pix * out_ld + c] = acc;
     if (accum != nullptr) accum[pix * accum_ld + c] += acc;          // flow += delta_flow (ppmstereo.py:571) without a second launch
 }
+// 3 x 3 x 3 taps (the flow head's tail, 20 launches per clip), fully unrolled: all 27 loads of a thread are in flight together -- the generic
+// kernel's runtime loops wait out a memory round trip per tap (12-14 us per launch whatever the map size).  Same order of additions.
+__global__ __launch_bounds__(256) void tap_gather_sum333_kernel(const float* __restrict__ y, int y_ld, const float* __restrict__ bias,
+                                                                float* __restrict__ out, int out_ld, float* __restrict__ accum, int accum_ld, int cout,
+                                                                int T, int H, int W, int t_halo, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % cout);
+    const int64_t pix = idx / cout;
+    const int x = (int)(pix % W), yy = (int)((pix / W) % H), t = (int)(pix / ((int64_t)W * H));
+    float v[27];
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+        const int tt = t + kz - 1, y2 = yy + ky - 1, x2 = x + kx - 1;
+        const bool ok = (unsigned)(tt + t_halo) < (unsigned)(T + 2 * t_halo) && (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W;
+        v[tap] = ok ? y[(((int64_t)tt * H + y2) * W + x2) * y_ld + tap * cout + c] : 0.0f;
+    }
+    float acc = bias ? bias[c] : 0.0f;
+#pragma unroll
+    for (int tap = 0; tap < 27; ++tap) {
+        const int kz = tap / 9, ky = (tap / 3) % 3, kx = tap % 3;
+        const int tt = t + kz - 1, y2 = yy + ky - 1, x2 = x + kx - 1;
+        const bool ok = (unsigned)(tt + t_halo) < (unsigned)(T + 2 * t_halo) && (unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W;
+        if (ok) acc += v[tap];                                     // (skipped, not "+ 0": the generic kernel's sum, bit for bit)
+    }
+    out[pix * out_ld + c] = acc;
+    if (accum != nullptr) accum[pix * accum_ld + c] += acc;
+}
 // accum (optional, [pixels][accum_ld], accum_ld >= cout): accum[p][c] += out[p][c] in the same launch
 extern "C" int ppms_tap_gather_sum(const float* y, int y_ld, const float* bias, float* out, int out_ld, float* accum, int accum_ld, int cout, int kt,
                                    int kh, int kw, int T, int H, int W, int t_halo, void* stream) {
     PPMS_REQUIRE(y && out && cout > 0 && kt * kh * kw * cout <= y_ld && out_ld >= cout && t_halo >= 0, "tap_gather_sum: bad arguments");
     PPMS_REQUIRE(accum == nullptr || accum_ld >= cout, "tap_gather_sum: accum_ld=%d < cout=%d", accum_ld, cout);
     const int64_t total = (int64_t)T * H * W * cout;
-    hipLaunchKernelGGL(tap_gather_sum_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, y, y_ld, bias, out, out_ld, accum, accum_ld,
-                       cout, kt, kh, kw, T, H, W, t_halo, total);
+    if (kt == 3 && kh == 3 && kw == 3)
+        hipLaunchKernelGGL(tap_gather_sum333_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, y, y_ld, bias, out, out_ld, accum,
+                           accum_ld, cout, T, H, W, t_halo, total);
+    else
+        hipLaunchKernelGGL(tap_gather_sum_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, y, y_ld, bias, out, out_ld, accum, accum_ld,
+                           cout, kt, kh, kw, T, H, W, t_halo, total);
     return ppms_check_launch("tap_gather_sum");
 }
 

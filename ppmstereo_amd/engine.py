@@ -186,7 +186,7 @@ class PwChain:
             ly.post_s = None if post is None else post[0].data_ptr()
             ly.post_t = None if post is None else post[1].data_ptr()
             keep += [packed, bias]
-        self.pixels, self.keep = pixels, keep
+        self.pixels, self.keep, self.cp = pixels, keep, cp
         self.dev = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).clone().to(device)
         self.events = None
 
@@ -195,7 +195,7 @@ class PwChain:
         if ev is not None:
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
-        L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
+        L.check(L.load().ppms_pwchain(C.byref(self.cp), self.dev.data_ptr(), self.pixels, L.stream_ptr()))
         if ev is not None:
             pair[1].record()
             ev.append(pair)
