@@ -271,9 +271,7 @@ int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
  * input and optional depthwise-1x1 post step: the ffn1 / pw / ffn2 parts of PCBlock4_Deep_nopool_res
  * (ppmtereo_update.py:1024-1030).  dev_params: device copy of the parameter block built by the host
  * (ppmstereo_amd/engine.py: PwChain; layout checked with ppms_pwchain_param_bytes). */
-/* host_params: the parameter block on the host (copied into the kernel arguments at launch); dev_params: its device copy (kept for ABI
- * symmetry with the conv entry points, not read by the kernel) */
-int ppms_pwchain(const void* host_params, const void* dev_params, int64_t pixels, void* stream);
+int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream);
 int ppms_pwchain_param_bytes(void);
 
 /* ---------------------------------------------------------------- update_block16 time / space attention pieces */

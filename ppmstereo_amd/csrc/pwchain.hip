@@ -33,11 +33,11 @@ struct ChainParams {
     int64_t P;
 };
 
-// The parameter block travels BY VALUE in the kernel arguments (as the conv descriptors do): through a device pointer every phase of the
-// chain started with a dependent scalar-load round trip for its layer's fields -- ~1 us x 6 phases of a launch that lasts 20-45 us.
-__global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams cpv) {
+// (The parameter block stays behind a device pointer: passed by value in the kernel arguments -- as the conv descriptors are -- the layer
+// loop's dynamic index c.layer[l] sends the struct to scratch memory: chain B at the 1/4 scale 43 -> 54 us, nothing gained at 1/16.)
+__global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restrict__ cp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const ChainParams& c = cpv;
+    const ChainParams& c = *cp;
     // Two activation buffers, used alternately, + one weight block: 80 KiB, so that TWO workgroups share a CU (three buffers: one
     // workgroup per CU and, with 400 tiles on 256 CUs, a half-empty second round).  The residual operand is the chain INPUT, buffer 0:
     // a residual layer is either the first layer (buffer 0 is its source) or the second one (buffer 0 is its DESTINATION: every lane
@@ -182,13 +182,12 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams cpv) {
 
 }  // namespace
 
-extern "C" int ppms_pwchain(const void* host_params, const void* dev_params, int64_t pixels, void* stream) {
-    (void)dev_params;                                            // (kept in the signature like the conv entry points' dev_desc)
-    PPMS_REQUIRE(host_params != nullptr && pixels > 0, "pwchain: bad arguments");
+extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
+    PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");
     constexpr size_t lds = 2 * ACT_BUF + W_BLK;                // 80 KiB: two workgroups per CU
     static ppms_device_once once;
     once.run([] { (void)hipFuncSetAttribute((const void*)pwchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ACT_BUF + W_BLK)); });
-    hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, *(const ChainParams*)host_params);
+    hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params);
     return ppms_check_launch("pwchain");
 }
 

@@ -195,7 +195,7 @@ class PwChain:
         if ev is not None:
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
-        L.check(L.load().ppms_pwchain(C.byref(self.cp), self.dev.data_ptr(), self.pixels, L.stream_ptr()))
+        L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
         if ev is not None:
             pair[1].record()
             ev.append(pair)
