@@ -180,13 +180,180 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Small maps (<= 16 384 pixels: the 1/8 and 1/16 scales).  The kernel above gives them 25-100 workgroups that walk 3-6 PHASES one after
+// the other (a phase = one 64-cout block of one layer: weights to LDS, barrier, 12 MFMAs per wave, epilogue): 20-33 us for a few MFLOP.
+// Here a workgroup owns 32 pixels (4x the workgroups) and a LAYER is one phase: all its weight blocks sit in LDS at once (<= 64 KiB) and
+// the waves split the 32-cout row blocks between them (a 256-cout layer: two row blocks per wave; a 64-cout layer: waves 0 and 1).
+// Same packs, same arithmetic per output element (k order, split products, epilogue), so the results are the big kernel's bit for bit.
+constexpr int TP32 = 32;
+constexpr int ACT32_PLANE = TP32 * ROWB;     // 2 KiB
+constexpr int ACT32_BUF = 4 * ACT32_PLANE;   // [kstep 2][plane 2][32 px][64 B] = 8 KiB
+constexpr int W32_MAX = 4 * W_BLK;           // weights of a 256-cout layer: 64 KiB (reused as the output staging patch of the last layer)
+
+__global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __restrict__ cp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ChainParams& c = *cp;
+    char* bufX = smem;
+    char* bufA = smem + ACT32_BUF;
+    char* wsm = smem + 2 * ACT32_BUF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * TP32;
+    {   // input tile: 32 px x 8 chunks (64 channels) per plane = one 16-byte piece of each plane per thread
+        const int px = tid >> 3, ch = tid & 7;
+        const int64_t pix = p0 + px;
+        u32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
+        if (pix < c.P) {
+            vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
+            vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
+        }
+        const int off = (ch >> 2) * 2 * ACT32_PLANE + swzp(px, ch & 3);
+        *(u32x4*)(bufX + off) = vh;
+        *(u32x4*)(bufX + ACT32_PLANE + off) = vl;
+    }
+    u32x4 wreg[16];                          // the next layer's weights (<= 4 blocks x 4 pieces per thread), requested one layer ahead
+    auto load_w = [&](int l) __attribute__((always_inline)) {
+        const Layer& Lw = c.layer[l];
+        const int mbs = Lw.M / 64;
+#pragma unroll
+        for (int mblk = 0; mblk < 4; ++mblk)
+            if (mblk < mbs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = tid + i * 256;
+                    const int ks = q >> 9, rem = q & 511;
+                    wreg[mblk * 4 + i] = gload16((const char*)Lw.w + ((int64_t)(ks * mbs + mblk) * 512 + rem) * 16);
+                }
+            }
+    };
+    load_w(0);
+    const char* src = bufX;
+    for (int l = 0; l < c.nlayers; ++l) {
+        const Layer& L = c.layer[l];
+        const bool last = (l == c.nlayers - 1);
+        char* dst = (src == bufX) ? bufA : bufX;
+        const int mbs = L.M / 64, nrb = L.M / 32;
+        __syncthreads();                                          // the previous layer's readers of wsm and writers of src are done
+#pragma unroll
+        for (int mblk = 0; mblk < 4; ++mblk)
+            if (mblk < mbs) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *(u32x4*)(wsm + mblk * W_BLK + (tid + i * 256) * 16) = wreg[mblk * 4 + i];
+            }
+        if (l + 1 < c.nlayers) load_w(l + 1);
+        __syncthreads();
+        bf16x4 keep_h[2][4], keep_l[2][4];                        // last layer: the wave's (<= 2) row blocks wait in registers for the staging patch
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int rb = wave + 4 * it;                         // 32-cout row block of the layer
+            if (rb >= nrb) continue;
+            const int mblk = rb >> 1, mb = rb & 1;
+            f32x16 acc = (f32x16){0};
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int k16 = 0; k16 < 2; ++k16) {
+                    const int boff = ks * 2 * ACT32_PLANE + swzp(r, 2 * k16 + h);
+                    const bf16x8 bh = *(const bf16x8*)(src + boff), bl = *(const bf16x8*)(src + ACT32_PLANE + boff);
+                    const int aoff = mblk * W_BLK + ks * 8192 + swzp(mb * 32 + r, 2 * k16 + h);
+                    const bf16x8 ah = *(const bf16x8*)(wsm + aoff), al = *(const bf16x8*)(wsm + 4096 + aoff);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cl = mb * 32 + 8 * g + 4 * h;             // within the 64-cout block
+                const int cg = mblk * 64 + cl;                       // global cout
+                const f32x4 b4 = gld<f32x4>(L.bias + cg);
+                float y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = acc[4 * g + j] + b4[j];
+                const int xo = (cl >> 5) * 2 * ACT32_PLANE + swzp(r, (cl & 31) >> 3) + (cl & 7) * 2;
+                if (L.resid) {
+                    const bf16x4 xh = *(const bf16x4*)(bufX + xo), xl = *(const bf16x4*)(bufX + ACT32_PLANE + xo);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] += join_bf16(xh[j], xl[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = gelu_erf(y[j]);
+                if (L.post_s != nullptr) {
+                    const f32x4 s4 = gld<f32x4>(L.post_s + cg), t4 = gld<f32x4>(L.post_t + cg);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) y[j] = gelu_erf(y[j] + (y[j] * s4[j] + t4[j]));
+                }
+                bf16x4 oh, ol;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    bf16_t hh = (bf16_t)0.0f, ll = (bf16_t)0.0f;
+                    if (cg + j < L.n_valid) split_bf16(y[j], hh, ll);
+                    oh[j] = hh;
+                    ol[j] = ll;
+                }
+                if (last) {
+                    keep_h[it][g] = oh;
+                    keep_l[it][g] = ol;
+                } else {
+                    *(bf16x4*)(dst + xo) = oh;
+                    *(bf16x4*)(dst + ACT32_PLANE + xo) = ol;
+                }
+            }
+        }
+        if (last) {
+            // staging patch over the weight area: [plane][32 px][M couts] bf16, then whole 16-byte pieces per pixel and plane to memory
+            __syncthreads();                                      // every wave is done reading the weights
+            const int rowb = L.M * 2 + 16;                        // bytes per pixel row of a plane (+16: rows start in different banks)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int rb = wave + 4 * it;
+                if (rb >= nrb) continue;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cg = rb * 32 + 8 * g + 4 * h;
+                    *(bf16x4*)(wsm + r * rowb + cg * 2) = keep_h[it][g];
+                    *(bf16x4*)(wsm + TP32 * rowb + r * rowb + cg * 2) = keep_l[it][g];
+                }
+            }
+            __syncthreads();
+            const int cpr = L.M / 8;                              // 16-byte pieces per pixel row
+            for (int qd = tid; qd < TP32 * 2 * cpr; qd += 256) {
+                const int plane = qd / (TP32 * cpr), rem = qd - plane * TP32 * cpr;
+                const int opx = rem / cpr, ch = rem - opx * cpr;
+                const int64_t opix = p0 + opx;
+                const int ocg = ch * 8;
+                if (opix < c.P && ocg < L.n_valid) {
+                    const u32x4 v = *(const u32x4*)(wsm + plane * TP32 * rowb + opx * rowb + ocg * 2);
+                    bf16_t* op = (bf16_t*)(plane ? c.out.lo : c.out.hi) + opix * c.out.ld + ocg;
+                    if (ocg + 8 <= L.n_valid) {
+                        gstore16(op, v);
+                    } else {
+                        const bf16_t* e = (const bf16_t*)&v;
+                        for (int j = 0; j < 8; ++j)
+                            if (ocg + j < L.n_valid) gst<bf16_t>(op + j, e[j]);
+                    }
+                }
+            }
+        }
+        src = dst;
+    }
+}
+
 }  // namespace
 
 extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
     PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");
     constexpr size_t lds = 2 * ACT_BUF + W_BLK;                // 80 KiB: two workgroups per CU
+    constexpr size_t lds32 = 2 * ACT32_BUF + W32_MAX;          // 80 KiB
     static ppms_device_once once;
-    once.run([] { (void)hipFuncSetAttribute((const void*)pwchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ACT_BUF + W_BLK)); });
+    once.run([] {
+        (void)hipFuncSetAttribute((const void*)pwchain_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ACT_BUF + W_BLK));
+        (void)hipFuncSetAttribute((const void*)pwchain32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ACT32_BUF + W32_MAX));
+    });
+    if (pixels <= 16384) {                                       // small maps: 32-pixel tiles, one phase per layer
+        hipLaunchKernelGGL(pwchain32_kernel, dim3(ceil_div(pixels, TP32)), dim3(256), lds32, (hipStream_t)stream, (const ChainParams*)dev_params);
+        return ppms_check_launch("pwchain");
+    }
     hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params);
     return ppms_check_launch("pwchain");
 }

@@ -708,13 +708,14 @@ def test_tap_gather_sum(lib, T, H, W):
     assert torch.equal(out2, out)
 
 
-def test_pwchain_vs_unfused_layers(lib):
+@pytest.mark.parametrize("P", [5 * 7 * 9 + 3, 16384 + 128 + 5])
+def test_pwchain_vs_unfused_layers(lib, P):
     """Fused per-pixel chains of the correlation encoder (pwchain.hip) against fp32 torch math of
-    PCBlock4_Deep_nopool_res.forward (ppmtereo_update.py:1024-1030), ragged pixel count."""
+    PCBlock4_Deep_nopool_res.forward (ppmtereo_update.py:1024-1030), ragged pixel counts: 318 pixels run the small-map kernel (32-pixel
+    tiles, one phase per layer), 16 517 the large-map one (128-pixel tiles, one phase per 64-cout block)."""
     from ppmstereo_amd.engine import PwChain
     from ppmstereo_amd.packing import pack_conv2
     L = lib
-    P = 5 * 7 * 9 + 3
     x = hash_normal((P, 36), 520)
     mk = lambda co, ci, s: (hash_normal((co, ci, 1, 1), s) / math.sqrt(ci), hash_normal((co,), s + 1) * 0.1)
     (w0, b0), (w2, b2), (wp, bp), (w3, b3), (w4, b4) = mk(54, 36, 521), mk(36, 54, 523), mk(36, 36, 525), mk(54, 36, 527), mk(256, 54, 529)
