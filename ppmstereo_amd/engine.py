@@ -42,6 +42,7 @@ TUNING = dict(
     slices=True,          # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
     hoist=True,           # iteration-invariant inp share of the GRU gates computed once per scale
     gemm1=True,           # thin-GEMM kernel (gemm1.hip) for the 1x1 convolutions / Linear layers it serves
+    convf2_unsliced=True,
     conv5_pad2x=False,    # conv_gemm5 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 78 us instead of 65 + 143 us
                           # of the K-sliced form, but on the side stream it then competes with convc2 for whole CUs: clip time unchanged, 40.8 ms)
 )
@@ -421,7 +422,7 @@ class ScaleEngine:
 
     # ------------------------------------------------------------------ descriptors
     def _conv(self, wname, segs: List[L.SP], k3, epi0: L.Epilogue, epi1: Optional[L.Epilogue] = None, m_split: Optional[int] = None,
-              keep=()) -> ConvOp:
+              keep=(), nslice: Optional[int] = None) -> ConvOp:
         packed, bias, meta = self.pk.w[wname] if isinstance(wname, str) else wname
         d = L.Conv()
         for i, s in enumerate(segs):
@@ -464,7 +465,7 @@ class ScaleEngine:
                 packed_y, bias_y, _ = self.pk.w[key]
                 d.w, d.bias = packed_y.data_ptr(), bias_y.data_ptr()
                 return ConvOp(d, [packed_y, bias_y, *keep], 2, ysweep=True, device=self.dev)
-        return ConvOp(d, [packed, bias, *keep], version, device=self.dev)
+        return ConvOp(d, [packed, bias, *keep], version, nslice=nslice, device=self.dev)
 
     def _try_fragment_kernels(self, wname: str, d: L.Conv, m_split, keep) -> Optional[ConvOp]:
         """conv_gemm5 (weights in MFMA-fragment order, pack_conv4, couts padded to 128) when it serves the conv."""
@@ -527,7 +528,10 @@ class ScaleEngine:
             cf, cf_next = self.CF[par], self.CF[1 - par]
             o[f"init2_{par}"] = self._conv("init2", [self.ZT.view(0, 64)], k3, E(n_valid=64, out_sp=cf.view(256, 64)))
             o[f"convc2_{par}"] = self._conv_padded("convc2", [self.COR256.view()], k3, E(act=L.ACT_RELU, n_valid=192, out_sp=cf.view(0, 192)))
-            o[f"convf2_{par}"] = self._conv("convf2", [self.FLO1.view()], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=cf.view(192, 64)))
+            # (large maps: unsliced -- the library would cut its 400 workgroups in two K slices, and the slice-reduce launch of this side-stream
+            # conv then crawls on the CUs the main stream's convc2 leaves free: 143 us, TUNING["convf2_unsliced"])
+            o[f"convf2_{par}"] = self._conv("convf2", [self.FLO1.view()], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=cf.view(192, 64)),
+                                            nslice=1 if (TUNING["convf2_unsliced"] and self.P >= 32768) else None)
             o[f"final_{par}"] = self._conv_padded("final", [cf.view()], k3, E(act=L.ACT_RELU, n_valid=126, out_sp=mf),
                                            E(act=L.ACT_RELU, n_valid=64, out_sp=cf_next.view(256, 64)), m_split=128)
         o["to_v"] = self._conv("to_v", [mf], k1, E(n_valid=128, out_sp=self.VAL.view(), out_vt=self.VT))
