@@ -42,7 +42,7 @@ TUNING = dict(
     slices=True,          # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
     hoist=True,           # iteration-invariant inp share of the GRU gates computed once per scale
     gemm1=True,           # thin-GEMM kernel (gemm1.hip) for the 1x1 convolutions / Linear layers it serves
-    convf2_unsliced=True,
+    convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
     conv5_pad2x=False,    # conv_gemm5 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 78 us instead of 65 + 143 us
                           # of the K-sliced form, but on the side stream it then competes with convc2 for whole CUs: clip time unchanged, 40.8 ms)
 )
@@ -528,8 +528,8 @@ class ScaleEngine:
             cf, cf_next = self.CF[par], self.CF[1 - par]
             o[f"init2_{par}"] = self._conv("init2", [self.ZT.view(0, 64)], k3, E(n_valid=64, out_sp=cf.view(256, 64)))
             o[f"convc2_{par}"] = self._conv_padded("convc2", [self.COR256.view()], k3, E(act=L.ACT_RELU, n_valid=192, out_sp=cf.view(0, 192)))
-            # (large maps: unsliced -- the library would cut its 400 workgroups in two K slices, and the slice-reduce launch of this side-stream
-            # conv then crawls on the CUs the main stream's convc2 leaves free: 143 us, TUNING["convf2_unsliced"])
+            # (on large maps the library cuts its 400 workgroups in two K slices, and the slice-reduce launch of this side-stream conv crawls on
+            # the CUs the main stream's convc2 leaves free -- 143 us, but off the critical path: unsliced is neither faster nor slower)
             o[f"convf2_{par}"] = self._conv("convf2", [self.FLO1.view()], k3, E(act=L.ACT_RELU, n_valid=64, out_sp=cf.view(192, 64)),
                                             nslice=1 if (TUNING["convf2_unsliced"] and self.P >= 32768) else None)
             o[f"final_{par}"] = self._conv_padded("final", [cf.view()], k3, E(act=L.ACT_RELU, n_valid=126, out_sp=mf),
