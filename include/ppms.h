@@ -282,7 +282,9 @@ int ppms_time_attn(ppms_sp x, const float* ln_w, const float* ln_b, ppms_sp out,
 /* out = resid + LayerNorm(x) (resid.hi == NULL: no residual); x fp32 [pixel][ld]; C = 384 or 256 (attention.py:186-190) */
 int ppms_layernorm(const float* x, int ld, const float* w, const float* b, ppms_sp resid, ppms_sp out, int64_t pixels, int C, void* stream);
 /* LinearAttention.forward (attention.py:73-100) per frame and head: Q, K already elu()+1, V already / n;
- * kv_ws: fp32 workspace of 4*T*heads*dh*(dh+1) floats; out (SP) = (Q KV) / (Q . sum K + 1e-6) * n */
+ * kv_ws: fp32 workspace of ppms_linear_attention_workspace_floats(T, n, heads, dh) floats (the per-pixel-split partial sums);
+ * out (SP) = (Q KV) / (Q . sum K + 1e-6) * n */
+int64_t ppms_linear_attention_workspace_floats(int T, int n, int heads, int dh);
 int ppms_linear_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* kv_ws, ppms_sp out, int T, int n,
                           int heads, int dh, void* stream);
 

@@ -104,6 +104,7 @@ _SIGS = {
     "ppms_pwchain_param_bytes": (c_int, []),
     "ppms_time_attn": (c_int, [SP, c_void_p, c_void_p, SP, c_int, c_int, c_int, c_void_p]),
     "ppms_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, SP, SP, c_int64, c_int, c_void_p]),
+    "ppms_linear_attention_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "ppms_linear_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, SP, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ppms_mem_attn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),

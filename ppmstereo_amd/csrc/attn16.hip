@@ -22,12 +22,29 @@ __global__ __launch_bounds__(64) void time_attn_kernel(ppms_sp x, const float* _
         w[j] = lnw[lane * CPL + j];
         b[j] = lnb[lane * CPL + j];
     }
+    // all T frames of the pixel are requested before anything is consumed (the loop used to wait out one memory round trip per frame, with
+    // six 2-byte loads per plane and lane): 32-bit loads of channel pairs into LDS, then LayerNorm frame by frame from LDS
+    {
+        constexpr int PAIRS = CPL / 2;
+#pragma unroll 8
+        for (int t = 0; t < T; ++t) {
+            const int64_t pix = (int64_t)t * n + pin;
+            const unsigned* ph = (const unsigned*)((const bf16_t*)x.hi + pix * x.ld + lane * CPL);
+            const unsigned* pl = (const unsigned*)((const bf16_t*)x.lo + pix * x.ld + lane * CPL);
+#pragma unroll
+            for (int j = 0; j < PAIRS; ++j) {
+                const unsigned uh = ph[j], ul = pl[j];
+                // bf16 -> fp32 is a 16-bit shift: low half = even channel, high half = odd channel
+                ysh[t * C + lane * CPL + 2 * j] = __uint_as_float(uh << 16) + __uint_as_float(ul << 16);
+                ysh[t * C + lane * CPL + 2 * j + 1] = __uint_as_float(uh & 0xffff0000u) + __uint_as_float(ul & 0xffff0000u);
+            }
+        }
+    }
     for (int t = 0; t < T; ++t) {
-        const int64_t pix = (int64_t)t * n + pin;
         float v[CPL], s = 0.0f;
 #pragma unroll
         for (int j = 0; j < CPL; ++j) {
-            v[j] = join_bf16(((const bf16_t*)x.hi)[pix * x.ld + lane * CPL + j], ((const bf16_t*)x.lo)[pix * x.ld + lane * CPL + j]);
+            v[j] = ysh[t * C + lane * CPL + j];
             s += v[j];
         }
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
@@ -143,11 +160,18 @@ extern "C" int ppms_layernorm(const float* x, int ld, const float* w, const floa
 // kv[f][hd][d][v] = sum_s K[f,s,hd,d] V[f,s,hd,v];  ksum[f][hd][d] = sum_s K[f,s,hd,d].
 // Grid (head, frame, pixel split): each workgroup reduces n/NSPLIT pixels into its own partial (fixed order: deterministic),
 // each thread owns a B x B block of the DH x DH outer product, B = DH / 16 (DH = 48: 6 LDS reads per 9 FMAs; DH = 32: 4 per 4).
-constexpr int LA_NSPLIT = 4;
+// The pixel splits: enough of them that a workgroup stages its share in ONE pass of 64 pixels when n is small (n = 640: 10 splits -- with 4
+// splits and 32-pixel passes a workgroup walked 5 passes of load -> barrier -> FMA, 26 us per call), at most LA_MAXSPLIT (workspace size).
+constexpr int LA_MAXSPLIT = 32;
+static inline int la_nsplit(int n) {
+    int s = (n + 63) / 64;
+    return s < 4 ? 4 : (s > LA_MAXSPLIT ? LA_MAXSPLIT : s);
+}
 template <int DH>
 __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
                                                          float* __restrict__ kv, float* __restrict__ ksum, int n, int heads) {
-    constexpr int CH = 32, B = DH / 16;                // pixels staged per pass; block edge per thread
+    constexpr int CH = 64, B = DH / 16;                // pixels staged per pass; block edge per thread
+    const int LA_NSPLIT = gridDim.z;
     __shared__ float ks[CH][DH + 1], vs[CH][DH + 1];
     const int hd = blockIdx.x, f = blockIdx.y, sp_id = blockIdx.z;
     const int tid = threadIdx.x;
@@ -196,7 +220,7 @@ __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict
 // msg[f,l,hd,v] = (sum_d Q[f,l,hd,d] kv[f,hd,d,v]) * (1 / (Q . ksum + eps)) * n   (one workgroup = 32 pixels of one frame x head)
 template <int DH>
 __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ kv,
-                                                            const float* __restrict__ ksum, ppms_sp out, int n, int heads, float eps) {
+                                                            const float* __restrict__ ksum, ppms_sp out, int n, int heads, float eps, int LA_NSPLIT) {
     constexpr int PX = 32;
     __shared__ float kvs[DH][DH + 1], kss[DH], qs[PX][DH];
     const int hd = blockIdx.y, f = blockIdx.z, p0 = blockIdx.x * PX;
@@ -239,16 +263,22 @@ extern "C" int ppms_linear_attention(const float* Q, int ldq, const float* K, in
                                      int T, int n, int heads, int dh, void* stream) {
     PPMS_REQUIRE(Q && K && V && kv_ws && out.hi && out.lo && heads == 8 && (dh == 48 || dh == 32),
                  "linear_attention: 8 heads x 48 (update_block16) or x 32 (SST block) channels expected");
+    const int nsplit = la_nsplit(n);
     float* kv = kv_ws;
-    float* ksum = kv_ws + (size_t)LA_NSPLIT * T * heads * dh * dh;
+    float* ksum = kv_ws + (size_t)nsplit * T * heads * dh * dh;
     if (dh == 48) {
-        hipLaunchKernelGGL(linattn_kv_kernel<48>, dim3(heads, T, LA_NSPLIT), dim3(256), 0, (hipStream_t)stream, K, ldk, V, ldv, kv, ksum, n, heads);
+        hipLaunchKernelGGL(linattn_kv_kernel<48>, dim3(heads, T, nsplit), dim3(256), 0, (hipStream_t)stream, K, ldk, V, ldv, kv, ksum, n, heads);
         hipLaunchKernelGGL(linattn_apply_kernel<48>, dim3(ceil_div(n, 32), heads, T), dim3(256), 0, (hipStream_t)stream, Q, ldq, kv, ksum, out, n, heads,
-                           1e-6f);
+                           1e-6f, nsplit);
     } else {
-        hipLaunchKernelGGL(linattn_kv_kernel<32>, dim3(heads, T, LA_NSPLIT), dim3(256), 0, (hipStream_t)stream, K, ldk, V, ldv, kv, ksum, n, heads);
+        hipLaunchKernelGGL(linattn_kv_kernel<32>, dim3(heads, T, nsplit), dim3(256), 0, (hipStream_t)stream, K, ldk, V, ldv, kv, ksum, n, heads);
         hipLaunchKernelGGL(linattn_apply_kernel<32>, dim3(ceil_div(n, 32), heads, T), dim3(256), 0, (hipStream_t)stream, Q, ldq, kv, ksum, out, n, heads,
-                           1e-6f);
+                           1e-6f, nsplit);
     }
     return ppms_check_launch("linear_attention");
+}
+
+// floats the caller must provide as kv_ws: the pixel splits' partial K^T V blocks and K sums
+extern "C" int64_t ppms_linear_attention_workspace_floats(int T, int n, int heads, int dh) {
+    return (int64_t)la_nsplit(n) * T * heads * dh * (dh + 1);
 }

@@ -364,7 +364,7 @@ class ScaleEngine:
             self.O1 = L.SPTensor(P, 384, device, before=self.f0 * n, after=(Tg - self.f0 - T) * n)
             self.XG = self.X if shard is None else L.SPTensor(Tg * n, 384, device)
             self.QKF, self.VF, self.M2, self.M3 = f32(P, 768), f32(P, 384), f32(P, 384), f32(P, 384)
-            self.KVWS = f32(4 * T * 8 * 48 * 49)
+            self.KVWS = f32(int(L.load().ppms_linear_attention_workspace_floats(T, n, 8, 48)))
         self.Hb = [sp(128), sp(128), sp(128)]
         self.ZT, self.RT, self.RH, self.FH1, self.M1 = sp(128), sp(128), sp(128), sp(256), sp(256)
         self.Z, self.MASK, self.QK = f32(P, 128), f32(P, pk.mask_ch), f32(P, 256)

@@ -162,7 +162,7 @@ class _SstEngine:
         self.Y = [sp(DIM), sp(DIM)]                 # ping-pong partners
         self.QF, self.KVF, self.M2, self.M3 = f32(DIM), f32(2 * DIM), f32(DIM), f32(DIM)
         self.MSG, self.MSGN, self.H1, self.O1, self.O2 = sp(DIM), sp(DIM), sp(2 * DIM), sp(DIM), sp(DIM)
-        self.KVWS = torch.empty(4 * T * HEADS * 32 * 33 + 64, device=device, dtype=torch.float32)
+        self.KVWS = torch.empty(int(lib.ppms_linear_attention_workspace_floats(T, n, HEADS, DIM // HEADS)) + 64, device=device, dtype=torch.float32)
         self.steps: List = []
         none_sp = L.SP(None, None, 0, 0)
         s = L.stream_ptr

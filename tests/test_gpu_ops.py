@@ -781,7 +781,7 @@ def test_attn16_kernels(lib, T, n):
     K = (F.elu(hash_normal((P, Cc), 544)) + 1).contiguous()
     V = (hash_normal((P, Cc), 545) / n).contiguous()
     Qd, Kd, Vd = Q.to(DEV), K.to(DEV), V.to(DEV)
-    ws = torch.zeros(4 * T * heads * d * (d + 1), device=DEV)
+    ws = torch.zeros(int(lb.ppms_linear_attention_workspace_floats(T, n, heads, d)), device=DEV)
     L.check(lb.ppms_linear_attention(Qd.data_ptr(), Cc, Kd.data_ptr(), Cc, Vd.data_ptr(), Cc, ws.data_ptr(), o.view(), T, n, heads, d, L.stream_ptr()))
     torch.cuda.synchronize()
     q4, k4, v4 = (t.view(T, n, heads, d) for t in (Q, K, V))
