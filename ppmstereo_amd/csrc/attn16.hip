@@ -160,13 +160,13 @@ extern "C" int ppms_layernorm(const float* x, int ld, const float* w, const floa
 // kv[f][hd][d][v] = sum_s K[f,s,hd,d] V[f,s,hd,v];  ksum[f][hd][d] = sum_s K[f,s,hd,d].
 // Grid (head, frame, pixel split): each workgroup reduces n/NSPLIT pixels into its own partial (fixed order: deterministic),
 // each thread owns a B x B block of the DH x DH outer product, B = DH / 16 (DH = 48: 6 LDS reads per 9 FMAs; DH = 32: 4 per 4).
-// The pixel splits: a workgroup stages its share in at most two passes of 64 pixels when n is small (n = 640: 5 splits; with 4 splits and
-// 32-pixel passes a workgroup walked 5 passes of load -> barrier -> FMA: 26 us per call, now 14).  Not more: every workgroup of the apply
-// kernel sums all the splits' partial blocks (10 splits: kv 11 us but apply 17 -> 38 us).  At most LA_MAXSPLIT (workspace size).
+// Four pixel splits, 64-pixel passes.  More splits shorten this kernel (10 splits: 26 -> 11 us at n = 640) but every workgroup of the apply
+// kernel sums all the splits' partial blocks (17 -> 38 us): measured best in total at 4 (round 3; the split count is a function so that the
+// workspace size follows it).
 constexpr int LA_MAXSPLIT = 32;
 static inline int la_nsplit(int n) {
-    int s = (n + 127) / 128;
-    return s < 4 ? 4 : (s > LA_MAXSPLIT ? LA_MAXSPLIT : s);
+    (void)n;
+    return 4;
 }
 template <int DH>
 __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
