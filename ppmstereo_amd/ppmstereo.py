@@ -334,6 +334,8 @@ class InputPadder:
         for x in inputs:
             if x.ndim != 4:
                 raise ValueError(f"InputPadder.pad: 4-D tensors expected, got {tuple(x.shape)}")
+        if not any(self._pad):
+            return list(inputs)                                           # (already a multiple: nothing to copy)
         return [torch.nn.functional.pad(x, self._pad, mode="replicate") for x in inputs]
 
     def unpad(self, x):
@@ -492,10 +494,11 @@ class PPMStereo(PPMStereoHotPath):
             for wi, (start, stop, keep_from, keep_to) in enumerate(plan):
                 if wi % world != rank:
                     continue
-                left, right = video[start:stop, 0], video[start:stop, 1]
+                win = video[start:stop].to(dev)                              # one host -> device copy per window (see below)
+                left, right = win[:, 0], win[:, 1]
                 padder = InputPadder(left.shape, divis_by=32)
                 left, right = padder.pad(left, right)
-                d, u = self.forward(left[None].to(dev), right[None].to(dev), iters=iters, test_mode=True)
+                d, u = self.forward(left[None], right[None], iters=iters, test_mode=True)
                 d, u = padder.unpad(d[0]), padder.unpad(u[0])               # (T, 1, H0, W0)
                 mine_d.append((firsts[wi], d[keep_from:keep_to].abs()[:, :1]))
                 mine_u.append((firsts[wi], u[keep_from:keep_to].abs()[:, :1]))
@@ -519,10 +522,13 @@ class PPMStereo(PPMStereoHotPath):
 
         with torch.cuda.device(dev):
             for start, stop, keep_from, keep_to in plan:
-                left, right = video[start:stop, 0], video[start:stop, 1]
+                # host -> device: ONE copy of the window's contiguous (T, 2, 3, H, W) block; the two views are split and padded on the
+                # device (slicing a view out on the host first costs a host-side copy of each view, padding there another one)
+                win = video[start:stop].to(dev)
+                left, right = win[:, 0], win[:, 1]
                 padder = InputPadder(left.shape, divis_by=32)
                 left, right = padder.pad(left, right)
-                d, u = self.forward(left[None].to(dev), right[None].to(dev), iters=iters, test_mode=True, pipeline=pipe)      # host -> device: once per window
+                d, u = self.forward(left[None], right[None], iters=iters, test_mode=True, pipeline=pipe)
                 item = (d, u, None if pipe is None else pipe.last, padder, keep_from, keep_to)
                 if pending is not None:
                     collect(pending)
