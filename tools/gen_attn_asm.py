@@ -46,6 +46,9 @@ DOT = int(os.environ.get("PPMS_ATTN_DOT", "0"))
 LSUM = os.environ.get("PPMS_ATTN_LSUM", "mfma16")
 assert LSUM in ("mfma", "mfma16", "add")
 MF16 = "v_mfma_f32_16x16x32_bf16"
+# 1: the first score argument of a pair is formed in the pair's EVEN slot (behind the exp there) instead of both in the odd slot: VALU ops
+# per slot 2 / 3 instead of 1 / 4
+BAL = int(os.environ.get("PPMS_ATTN_BAL", "0"))
 ABL = int(os.environ.get("PPMS_ATTN_ABL", "0"))     # timing experiments only (wrong results): 1 drops the softmax VALU work, 2 the LDS
                                                     # requests and waits, 4 the MFMAs, 8 the address upkeep
 
@@ -150,6 +153,8 @@ def substep(par):
         pf_word = f"pf{half}[{pb}][{(g & 7) >> 1}]"
         if s % 2 == 0:
             E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[{(p + 1) & 1}][0]")], [("t", "v", f"tt2[{(p + 1) & 1}][0]")])
+            if BAL and not PK:
+                arg(0)
             if PK:
                 E.asm("v_pk_add_f32 {l}, {l}, {p}", [("l", "+v", f"lsum2[{pb}]")], [("p", "v", f"pt2[{p & 1}]")])
             elif DOT or LSUM != "add":
@@ -162,7 +167,8 @@ def substep(par):
                 E.asm("v_pk_fma_f32 {t}, {x}, {sc}, {m}", [("t", "=v", f"tt2[{p & 1}]")],
                       [("x", "v", f"__builtin_shufflevector({tile}, {tile}, {lg}, {lg + 1})"), ("sc", "v", "scale2"), ("m", "v", f"negm2[{lb}]")])
             else:
-                arg(0)
+                if not BAL:
+                    arg(0)
                 arg(1)
             E.asm("v_exp_f32 {p}, {t}", [("p", "=v", f"pt2[{(p + 1) & 1}][1]")], [("t", "v", f"tt2[{(p + 1) & 1}][1]")])
             E.asm("v_cvt_pk_bf16_f32 {d}, {p0}, {p1}", [("d", "+v", pf_word)], [("p0", "v", f"pt2[{p & 1}][0]"), ("p1", "v", f"pt2[{p & 1}][1]")])
