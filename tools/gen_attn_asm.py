@@ -27,8 +27,9 @@ MF = "v_mfma_f32_32x32x16_bf16"
 # on the kernel, the library being built without packed-fp32 code generation
 PK = int(os.environ.get("PPMS_ATTN_PK", "0"))
 # fragment ring: RING buffers, a fragment is requested RING - 1 uses ahead; PAIRWAIT: one counted wait per TWO fragments (RING = 6:
-# 13 instead of 25 waits per tile -- measured no faster, 1.24 vs 1.22 ms, so 4 stays)
-RING = int(os.environ.get("PPMS_ATTN_RING", "4"))
+# 13 instead of 25 waits per tile).  Round 2 measured 6 no faster than 4 (1.24 vs 1.22 ms); with the softmax denominator in the matrix pipe
+# (fewer VALU ops between the waits) it is 1.5 % faster in situ (1.055 vs 1.071 ms per 1/4-scale call, tools/ab_attn_ring.sh): 6 since round 3
+RING = int(os.environ.get("PPMS_ATTN_RING", "6"))
 PAIRWAIT = RING >= 6
 # 1: the softmax denominator is accumulated from the PACKED bf16 probabilities (v_dot2_f32_bf16 with (1, 1): one op per pair instead of
 # two fp32 adds) -- correct (15 tests) but measured SLOWER on gfx950 (1.32 vs 1.25 ms: like the packed fp32 ops, the dot op does not
