@@ -550,6 +550,192 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     ATTN_STAMP(3)
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same kernel on the 16x16x32 MFMA (attn64x_asm.h, generated by tools/gen_attn16_asm.py).  Same workgroup shape, DMA ring, split
+// workspace, fixed softmax reference and fix-up protocol as mem_attn64_kernel above; what changes is the matrix-pipe tiling: the wave's 64
+// queries are four 16-query blocks, a 32-key sub-tile is two 16-key block rows, S^T = K Q^T takes 4 k-steps of 32 channels per block and
+// O^T (128 x 64) is 8 x 4 blocks of 16 x 16.  At equal cycles per FLOP the part holds a ~12 % higher clock on this shape under MFMA load
+// (tools/probe/mfma_shape_probe.hip), and the 32 keys of a sub-tile are ONE k-step of O^T += V^T P, so the V^T fragments are read
+// once per sub-tile (16 LDS reads per substep instead of 20).
+//  * K row m of block row b is key 8 (m >> 2) + 4 b + (m & 3) of the sub-tile: lane (query c, g = lane >> 4) then holds keys 8g..8g+3
+//    (block row 0) and 8g+4..8g+7 (block row 1), i.e. packed to bf16 exactly k-block g of the P operand;
+//  * the K tile's 16-B chunks are swizzled by f(row) = bits {0, 1, 3, 4} of the row (the 16 rows a 16-lane group reads differ in exactly
+//    those bits): conflict-free ds_read_b128, applied on the DMA's source side as before.
+#include "attn64x_asm.h"
+
+__device__ __forceinline__ int att_kswz(int row) { return (row & 3) | ((row >> 1) & 12); }
+
+__global__ __launch_bounds__(256, 1) void mem_attn64x_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
+                                                             const bf16_t* __restrict__ vt_g, const int32_t* __restrict__ sel, int ksel,
+                                                             float scale_log2, int n, float* __restrict__ part_o, float* __restrict__ part_ml,
+                                                             int32_t* __restrict__ redo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ATTN_STAMP(0)
+    constexpr int QB = 4;                         // 16-query blocks per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int nsplit = gridDim.z;                 // one picked frame per workgroup (gridDim.z == ksel)
+    int qblk, clip, slot0;
+    {                                             // XCD-aware order (see mem_attn64_kernel)
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int xcd = lin & 7, k = lin >> 3, q = nwg >> 3, rem = nwg & 7;
+        const int w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;      // a bijection of [0, nwg)
+        qblk = w % (int)gridDim.x;
+        const int pair = w / (int)gridDim.x;
+        clip = pair % (int)gridDim.y;
+        slot0 = pair / (int)gridDim.y;
+    }
+    const int q0 = qblk * (64 * NW) + wave * 64;
+    const int nt = n / KT;
+
+    bf16x8 qf[QB][4];                             // Q^T fragments: query 16 b + c, channels 32 s + 8 g .. + 8
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+        const int qi = q0 + b * 16 + c;
+        const int qc = qi < n ? qi : n - 1;
+        const bf16_t* qp = qb + ((int64_t)clip * n + qc) * D + 8 * g;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[b][s] = *(const bf16x8*)(qp + 32 * s);
+    }
+    // ---- DMA sources of this thread (tile 0); LDS chunk q = i*256 + tid, i = 0..3 -----------------------------------
+    //  K tile: row = q >> 4 (key), LDS position q & 15 holds source chunk (q & 15) ^ att_kswz(row)
+    //  V^T tile: row d = q >> 3, LDS position q & 7 holds source chunk (q & 7) ^ ((d >> 1) & 7)     (chunk = 8 keys)
+    const char* kbase = (const char*)(kb + (int64_t)(clip * ksel + slot0) * n * D);
+    const char* vbase = (const char*)(vt_g + (int64_t)sel[clip * 5 + slot0] * D * n);
+    unsigned koff[4], voff[4];
+    {
+        const int d = tid >> 3;
+        const unsigned v0 = (unsigned)(d * n * 2 + (((tid & 7) ^ ((d >> 1) & 7)) << 4));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (tid >> 4) + 16 * i;
+            koff[i] = (unsigned)(row * D * 2 + (((tid & 15) ^ att_kswz(row)) << 4));
+            voff[i] = v0 + (unsigned)(i * 32 * n * 2);            // V^T rows d + 32 i  (128 rows x n keys x 2 B < 4 GiB)
+        }
+    }
+    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem + wave * 1024);
+    auto issue_tile = [&](int j) __attribute__((always_inline)) {
+        const unsigned st = lds_wave + (unsigned)((j & (ATT_NS - 1)) * ATT_STAGE);
+        const char* kp = kbase + (int64_t)j * KT * D * 2;
+        const char* vp = vbase + (int64_t)j * KT * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(koff[i]), "s"(kp), "s"(st + (unsigned)(i * 4096)) : "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[i]), "s"(vp), "s"(st + (unsigned)(K_TILE + i * 4096)) : "memory");
+    };
+
+    f32x4 o[8][QB];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int b = 0; b < QB; ++b) o[i][b] = (f32x4){0};
+    // LDS addresses of this lane's fragments in stage 0 (attn64x_asm.h moves them from stage to stage):
+    //  K, block row b, k-step s: row 8 (c >> 2) + 4 b + (c & 3) (+ 32 rows = 8192 B for the tile's second sub-tile), chunk (4 s + g) ^ att_kswz(row)
+    //  V^T, sub-tile p: row d = c (+ 16 rows = 2048 B per d block), chunk (4 p + g) ^ ((c >> 1) & 7)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    unsigned kaddr[8], vaddr[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int row = 8 * (c >> 2) + 4 * b + (c & 3);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) kaddr[b * 4 + s] = lds0 + row * 256 + (((4 * s + g) ^ att_kswz(row)) << 4);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) vaddr[p] = lds0 + K_TILE + c * 128 + (((4 * p + g) ^ ((c >> 1) & 7)) << 4);
+
+    issue_tile(0);
+    if (nt > 1) issue_tile(1);
+    if (nt > 2) issue_tile(2);
+    if (nt > 2)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x4 sa[2][QB], sb[2][QB];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)                   // S^T of sub-tile 0
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 kf = *(const bf16x8*)(smem + (kaddr[b * 4 + s] - lds0));
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const f32x4 c0 = (s == 0) ? (f32x4){0} : sa[b][q];
+                sa[b][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[q][s], c0, 0, 0, 0);
+            }
+        }
+    float negm[QB];
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {                // softmax reference: maximum over the first 32 keys of the frame
+        float mx = fmaxf(fmaxf(sa[0][q][0], sa[0][q][1]), fmaxf(sa[0][q][2], sa[0][q][3]));
+        mx = fmaxf(mx, fmaxf(fmaxf(sa[1][q][0], sa[1][q][1]), fmaxf(sa[1][q][2], sa[1][q][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        negm[q] = -(mx * scale_log2);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) asm volatile("" : "+v"(sa[b][q]));      // the loop's VALU reads the S^T tiles: VGPR half of the register file
+    }
+    u32x4 ring[4], vt[8] = {}, pf[QB] = {};
+    f32x4 lacc[QB] = {(f32x4){0}, (f32x4){0}, (f32x4){0}, (f32x4){0}};
+    u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+v"(ones));
+    f32x2 pt[2], tt[2];
+    attn64x_prime(sa, ring, pt, tt, negm, scale_log2, kaddr);
+    ATTN_STAMP(1)
+    for (int j = 0; j < nt; ++j) {
+        // tile j + 3 travels into the stage tile j - 1 left at the barrier; its 8 DMA instructions sit inside the substeps.  Past the frame's end
+        // the last tile is fetched again (into a stage nobody reads): the instruction stream and the vmcnt bookkeeping stay unconditional
+        const int jn = j + 3 < nt ? j + 3 : nt - 1;
+        const unsigned st = lds_wave + (unsigned)(((j + 3) & (ATT_NS - 1)) * ATT_STAGE);
+        const char* kp = kbase + (int64_t)jn * KT * D * 2;
+        const char* vp = vbase + (int64_t)jn * KT * 2;
+        const unsigned dst[8] = {st, st + 4096u, st + 8192u, st + 12288u, st + K_TILE, st + K_TILE + 4096u, st + K_TILE + 8192u, st + K_TILE + 12288u};
+        const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
+        attn64x_substep<0>(sa, sb, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
+        attn64x_substep<1>(sb, sa, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tiles <= j + 2 have landed (this thread's share; the barrier covers the others')
+#if !defined(PPMS_ATTN_NOSYNC)
+        __builtin_amdgcn_s_barrier();
+#endif
+        if (j + 1 == nt) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // drain the matrix pipe in front of whatever the compiler places at the exit
+    }
+    attn64x_tail();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may be in flight when the workgroup's LDS is handed on
+    ATTN_STAMP(2)
+#pragma unroll
+    for (int dblk = 0; dblk < 8; ++dblk)          // O^T[:, qb 3] += V^T P of the last sub-tile
+        o[dblk][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vt[dblk]), __builtin_bit_cast(bf16x8, pf[3]), o[dblk][3], 0, 0, 0);
+    lacc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[3]), lacc[3], 0, 0, 0);
+    // a score more than 2^60 above the reference (or a NaN) anywhere shows in the sum: the fix-up pass redoes the tile
+    bool bail = false;
+#pragma unroll
+    for (int q = 0; q < QB; ++q) bail = bail || !(lacc[q][0] <= 0x1p60f);
+    {
+        const int flag = __syncthreads_or(bail);
+        if (tid == 0) {
+            int32_t* f = redo + ((int64_t)(clip * nsplit + slot0) * gridDim.x + qblk) * 2;
+            f[0] = flag ? 1 : 0;
+            f[1] = flag ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+        const int qi = q0 + q * 16 + c;
+        if (qi >= n) continue;
+        const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
+        float* po = part_o + row * D + 4 * g;
+#pragma unroll
+        for (int dblk = 0; dblk < 8; ++dblk) *(f32x4*)(po + dblk * 16) = o[dblk][q];
+        if (g == 0) {
+            part_ml[row * 2] = -negm[q];
+            part_ml[row * 2 + 1] = lacc[q][0];
+        }
+    }
+    ATTN_STAMP(3)
+}
+
 // merges the per-frame partials of split mode: O = sum_s O_s 2^(m_s - m), l = sum_s l_s 2^(m_s - m); then the same
 // epilogue as the fused kernel (hid = bf16(O / l), mfg = mf + beta * hid).  One thread = one query x 8 channels.
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int nsplit,
@@ -609,6 +795,7 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         (void)hipFuncSetAttribute((const void*)mem_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         (void)hipFuncSetAttribute((const void*)mem_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         (void)hipFuncSetAttribute((const void*)mem_attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)mem_attn64x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
     });
     const float scale_log2 = scale * 1.4426950408889634f;
     // split over the picked frames when a workspace is given (ppms_mem_attn_workspace_bytes) and there is more than one
@@ -621,7 +808,12 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         const int g64 = (int)ceil_div(n, 64 * NW);
         int32_t* redo = (int32_t*)(part_ml + (size_t)T * ksel * n * 2);
         dim3 grid64(g64, T, ksel), grid32(ceil_div(n, QW * NW), T, ksel);
-        hipLaunchKernelGGL(mem_attn64_kernel, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+#ifdef PPMS_ATTN_SHAPE32
+        constexpr auto kern64 = mem_attn64_kernel;
+#else
+        constexpr auto kern64 = mem_attn64x_kernel;
+#endif
+        hipLaunchKernelGGL(kern64, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                            sel, ksel, scale_log2, n, part_o, part_ml, redo);
         hipLaunchKernelGGL(mem_attn_kernel<false>, grid32, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                            sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, redo, 2 * g64);
