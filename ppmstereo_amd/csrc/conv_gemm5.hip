@@ -73,6 +73,9 @@ __device__ __forceinline__ void vm_wait5(int n) {
 #undef PPMS_VMW
 }
 
+#ifndef CONV5_NOSYNC
+#define CONV5_NOSYNC 0       // ablation builds: 1 drops wait + barrier + DMA at the window switches, 2 the DMA, 3 the barrier: wrong results, timing only
+#endif
 #ifndef CONV5_ABL_A
 #define CONV5_ABL_A 0        // ablation builds (-DCONV5_ABL_A=1): every k-step loads the FIRST step's weights (L1 hits): wrong results, timing only
 #endif
@@ -246,10 +249,10 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
         if (++sw == g.nsweep) {                                                                                                \
             sw = swx = trow = 0;                                                                                               \
             if (ahead > 0) {                                                                                                   \
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                               \
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                             \
-                __builtin_amdgcn_s_barrier();                                                                                  \
-                if (w + 2 < nwin) dma_b(win0 + wstride * (w + 2), w & 1);                                                      \
+                if (CONV5_NOSYNC != 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                        \
+                if (CONV5_NOSYNC != 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+                if (CONV5_NOSYNC != 1 && CONV5_NOSYNC != 3) __builtin_amdgcn_s_barrier();                                      \
+                if (CONV5_NOSYNC != 1 && CONV5_NOSYNC != 2) if (w + 2 < nwin) dma_b(win0 + wstride * (w + 2), w & 1);          \
             }                                                                                                                  \
             ++w;                                                                                                               \
         } else {                                                                                                               \

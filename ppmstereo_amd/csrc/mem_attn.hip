@@ -300,23 +300,30 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// 64 queries per wave, LDS-DMA ring (n % 64 == 0, split workspace given).
+// 64 queries per wave, LDS-DMA ring, 16x16x32 MFMA (n % 64 == 0, split workspace given).  The hot loop is attn64_asm.h, generated by
+// tools/gen_attn_asm.py (schedule and register roles: its docstring).
 //
 // What bounds the 32-query kernel above is not the matrix pipe: (1) it issues one ds_read_b128 per MFMA (each K / V^T
 // fragment feeds a single 32-query block); (2) its KV tile for iteration j+1 is requested at the start of iteration j and
 // must have arrived by its end -- a ~2 us round trip through L2 / Infinity Cache under load, against ~1 us of MFMA work;
 // (3) softmax VALU work and MFMAs of two co-resident waves do not overlap on this part (a wave streaming MFMAs starves
-// the other wave's VALU; independent VALU work of the SAME wave does issue under its MFMAs, ~6 ops per 32-cycle MFMA:
-// tools/probe/coissue_probe.hip).  This kernel addresses all three:
-//  * a wave owns TWO 32-query blocks: every fragment read feeds two MFMAs.  State = O^T (128 accumulator registers) +
-//    two S^T sub-tiles (2 x 32) + Q (64): the unified 512-register file, one wave per SIMD;
+// the other wave's VALU; independent VALU work of the SAME wave does issue under its MFMAs: tools/probe/coissue_probe.hip).
+// This kernel addresses all three:
+//  * a wave owns FOUR 16-query blocks: every K / V^T fragment read feeds four MFMAs.  State = O^T (128 x 64: 8 x 4 blocks of 16 x 16,
+//    128 accumulator registers) + two S^T sub-tiles (2 x 32) + Q (64): the unified 512-register file, one wave per SIMD;
+//  * the MFMA shape is 16x16x32, not 32x32x16: at equal cycles per FLOP the part holds a ~12 % higher clock on it under dense MFMA
+//    load on real operands (tools/probe/mfma_shape_probe.hip: 2065 vs 1854 TFLOP/s from registers, 1720 vs 1576 from LDS; equal on zeros),
+//    and the 32 keys of a sub-tile are ONE k-step of O^T += V^T P, so the V^T fragments are read once per sub-tile.  K row m of block
+//    row b is key 8 (m >> 2) + 4 b + (m & 3) of the sub-tile: lane (query c, g = lane >> 4) then holds keys 8g..8g+3 (block row 0) and
+//    8g+4..8g+7 (block row 1), i.e. packed to bf16 exactly k-block g of the P operand -- no LDS round trip for P, no key permutation of V^T;
 //  * KV tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers) into a ring of FOUR 32 KiB
 //    stages, requested three tiles ahead and waited for with counted s_waitcnt vmcnt: >= 2 iterations of latency hiding.
-//    The DMA destination is lane-linear, so the bank-conflict swizzles are applied on the SOURCE chunk index; V^T needs
-//    no key permutation any more because the K rows are fed to the MFMA in an order (bits 2 and 3 of the row swapped)
-//    that makes every lane's 8 P values belong to 8 CONSECUTIVE keys;
+//    The DMA destination is lane-linear, so the bank-conflict swizzles are applied on the SOURCE chunk index: the K tile's 16-B chunks by
+//    f(row) = bits {0, 1, 3, 4} of the row (the 16 rows a 16-lane group reads differ in exactly those bits), V^T's by (d >> 1) & 7.
+//    The tile's 8 DMA instructions sit INSIDE the scheduled loop, one per ~16 MFMAs: issued as a burst at the top of the iteration
+//    (behind the barrier, no MFMA in flight) they cost 6.5 % of the loop and doubled the barrier's cost (profiles/r03_attn_shape_ab.txt);
 //  * the 64-key tile is consumed as two 32-key sub-tiles, software pipelined inside the wave: the matrix pipe computes S
-//    of the next sub-tile while the VALU runs exp / sum / bf16 of the current one, then O += V P.  One basic block;
+//    of the next sub-tile while the VALU runs exp / bf16 pack of the current one, then O += V P.  One basic block;
 //  * above 256 registers the MFMA accumulators live in the accumulator half of the register file, which the VALU only
 //    reaches through copies, and the compiler puts such copies on the hot path as soon as ANY code multiplies O^T (the
 //    usual online-softmax rescale).  So O^T is never rescaled here: the softmax reference of a query is fixed to the
@@ -324,14 +331,13 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
 //    scores may exceed it by up to 2^60 (P, l and O carry that factor in fp32 / bf16, exponent range 2^127), and
 //    (O, m, l) go to the split workspace for attn_combine_kernel, which normalises.  A larger jump (or a NaN, T == 1)
 //    makes the workgroup raise a flag instead: the 32-query kernel, launched right after as a fix-up pass, recomputes
-//    exactly the flagged tiles with the classic online softmax and returns immediately everywhere else.
+//    exactly the flagged tiles with the classic online softmax and returns immediately everywhere else;
+//  * the softmax denominator comes out of the matrix pipe too: l += 1 * P with an all-ones A operand, i.e. the sum of exactly the
+//    bf16-rounded probabilities the numerator uses, accumulated the same way (the rounding of P then cancels
+//    to first order between numerator and denominator).
+//  * workgroups are renumbered so that the ~40 workgroups streaming one (clip, picked frame) K / V^T sit on ONE XCD (each XCD has
+//    its own L2; dealt round-robin every XCD would read all of K / V^T: 8x the fetch traffic).
 constexpr int ATT_NS = 4;                   // LDS ring stages (K 16 KiB + V^T 16 KiB each)
-
-__device__ __forceinline__ void att_dma16(const void* src, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const PPMS_GLOBAL void*)(uintptr_t)src, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-#include "attn64_asm.h"
 
 #ifdef PPMS_ATTN_TIMING
 static __device__ long long* g_attn_dbg_dev = nullptr;          // debug builds only: [workgroup][4] wall-clock stamps (100 MHz) of wave 0
@@ -341,231 +347,11 @@ static __device__ long long* g_attn_dbg_dev = nullptr;          // debug builds 
 #else
 #define ATTN_STAMP(K)
 #endif
-__global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
-                                                            const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
-                                                            float scale_log2, int n, float* __restrict__ part_o, float* __restrict__ part_ml,
-                                                            int32_t* __restrict__ redo) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    ATTN_STAMP(0)
-    constexpr int QB = 2;                         // 32-query blocks per wave
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    // XCD-aware order: workgroups are dealt to the 8 XCDs round-robin by dispatch index, and each XCD has its own L2.  The 40-odd
-    // workgroups that stream the same (clip, picked frame) K / V^T should therefore sit on ONE XCD (they then advance through the
-    // tiles together and share every line); dealt the plain way each XCD reads all of K / V^T: 8x the fetch traffic.
-    const int nsplit = gridDim.z;                 // one picked frame per workgroup (gridDim.z == ksel)
-    int qblk, clip, slot0;
-    {
-        const int nwg = gridDim.x * gridDim.y * gridDim.z;
-        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int xcd = lin & 7, k = lin >> 3, q = nwg >> 3, rem = nwg & 7;
-        const int w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;      // a bijection of [0, nwg)
-        qblk = w % (int)gridDim.x;
-        const int pair = w / (int)gridDim.x;
-        clip = pair % (int)gridDim.y;
-        slot0 = pair / (int)gridDim.y;
-    }
-    const int q0 = qblk * (64 * NW) + wave * 64;
-    const int nt = n / KT;
-
-    bf16x8 qf[QB][8];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        const int qi = q0 + b * 32 + r;
-        const int qc = qi < n ? qi : n - 1;
-        const bf16_t* qp = qb + ((int64_t)clip * n + qc) * D + 8 * h;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) qf[b][s] = *(const bf16x8*)(qp + 16 * s);
-    }
-    // ---- DMA sources of this thread (tile 0); LDS chunk q = i*256 + tid, i = 0..3 -----------------------------------
-    //  K tile: row = q >> 4 (key), LDS position q & 15 holds source chunk (q & 15) ^ (row & 15)
-    //  V^T tile: row d = q >> 3, LDS position q & 7 holds source chunk (q & 7) ^ ((d >> 1) & 7)     (chunk = 8 keys)
-    // The 8 DMA instructions of a tile address memory as (scalar tile base) + (per-thread 32-bit offset, constant for the whole kernel):
-    // the only per-tile work is two scalar 64-bit adds, and per DMA one scalar write of M0 (the wave's LDS destination).
-    const char* kbase = (const char*)(kb + (int64_t)(clip * ksel + slot0) * n * D);                    // K tile 0 of this (clip, slot)
-    const char* vbase = (const char*)(vt + (int64_t)sel[clip * 5 + slot0] * D * n);                    // V^T tile 0 of the picked frame
-    unsigned koff[4], voff[4];
-    {
-        const int d = tid >> 3;
-        const unsigned k0 = (unsigned)((tid >> 4) * D * 2 + (((tid & 15) ^ ((tid >> 4) & 15)) << 4));
-        const unsigned v0 = (unsigned)(d * n * 2 + (((tid & 7) ^ ((d >> 1) & 7)) << 4));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            koff[i] = k0 + (unsigned)(i * 16 * D * 2);
-            voff[i] = v0 + (unsigned)(i * 32 * n * 2);            // V^T rows d + 32 i  (128 rows x n keys x 2 B < 4 GiB)
-        }
-    }
-    const unsigned lds_wave = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem + wave * 1024);
-    auto issue_tile = [&](int j) __attribute__((always_inline)) {
-        const unsigned st = lds_wave + (unsigned)((j & (ATT_NS - 1)) * ATT_STAGE);
-        const char* kp = kbase + (int64_t)j * KT * D * 2;
-        const char* vp = vbase + (int64_t)j * KT * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(koff[i]), "s"(kp), "s"(st + (unsigned)(i * 4096)) : "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff[i]), "s"(vp), "s"(st + (unsigned)(K_TILE + i * 4096)) : "memory");
-    };
-
-    f32x16 o[4][QB];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int b = 0; b < QB; ++b) o[i][b] = (f32x16){0};
-    // K rows enter the MFMA with bits 2 and 3 of the row index swapped: S^T register g of lane half h then belongs to key
-    // 16 (g >> 3) + 8 h + (g & 7) of the sub-tile, i.e. a lane's 8 P values per PV step are 8 consecutive keys
-    const int rk_row = (r & 19) | ((r & 4) << 1) | ((r & 8) >> 1);
-    auto s_steps = [&](const char* ks, int kblk, f32x16 (&st)[QB]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int row = kblk * 32 + rk_row;
-            const bf16x8 kf = *(const bf16x8*)(ks + row * 256 + (((2 * s + h) ^ (row & 15)) << 4));
-#pragma unroll
-            for (int b = 0; b < QB; ++b) {
-                const f32x16 c = (s == 0) ? (f32x16){0} : st[b];
-                st[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[b][s], c, 0, 0, 0);
-            }
-        }
-    };
-    // LDS addresses of this lane's fragments in stage 0 (attn64_asm.h moves them from stage to stage):
-    //  K, k-step s: row rk_row (+ 32 rows = 8192 B for the tile's second sub-tile), chunk (2 s + h) ^ (row & 15)
-    //  V^T, 16-key group c4 of the tile: row d = r (+ 32 rows = 4096 B per d block), chunk (2 c4 + h) ^ ((d >> 1) & 7)
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
-    unsigned kaddr[8], vaddr[4];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) kaddr[s] = lds0 + rk_row * 256 + (((2 * s + h) ^ (rk_row & 15)) << 4);
-#pragma unroll
-    for (int c4 = 0; c4 < 4; ++c4) vaddr[c4] = lds0 + K_TILE + r * 128 + (((2 * c4 + h) ^ ((r >> 1) & 7)) << 4);
-
-    // ring: iteration j requests tile j+3 (into the stage tile j-1 left at the barrier), computes with K_j, K_{j+1}, V_j, and ends
-    // with "tiles <= j+2 have landed" (counted vmcnt: only tile j+3's 8 DMAs of this thread may still be in flight) + barrier
-    issue_tile(0);
-    if (nt > 1) issue_tile(1);
-    if (nt > 2) issue_tile(2);
-    if (nt > 2)
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    f32x16 sa[QB], sb[QB];
-    s_steps(smem, 0, sa);
-    float neg_m[QB];
-    f32x2 negm2[QB], lsum2[QB] = {{0.0f, 0.0f}, {0.0f, 0.0f}};   // (the loop works on pairs of scores)
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {                // softmax reference: maximum over the first 32 keys of the frame
-        float mx = sa[b][0];
-#pragma unroll
-        for (int g = 1; g < 16; ++g) mx = fmaxf(mx, sa[b][g]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        neg_m[b] = -(mx * scale_log2);
-        negm2[b] = (f32x2){neg_m[b], neg_m[b]};
-        asm volatile("" : "+v"(sa[b]));           // the loop keeps the S^T tiles in the VGPR half of the register file (its VALU reads them)
-    }
-    // the hand-scheduled loop (attn64_asm.h, generated by tools/gen_attn_asm.py): 2 substeps = one 64-key tile.  The O += V P group
-    // of a sub-tile's second key half runs one substep late, so the first substep multiplies zeros by zeros
-    u32x4 ring[ATT_RING], vh1[4] = {}, pf0[2] = {}, pf1[2] = {};
-    // the softmax denominator from the matrix pipe: l^T[d][query] += 1 * P over the keys of every PV step (A operand = all ones, so every
-    // row d of the 32 x 32 result holds the same sum): exactly the bf16-rounded probabilities the numerator uses, accumulated the same way
-    // ATT_LSUM == 2: one 16x16x32 MFMA instead (half the matrix-pipe time): read as that shape's B operand, this lane's fragment is
-    // column r & 15, k-block 2 h + (r >> 4); A = ones on (row 0, k-blocks 0 and 2) and (row 1, k-blocks 1 and 3), i.e. in lanes 0, 32, 17,
-    // 49: row 0 of the 16 x 16 result = the sums of queries 0..15, row 1 = queries 16..31 (registers 0, 1 of lanes 0..15)
-    f32x16 lacc[QB] = {(f32x16){0}, (f32x16){0}};
-    f32x4 lacc4[QB] = {(f32x4){0}, (f32x4){0}};
-    const bool sel_lane = (ATT_LSUM == 2) ? (lane == 0 || lane == 32 || lane == 17 || lane == 49) : true;
-    const unsigned one2 = sel_lane ? 0x3f803f80u : 0u;
-    u32x4 ones = {one2, one2, one2, one2};
-    asm volatile("" : "+v"(ones));
-    f32x2 pt2[2], tt2[2];
-    const f32x2 scale2 = {scale_log2, scale_log2};
-    attn64_prime(sa, ring, pt2, tt2, negm2, scale2, kaddr);
-    ATTN_STAMP(1)
-    for (int j = 0; j < nt; ++j) {
-        const bool more3 = j + 3 < nt;
-        if (more3) issue_tile(j + 3);
-        const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
-        attn64_substep<0>(sa, sb, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, lacc, lacc4, ones, negm2, scale2, kaddr, vaddr, delta);
-        attn64_substep<1>(sb, sa, qf, o, ring, vh1, pf0, pf1, pt2, tt2, lsum2, lacc, lacc4, ones, negm2, scale2, kaddr, vaddr, delta);
-        if (more3)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // the loop's MFMAs are inline asm: the compiler pads no MFMA-write -> VALU-read wait states behind them, and after the loop it
-        // copies accumulators around.  Drain the matrix pipe inside the last iteration, in front of anything it may place at the exit
-        if (j + 1 == nt) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-    }
-    attn64_tail();
-    ATTN_STAMP(2)
-#pragma unroll
-    for (int dblk = 0; dblk < 4; ++dblk)          // O += V P for keys 16..31 of the last sub-tile
-#pragma unroll
-        for (int b = 0; b < QB; ++b)
-            o[dblk][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vh1[dblk]), __builtin_bit_cast(bf16x8, pf1[b]), o[dblk][b], 0, 0, 0);
-    float lsum[QB];                               // per lane: the sum over the keys seen by this lane's half (add form) / by the wave (MFMA form)
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        if (ATT_LSUM == 1) {
-            lacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf1[b]), lacc[b], 0, 0, 0);
-            lsum[b] = lacc[b][0];                 // every row of l^T is the same sum; register 0 of lane (r, h) = column r = this lane's query
-        } else if (ATT_LSUM == 2) {
-            lacc4[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf1[b]), lacc4[b], 0, 0, 0);
-            const float lo16 = __shfl(lacc4[b][0], r & 15), hi16 = __shfl(lacc4[b][1], r & 15);      // rows 0 / 1 live in lanes 0..15
-            lsum[b] = (r & 16) ? hi16 : lo16;
-        } else {
-            lsum[b] = lsum2[b][0] + lsum2[b][1];
-        }
-    }
-    // a score more than 2^60 above the reference (or a NaN) anywhere shows in the sum: the fix-up pass redoes the tile
-    const bool bail = !(lsum[0] <= 0x1p60f) || !(lsum[1] <= 0x1p60f);
-
-    // ---- (O, m, l) -> this workgroup's partial slot; attn_combine_kernel finishes the softmax and the aggregation ------
-    {                                             // both 128-query halves of this workgroup are redone by the fix-up pass when any
-        const int flag = __syncthreads_or(bail);  // of its queries bailed; written either way (no memset of the flags per call)
-        if (tid == 0) {
-            int32_t* f = redo + ((int64_t)(clip * nsplit + slot0) * gridDim.x + qblk) * 2;
-            f[0] = flag ? 1 : 0;
-            f[1] = flag ? 1 : 0;
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        const int qi = q0 + b * 32 + r;
-        const float l_tot = ATT_LSUM != 0 ? lsum[b] : lsum[b] + __shfl_xor(lsum[b], 32);
-        if (qi >= n) continue;
-        const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
-        float* po = part_o + row * D;
-#pragma unroll
-        for (int dblk = 0; dblk < 4; ++dblk)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 v4 = {o[dblk][b][4 * g], o[dblk][b][4 * g + 1], o[dblk][b][4 * g + 2], o[dblk][b][4 * g + 3]};
-                *(f32x4*)(po + dblk * 32 + 8 * g + 4 * h) = v4;
-            }
-        if (h == 0) {
-            part_ml[row * 2] = -neg_m[b];
-            part_ml[row * 2 + 1] = l_tot;
-        }
-    }
-    ATTN_STAMP(3)
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// The same kernel on the 16x16x32 MFMA (attn64x_asm.h, generated by tools/gen_attn16_asm.py).  Same workgroup shape, DMA ring, split
-// workspace, fixed softmax reference and fix-up protocol as mem_attn64_kernel above; what changes is the matrix-pipe tiling: the wave's 64
-// queries are four 16-query blocks, a 32-key sub-tile is two 16-key block rows, S^T = K Q^T takes 4 k-steps of 32 channels per block and
-// O^T (128 x 64) is 8 x 4 blocks of 16 x 16.  At equal cycles per FLOP the part holds a ~12 % higher clock on this shape under MFMA load
-// (tools/probe/mfma_shape_probe.hip), and the 32 keys of a sub-tile are ONE k-step of O^T += V^T P, so the V^T fragments are read
-// once per sub-tile (16 LDS reads per substep instead of 20).
-//  * K row m of block row b is key 8 (m >> 2) + 4 b + (m & 3) of the sub-tile: lane (query c, g = lane >> 4) then holds keys 8g..8g+3
-//    (block row 0) and 8g+4..8g+7 (block row 1), i.e. packed to bf16 exactly k-block g of the P operand;
-//  * the K tile's 16-B chunks are swizzled by f(row) = bits {0, 1, 3, 4} of the row (the 16 rows a 16-lane group reads differ in exactly
-//    those bits): conflict-free ds_read_b128, applied on the DMA's source side as before.
-#include "attn64x_asm.h"
+#include "attn64_asm.h"
 
 __device__ __forceinline__ int att_kswz(int row) { return (row & 3) | ((row >> 1) & 12); }
 
-__global__ __launch_bounds__(256, 1) void mem_attn64x_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
+__global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
                                                              const bf16_t* __restrict__ vt_g, const int32_t* __restrict__ sel, int ksel,
                                                              float scale_log2, int n, float* __restrict__ part_o, float* __restrict__ part_ml,
                                                              int32_t* __restrict__ redo) {
@@ -576,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64x_kernel(const bf16_t* __res
     const int c = lane & 15, g = lane >> 4;
     const int nsplit = gridDim.z;                 // one picked frame per workgroup (gridDim.z == ksel)
     int qblk, clip, slot0;
-    {                                             // XCD-aware order (see mem_attn64_kernel)
+    {                                             // XCD-aware order
         const int nwg = gridDim.x * gridDim.y * gridDim.z;
         const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int xcd = lin & 7, k = lin >> 3, q = nwg >> 3, rem = nwg & 7;
@@ -632,7 +418,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64x_kernel(const bf16_t* __res
     for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int b = 0; b < QB; ++b) o[i][b] = (f32x4){0};
-    // LDS addresses of this lane's fragments in stage 0 (attn64x_asm.h moves them from stage to stage):
+    // LDS addresses of this lane's fragments in stage 0 (attn64_asm.h moves them from stage to stage):
     //  K, block row b, k-step s: row 8 (c >> 2) + 4 b + (c & 3) (+ 32 rows = 8192 B for the tile's second sub-tile), chunk (4 s + g) ^ att_kswz(row)
     //  V^T, sub-tile p: row d = c (+ 16 rows = 2048 B per d block), chunk (4 p + g) ^ ((c >> 1) & 7)
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
@@ -682,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64x_kernel(const bf16_t* __res
     u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     asm volatile("" : "+v"(ones));
     f32x2 pt[2], tt[2];
-    attn64x_prime(sa, ring, pt, tt, negm, scale_log2, kaddr);
+    attn64_prime(sa, ring, pt, tt, negm, scale_log2, kaddr);
     ATTN_STAMP(1)
     for (int j = 0; j < nt; ++j) {
         // tile j + 3 travels into the stage tile j - 1 left at the barrier; its 8 DMA instructions sit inside the substeps.  Past the frame's end
@@ -693,15 +479,15 @@ __global__ __launch_bounds__(256, 1) void mem_attn64x_kernel(const bf16_t* __res
         const char* vp = vbase + (int64_t)jn * KT * 2;
         const unsigned dst[8] = {st, st + 4096u, st + 8192u, st + 12288u, st + K_TILE, st + K_TILE + 4096u, st + K_TILE + 8192u, st + K_TILE + 12288u};
         const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
-        attn64x_substep<0>(sa, sb, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
-        attn64x_substep<1>(sb, sa, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
+        attn64_substep<0>(sa, sb, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
+        attn64_substep<1>(sb, sa, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tiles <= j + 2 have landed (this thread's share; the barrier covers the others')
 #if !defined(PPMS_ATTN_NOSYNC)
         __builtin_amdgcn_s_barrier();
 #endif
         if (j + 1 == nt) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // drain the matrix pipe in front of whatever the compiler places at the exit
     }
-    attn64x_tail();
+    attn64_tail();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may be in flight when the workgroup's LDS is handed on
     ATTN_STAMP(2)
 #pragma unroll
@@ -795,7 +581,6 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         (void)hipFuncSetAttribute((const void*)mem_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         (void)hipFuncSetAttribute((const void*)mem_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
         (void)hipFuncSetAttribute((const void*)mem_attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
-        (void)hipFuncSetAttribute((const void*)mem_attn64x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
     });
     const float scale_log2 = scale * 1.4426950408889634f;
     // split over the picked frames when a workspace is given (ppms_mem_attn_workspace_bytes) and there is more than one
@@ -808,12 +593,7 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         const int g64 = (int)ceil_div(n, 64 * NW);
         int32_t* redo = (int32_t*)(part_ml + (size_t)T * ksel * n * 2);
         dim3 grid64(g64, T, ksel), grid32(ceil_div(n, QW * NW), T, ksel);
-#ifdef PPMS_ATTN_SHAPE32
-        constexpr auto kern64 = mem_attn64_kernel;
-#else
-        constexpr auto kern64 = mem_attn64x_kernel;
-#endif
-        hipLaunchKernelGGL(kern64, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+        hipLaunchKernelGGL(mem_attn64_kernel, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                            sel, ksel, scale_log2, n, part_o, part_ml, redo);
         hipLaunchKernelGGL(mem_attn_kernel<false>, grid32, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                            sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, redo, 2 * g64);
