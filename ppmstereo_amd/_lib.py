@@ -108,6 +108,7 @@ _SIGS = {
     "ppms_linear_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, SP, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ppms_mem_attn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "ppms_debug_mem_attn_frames_per_workgroup": (None, [c_int]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
                                                           float scale_log2, const float* __restrict__ beta_p, ppms_sp mf, ppms_sp mfg,
                                                           bf16_t* __restrict__ out_bf16, int n, float* __restrict__ part_o,
-                                                          float* __restrict__ part_ml, int32_t* __restrict__ redo, int redo_stride) {
+                                                          float* __restrict__ part_ml, int32_t* __restrict__ redo, int redo_stride, int sps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -67,13 +67,13 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
     float m_run = -INFINITY, l_run = 0.0f;
 
     const int tpf = (n + KT - 1) / KT;           // tiles per frame
-    // split mode (part_o != null): gridDim.z = ksel, this workgroup reads ONE picked frame and writes unnormalised
-    // partials; a combine kernel merges them (more, smaller work units: 400 -> 2000 at 320x512, and the small scales
-    // get ksel x the parallelism)
+    // split mode (part_o != null): gridDim.z = ceil(ksel / sps) splits, this workgroup reads the `sps` picked frames of split blockIdx.z
+    // and writes unnormalised partials; a combine kernel merges them (more, smaller work units, and the small scales get ksel x the
+    // parallelism)
     const int nsplit = gridDim.z;
-    const int slot0 = (nsplit > 1) ? (int)blockIdx.z : 0;
-    const int it0 = slot0 * tpf;
-    const int ntile = (nsplit > 1) ? it0 + tpf : ksel * tpf;
+    const int split = (nsplit > 1) ? (int)blockIdx.z : 0;
+    const int it0 = split * sps * tpf;
+    const int ntile = (nsplit > 1 && it0 + sps * tpf < ksel * tpf) ? it0 + sps * tpf : ksel * tpf;
 
     u32x4 rk[4], rv[4];
     auto load_k = [&](int it) {
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     if (qi >= n) return;
     if (part_o != nullptr) {
-        const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
+        const int64_t row = ((int64_t)clip * nsplit + split) * n + qi;
         float* po = part_o + row * D;
 #pragma unroll
         for (int dblk = 0; dblk < 4; ++dblk)
@@ -354,26 +354,48 @@ __device__ __forceinline__ int att_kswz(int row) { return (row & 3) | ((row >> 1
 __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
                                                              const bf16_t* __restrict__ vt_g, const int32_t* __restrict__ sel, int ksel,
                                                              float scale_log2, int n, float* __restrict__ part_o, float* __restrict__ part_ml,
-                                                             int32_t* __restrict__ redo) {
+                                                             int32_t* __restrict__ redo, int sps) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ATTN_STAMP(0)
     constexpr int QB = 4;                         // 16-query blocks per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
-    const int nsplit = gridDim.z;                 // one picked frame per workgroup (gridDim.z == ksel)
-    int qblk, clip, slot0;
-    {                                             // XCD-aware order
-        const int nwg = gridDim.x * gridDim.y * gridDim.z;
-        const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int xcd = lin & 7, k = lin >> 3, q = nwg >> 3, rem = nwg & 7;
-        const int w = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + k;      // a bijection of [0, nwg)
-        qblk = w % (int)gridDim.x;
-        const int pair = w / (int)gridDim.x;
-        clip = pair % (int)gridDim.y;
-        slot0 = pair / (int)gridDim.y;
+    // a workgroup streams the `sps` (1 or 2) consecutive picked frames of split gz = blockIdx.z (gridDim.z == ceil(ksel / sps)): two where the
+    // one-frame grid would run several rounds on the chip anyway -- 40 % fewer partials to write, read and combine, one prologue / epilogue per
+    // two frames.  K' of consecutive slots is contiguous ([clip][slot][key][128]): one stream of nfr * nt tiles; V^T switches frames at tile nt
+    const int nsplit = gridDim.z;
+    int qblk, clip, gz;
+    {   // XCD-aware order.  Workgroups are dealt to the 8 XCDs round-robin by dispatch index (xcd = lin & 7; the k-th workgroup of an XCD is
+        // lin >> 3) and each XCD has its own L2, so (1) the ~40 workgroups that stream the same (clip, split) K / V^T get consecutive k on
+        // ONE XCD (dealt the plain way every XCD reads all of K / V^T: 8x the fetch traffic), and (2) with two-frame splits every XCD gets
+        // its eighth of the two-frame ("heavy") workgroups AND its eighth of the one-frame ones, heavy first -- equal work per XCD
+        // (in plain split order five XCDs hold only heavy workgroups: 1.33 instead of 1.08 ms per 1/4-scale call)
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int nwg = gx * gy * nsplit;
+        const int nfull = ksel / sps;                                   // splits with `sps` frames; one more, shorter split if ksel % sps
+        const int nH = gx * gy * nfull;
+        const int lin = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+        const int xcd = lin & 7, k = lin >> 3;
+        const int kpre = xcd * (nwg >> 3) + (xcd < (nwg & 7) ? xcd : (nwg & 7));          // workgroups of the XCDs before this one
+        const int hpre = xcd * (nH >> 3) + (xcd < (nH & 7) ? xcd : (nH & 7));             // heavy workgroups of the XCDs before this one
+        const int hx = (nH >> 3) + (xcd < (nH & 7) ? 1 : 0);                              // heavy workgroups of this XCD
+        int idx, pair;
+        if (k < hx) {
+            idx = hpre + k;                                             // index in the heavy list: [split][clip][qblk]
+            pair = idx / gx;
+            gz = pair / gy;
+        } else {
+            idx = (kpre - hpre) + (k - hx);                             // index in the light list: [clip][qblk]
+            pair = idx / gx;
+            gz = nfull + pair / gy;
+        }
+        qblk = idx - pair * gx;
+        clip = pair % gy;
     }
     const int q0 = qblk * (64 * NW) + wave * 64;
-    const int nt = n / KT;
+    const int slot0 = gz * sps;
+    const int nfr = (slot0 + sps <= ksel) ? sps : ksel - slot0;
+    const int ntf = n / KT, nt = nfr * ntf;       // tiles per frame, tiles of this workgroup
 
     bf16x8 qf[QB][4];                             // Q^T fragments: query 16 b + c, channels 32 s + 8 g .. + 8
 #pragma unroll
@@ -388,7 +410,9 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     //  K tile: row = q >> 4 (key), LDS position q & 15 holds source chunk (q & 15) ^ att_kswz(row)
     //  V^T tile: row d = q >> 3, LDS position q & 7 holds source chunk (q & 7) ^ ((d >> 1) & 7)     (chunk = 8 keys)
     const char* kbase = (const char*)(kb + (int64_t)(clip * ksel + slot0) * n * D);
-    const char* vbase = (const char*)(vt_g + (int64_t)sel[clip * 5 + slot0] * D * n);
+    const char* vbase0 = (const char*)(vt_g + (int64_t)sel[clip * 5 + slot0] * D * n);
+    const char* vbase1 = (const char*)(vt_g + (int64_t)sel[clip * 5 + slot0 + (nfr > 1 ? 1 : 0)] * D * n);
+    auto v_tile = [&](int j) __attribute__((always_inline)) { return j < ntf ? vbase0 + (int64_t)j * KT * 2 : vbase1 + (int64_t)(j - ntf) * KT * 2; };
     unsigned koff[4], voff[4];
     {
         const int d = tid >> 3;
@@ -404,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     auto issue_tile = [&](int j) __attribute__((always_inline)) {
         const unsigned st = lds_wave + (unsigned)((j & (ATT_NS - 1)) * ATT_STAGE);
         const char* kp = kbase + (int64_t)j * KT * D * 2;
-        const char* vp = vbase + (int64_t)j * KT * 2;
+        const char* vp = v_tile(j);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(koff[i]), "s"(kp), "s"(st + (unsigned)(i * 4096)) : "memory");
@@ -476,7 +500,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         const int jn = j + 3 < nt ? j + 3 : nt - 1;
         const unsigned st = lds_wave + (unsigned)(((j + 3) & (ATT_NS - 1)) * ATT_STAGE);
         const char* kp = kbase + (int64_t)jn * KT * D * 2;
-        const char* vp = vbase + (int64_t)jn * KT * 2;
+        const char* vp = v_tile(jn);
         const unsigned dst[8] = {st, st + 4096u, st + 8192u, st + 12288u, st + K_TILE, st + K_TILE + 4096u, st + K_TILE + 8192u, st + K_TILE + 12288u};
         const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
         attn64_substep<0>(sa, sb, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     {
         const int flag = __syncthreads_or(bail);
         if (tid == 0) {
-            int32_t* f = redo + ((int64_t)(clip * nsplit + slot0) * gridDim.x + qblk) * 2;
+            int32_t* f = redo + ((int64_t)(clip * nsplit + gz) * gridDim.x + qblk) * 2;
             f[0] = flag ? 1 : 0;
             f[1] = flag ? 1 : 0;
         }
@@ -510,7 +534,7 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     for (int q = 0; q < QB; ++q) {
         const int qi = q0 + q * 16 + c;
         if (qi >= n) continue;
-        const int64_t row = ((int64_t)clip * nsplit + slot0) * n + qi;
+        const int64_t row = ((int64_t)clip * nsplit + gz) * n + qi;
         float* po = part_o + row * D + 4 * g;
 #pragma unroll
         for (int dblk = 0; dblk < 8; ++dblk) *(f32x4*)(po + dblk * 16) = o[dblk][q];
@@ -568,6 +592,21 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 
 }  // namespace
 
+static int attn_cus() {                          // CUs of the current device (cached per device)
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& c = cached[(unsigned)dev % 64];
+    if (c == 0) {
+        int n = 0;
+        c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return c;
+}
+
+static int g_attn_frames_per_wg = 0;             // 0 = automatic; 1 / 2 = forced (ppms_debug_mem_attn_frames_per_workgroup: tests)
+extern "C" void ppms_debug_mem_attn_frames_per_workgroup(int frames) { g_attn_frames_per_wg = (frames == 1 || frames == 2) ? frames : 0; }
+
 #ifdef PPMS_ATTN_TIMING
 extern "C" void ppms_debug_attn_timing(long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg_dev), &p, sizeof(p)); }   // tools/attn_phase_probe.py
 #endif
@@ -589,26 +628,30 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
     float* part_o = split ? (float*)split_ws : nullptr;
     float* part_ml = split ? part_o + (size_t)T * ksel * n * D : nullptr;
     hipStream_t st = (hipStream_t)stream;
+    int nsp = ksel;                                             // partial sets per clip
     if (use64) {
         const int g64 = (int)ceil_div(n, 64 * NW);
         int32_t* redo = (int32_t*)(part_ml + (size_t)T * ksel * n * 2);
-        dim3 grid64(g64, T, ksel), grid32(ceil_div(n, QW * NW), T, ksel);
+        // two picked frames per workgroup where the one-frame grid is at least two rounds of the chip (the 1/4 scale: 1000 workgroups)
+        const int sps = g_attn_frames_per_wg ? g_attn_frames_per_wg : ((g64 * T * ksel >= 2 * attn_cus() && ksel > 1) ? 2 : 1);
+        nsp = (int)ceil_div(ksel, sps);
+        dim3 grid64(g64, T, nsp), grid32(ceil_div(n, QW * NW), T, nsp);
         hipLaunchKernelGGL(mem_attn64_kernel, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
-                           sel, ksel, scale_log2, n, part_o, part_ml, redo);
+                           sel, ksel, scale_log2, n, part_o, part_ml, redo, sps);
         hipLaunchKernelGGL(mem_attn_kernel<false>, grid32, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
-                           sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, redo, 2 * g64);
+                           sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, redo, 2 * g64, sps);
     } else {
         dim3 grid(ceil_div(n, QW * NW), T, split ? ksel : 1);
         if (n % KT)
             hipLaunchKernelGGL(mem_attn_kernel<true>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
-                               sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, (int32_t*)nullptr, 0);
+                               sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, (int32_t*)nullptr, 0, 1);
         else
             hipLaunchKernelGGL(mem_attn_kernel<false>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
-                               sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, (int32_t*)nullptr, 0);
+                               sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, (int32_t*)nullptr, 0, 1);
     }
     if (split) {
         const int64_t total = (int64_t)T * n * 16;
-        hipLaunchKernelGGL(attn_combine_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, part_o, part_ml, ksel, beta, mf, mfg,
+        hipLaunchKernelGGL(attn_combine_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, part_o, part_ml, nsp, beta, mf, mfg,
                            (bf16_t*)out_bf16, n, total);
     }
     return ppms_check_launch("mem_attn");

@@ -573,11 +573,22 @@ def _attn_check(got, ref, operands, scale):
         assert err.mean().item() <= 0.2 * bound.mean().item(), (err.mean().item(), bound.mean().item())
 
 
+@pytest.fixture
+def attn_frames(lib, request):
+    """forces the 64-query kernel's frames per workgroup for one test (the automatic choice needs a 1/4-scale-sized grid to pick 2)"""
+    lib.load().ppms_debug_mem_attn_frames_per_workgroup(request.param)
+    yield request.param
+    lib.load().ppms_debug_mem_attn_frames_per_workgroup(0)
+
+
+@pytest.mark.parametrize("attn_frames", [0, 2], indirect=True)
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5)])
-def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split):
+def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
     """prep_q + prep_k + mem_attn against play_inputs + flash_attn_math (ppmstereo.py:517-552)."""
     L = lib
+    if attn_frames and not (split and n % 64 == 0):
+        pytest.skip("frames per workgroup only concerns the 64-query kernel")
     from ppmstereo_amd.engine import softmax_scale, temporal_pe
     h, w = (n // 32, 32) if n % 32 == 0 else (n // 20, 20) if n % 20 == 0 else (n // 18, 18)
     assert h * w == n
@@ -627,9 +638,11 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split):
     assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 1e-4
 
 
+@pytest.mark.parametrize("attn_frames", [0, 2], indirect=True)
 @pytest.mark.parametrize("boost", [40.0, 3.0])
-def test_mem_attn_sharp_softmax(lib, boost):
-    """One key per query dominates and sits in a late tile.  boost = 40: the score jumps ~650 log2 units above the
+def test_mem_attn_sharp_softmax(lib, boost, attn_frames):
+    """(attn_frames = 2: the dominating key sits in the SECOND frame of the workgroup's pair, whose scores are taken relative to the first
+    frame's reference.)  One key per query dominates and sits in a late tile.  boost = 40: the score jumps ~650 log2 units above the
     first keys, far beyond what the rescale-free 64-query kernel carries (2^60): its workgroups raise their redo flags
     and the 32-query online-softmax kernel recomputes them.  boost = 3: ~50 log2 units, carried in-kernel (P up to 2^50)."""
     L = lib

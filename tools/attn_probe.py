@@ -3,7 +3,7 @@ target for rocprofv3 --pmc passes.  Put the interpreter binary itself after `--`
 preloaded library has initialised the GPU, and an exec from such a process takes the box down):
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -- /usr/bin/python3 tools/attn_probe.py 4 1
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -- /usr/bin/python3 tools/attn_probe.py 4 1
-arguments: [reps] [split 0/1]"""
+arguments: [reps] [split 0/1] [frames per workgroup of the 64-query kernel: 0 = automatic, 1, 2]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,7 @@ from ppmstereo_amd import _lib as L
 from ppmstereo_amd.weights import hash_normal
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 split = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+frames = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = "cuda:0"
 T, n = 5, 10240
 qb = hash_normal((T, n, 128), 950).to(torch.bfloat16).to(dev)
@@ -20,6 +21,7 @@ sel = torch.arange(5, dtype=torch.int32)[None].expand(T, 5).contiguous().to(dev)
 X = L.SPTensor(T * n, 256, dev)
 beta = torch.tensor([0.5], device=dev)
 lib = L.load()
+lib.ppms_debug_mem_attn_frames_per_workgroup(frames)
 ws = torch.empty(int(lib.ppms_mem_attn_workspace_bytes(T, 5, n)), dtype=torch.uint8, device=dev) if split else None
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
 for a, b in ev:
