@@ -314,7 +314,18 @@ def main():
         whole.load_state_dict(sd, strict=True)
         whole = whole.to(dev).eval()
         video = Wm.hash_uniform((T, 2, 3, H, W), 613, 0.0, 255.0).round().contiguous()           # host tensor, as the reference's loader hands it over
-        call_ms = timed(lambda: whole.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=iters), reps=5)
+        def timed_median(fn, reps=7):             # (the call ends with its device->host copy: every repetition is a complete wall time; the median
+            fn()                                  #  keeps one slow repetition on a busy host from moving the number)
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t1)
+            return round(sorted(ts)[len(ts) // 2] * 1e3, 3)
+
+        call_ms = timed_median(lambda: whole.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=iters))
         encoders["whole_call_ms"] = call_ms
         encoders["whole_call_px_per_s"] = round(T * H * W / (call_ms * 1e-3), 1)
         encoders["whole_call_note"] = ("PPMStereo.forward_batch_test(host video) -> host disparity: H2D + encoders + SST + cascade + D2H, "
