@@ -67,43 +67,65 @@ static int in_slices_host(int N, int HW, int C) {                      // enough
     return S < 1 ? 1 : S;
 }
 
+// thread = 4 channels (one 16-byte load) of every 32nd pixel of the slice: 8 threads cover the workgroup's 32 channels, 32 pixel rows per step
+// (the 4-byte-per-lane form of round 2 ran at 2.4 TB/s: 4x the load instructions)
 __global__ __launch_bounds__(256) void instnorm_part_kernel(const float* __restrict__ x, int ld, int HW, int C, int S, float* __restrict__ part) {
-    __shared__ float red[8][32];
+    __shared__ float red[32][33];
     __shared__ float mean_s[32];
     const int n = blockIdx.y, c0 = blockIdx.x * 32, s = blockIdx.z;
-    const int lane = threadIdx.x & 31, row = threadIdx.x >> 5;            // 8 pixel rows x 32 channels per step
-    const int c = c0 + lane;
+    const int q = threadIdx.x & 7, row = threadIdx.x >> 3;                // channels c0 + 4 q .. + 3, pixel rows row, row + 32, ...
+    const int c = c0 + 4 * q;
     const int chunk = (HW + S - 1) / S;
     const int p0 = s * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
     const int cnt = p1 - p0;
-    const float* xp = x + (int64_t)n * HW * ld;
-    float acc = 0.0f;
-    if (c < C)
-        for (int p = p0 + row; p < p1; p += 8) acc += xp[(int64_t)p * ld + c];
-    red[row][lane] = acc;
-    __syncthreads();
-    if (row == 0) {
-        float t = 0.0f;
-        for (int r = 0; r < 8; ++r) t += red[r][lane];
-        mean_s[lane] = cnt > 0 ? t / (float)cnt : 0.0f;
-    }
-    __syncthreads();
-    const float mean = mean_s[lane];
-    acc = 0.0f;
-    if (c < C)
-        for (int p = p0 + row; p < p1; p += 8) {
-            const float d = xp[(int64_t)p * ld + c] - mean;
-            acc += d * d;
+    const float* xp = x + (int64_t)n * HW * ld + c;
+    const bool vec = (ld & 3) == 0 && c + 4 <= C && (((uintptr_t)x) & 15) == 0;      // (uniform per thread; the tail channels of a C % 4 != 0 layer go one by one)
+    auto load4 = [&](int p, float (&v)[4]) {
+        if (vec) {
+            const f32x4 t = *(const f32x4*)(xp + (int64_t)p * ld);
+            v[0] = t[0], v[1] = t[1], v[2] = t[2], v[3] = t[3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (c + j < C) ? xp[(int64_t)p * ld + j] : 0.0f;
         }
-    __syncthreads();
-    red[row][lane] = acc;
-    __syncthreads();
-    if (row == 0 && c < C) {
-        float t = 0.0f;
-        for (int r = 0; r < 8; ++r) t += red[r][lane];
-        float* o = part + (((int64_t)n * S + s) * C + c) * 2;
-        o[0] = mean;
-        o[1] = t;
+    };
+    auto reduce_rows = [&](const float (&acc)[4], float scale_by, float* dst) {   // sum over the 32 row groups in row order -> dst[32 channels]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[row][4 * q + j] = acc[j];
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float t = 0.0f;
+            for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+            dst[threadIdx.x] = t * scale_by;
+        }
+        __syncthreads();
+    };
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int p = p0 + row; p < p1; p += 32) {
+        float v[4];
+        load4(p, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j];
+    }
+    reduce_rows(acc, cnt > 0 ? 1.0f / (float)cnt : 0.0f, mean_s);
+    float mean[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mean[j] = mean_s[4 * q + j], acc[j] = 0.0f;
+    for (int p = p0 + row; p < p1; p += 32) {                            // second pass: the slice is L2 resident
+        float v[4];
+        load4(p, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[j] - mean[j];
+            acc[j] += d * d;
+        }
+    }
+    __shared__ float m2_s[32];
+    reduce_rows(acc, 1.0f, m2_s);
+    if (threadIdx.x < 32 && c0 + (int)threadIdx.x < C) {
+        float* o = part + (((int64_t)n * S + s) * C + c0 + threadIdx.x) * 2;
+        o[0] = mean_s[threadIdx.x];
+        o[1] = m2_s[threadIdx.x];
     }
 }
 
@@ -113,15 +135,22 @@ __global__ __launch_bounds__(256) void instnorm_merge_kernel(const float* __rest
     const int n = idx / C, c = idx - n * C;
     const int chunk = (HW + S - 1) / S;
     float na = 0.0f, mean = 0.0f, m2 = 0.0f;
-    for (int s = 0; s < S; ++s) {
-        const int p0 = s * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
-        const float nb = (float)(p1 - p0);
-        if (nb <= 0.0f) continue;
-        const float* o = part + (((int64_t)n * S + s) * C + c) * 2;
-        const float d = o[0] - mean, nn = na + nb;
-        mean += d * (nb / nn);
-        m2 += o[1] + d * d * (na * nb / nn);
-        na = nn;
+    const f32x2* pp = (const f32x2*)(part + ((int64_t)n * S * C + c) * 2);            // slice s at pp[s * C]
+    for (int s0 = 0; s0 < S; s0 += 8) {          // the 8 loads of a group are in flight together (one by one the S ~ 50 dependent-looking
+        f32x2 o[8];                              // round trips were the kernel: 13.6 us); the update order stays slice order
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (s0 + j < S) ? pp[(int64_t)(s0 + j) * C] : (f32x2){0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int s = s0 + j;
+            const int p0 = s * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
+            const float nb = (float)(p1 - p0);
+            if (s >= S || nb <= 0.0f) continue;
+            const float d = o[j][0] - mean, nn = na + nb;
+            mean += d * (nb / nn);
+            m2 += o[j][1] + d * d * (na * nb / nn);
+            na = nn;
+        }
     }
     stats[(int64_t)idx * 2] = mean;
     stats[(int64_t)idx * 2 + 1] = 1.0f / sqrtf(m2 / (float)HW + eps);
@@ -143,13 +172,32 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(const float* __rest
         rh = *(const bf16x8*)((const bf16_t*)res.hi + p * res.ld + c0);
         rl = *(const bf16x8*)((const bf16_t*)res.lo + p * res.ld + c0);
     }
+    float xv[8], sm[8], sr[8];
+    if (c0 + 8 <= C && (ld & 3) == 0 && (C & 1) == 0 && ((((uintptr_t)x) | ((uintptr_t)stats)) & 15) == 0) {       // 16-byte loads: the pixel's 8 values and their 8 (mean, rstd) pairs
+        const f32x4 a = *(const f32x4*)(x + p * ld + c0), b = *(const f32x4*)(x + p * ld + c0 + 4);
+        const f32x4* st4 = (const f32x4*)(stats + ((int64_t)n * C + c0) * 2);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xv[e] = a[e], xv[4 + e] = b[e];
+            const f32x4 t = st4[e];
+            sm[2 * e] = t[0], sr[2 * e] = t[1], sm[2 * e + 1] = t[2], sr[2 * e + 1] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + e;
+            const bool in = c < C;
+            xv[e] = in ? x[p * ld + c] : 0.0f;
+            sm[e] = in ? stats[((int64_t)n * C + c) * 2] : 0.0f;
+            sr[e] = in ? stats[((int64_t)n * C + c) * 2 + 1] : 0.0f;
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int c = c0 + e;
         float v = 0.0f;
         if (c < C) {
-            const float* st = stats + ((int64_t)n * C + c) * 2;
-            v = (x[p * ld + c] - st[0]) * st[1];
+            v = (xv[e] - sm[e]) * sr[e];
             if (has_res) v += join_bf16(rh[e], rl[e]);
             if (relu) v = fmaxf(v, 0.0f);
         }
@@ -308,7 +356,15 @@ __global__ __launch_bounds__(256) void grn_merge_kernel(const float* __restrict_
     float local = 0.0f;
     for (int c = threadIdx.x; c < C; c += 256) {
         float t = 0.0f;
-        for (int s = 0; s < S; ++s) t += part[((int64_t)n * S + s) * C + c];
+        const float* pp = part + (int64_t)n * S * C + c;
+        for (int s0 = 0; s0 < S; s0 += 8) {      // 8 loads in flight, summed in slice order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (s0 + j < S) ? pp[(int64_t)(s0 + j) * C] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (s0 + j < S) t += v[j];
+        }
         const float g = sqrtf(t);
         nx[(int64_t)n * C + c] = g;
         local += g;

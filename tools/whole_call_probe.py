@@ -57,3 +57,21 @@ for name, fn in (("fnet", lambda: m.fnet([i1, i2])), ("cnet", lambda: m.cnet(i1)
     t0 = time.perf_counter(); fn(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print(f"{name}: enqueue {1e3 * (t1 - t0):.1f} ms, total {1e3 * (t2 - t0):.1f} ms")
 print("host: cpus", os.cpu_count(), "loadavg", os.getloadavg())
+
+# the phases of one call, synchronised behind each (which one carries a slow repetition on a busy host?)
+from ppmstereo_amd.ppmstereo import InputPadder
+print("phases per call (ms): H2D | pad + forward (encoders + SST + cascade) | unpad + D2H")
+for _ in range(8):
+    t0 = time.perf_counter()
+    win = video.to(dev)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    left, right = win[:, 0], win[:, 1]
+    padder = InputPadder(left.shape, divis_by=32)
+    left, right = padder.pad(left, right)
+    d, u = m.forward(left[None], right[None], iters=iters, test_mode=True)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    dh, uh = padder.unpad(d[0])[:, None].cpu(), padder.unpad(u[0])[:, None].cpu()
+    t3 = time.perf_counter()
+    print(f"   {1e3 * (t1 - t0):7.2f} | {1e3 * (t2 - t1):7.2f} | {1e3 * (t3 - t2):7.2f}")
