@@ -583,7 +583,7 @@ def attn_frames(lib, request):
 
 @pytest.mark.parametrize("attn_frames", [0, 2], indirect=True)
 @pytest.mark.parametrize("split", [False, True])
-@pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5)])
+@pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5), (5, 320, 5)])      # (320: a partly filled 256-query block)
 def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
     """prep_q + prep_k + mem_attn against play_inputs + flash_attn_math (ppmstereo.py:517-552)."""
     L = lib
