@@ -22,6 +22,9 @@
 namespace {
 
 constexpr int BK = 32;
+#ifndef CONV2_ABL_A
+#define CONV2_ABL_A 0        // ablation builds (-DCONV2_ABL_A=1): every k-step loads the FIRST step's weights (cache hits): wrong results, timing only
+#endif
 constexpr int A_BLK = 64 * BK * 2 * 2;       // one 64-cout block, hi + lo planes: 8 KiB
 
 struct Geo2 {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
 
     u32x4 ra[4], rbh[MAXSLOT], rbl[MAXSLOT];
     auto load_a = [&](int ks) {
-        const char* wp = wbase + (int64_t)ks * wstep;
+        const char* wp = wbase + (int64_t)(CONV2_ABL_A ? 0 : ks) * wstep;
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = gload16(wp + i * NT * 16);
     };
