@@ -55,6 +55,20 @@ struct ppms_device_once {
         std::call_once(flag[(unsigned)dev % MAX_DEV], f);
     }
 };
+
+// compute units of the current device (cached per device; 256 if the query fails)
+inline int ppms_num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    int& c = cached[(unsigned)dev % 64];
+    if (c == 0) {
+        int n = 0;
+        c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return c;
+}
+
 #endif
 
 // ---- device helpers ----------------------------------------------------------------------------

@@ -455,18 +455,6 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
 
 // tile shape / window geometry for a descriptor; picks (NBT, C) with the best chip fill; false when nothing fits
 // compute units of the current device (the planner deals one workgroup per CU: 256 on MI355X); queried once per process and device
-static int conv5_cus() {
-    static int cached[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int& c = cached[(unsigned)dev % 64];
-    if (c == 0) {
-        int n = 0;
-        c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return c;
-}
-
 static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = false) {
     const bool gemm = d->kw == 1 && d->kh == 1;                              // no spatial sweep: windows of 16 RW channels, no halo
     const int mode = gemm ? 3 : (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);      // 0: x sweep, 1: y sweep, 2: 2-D sweep, 3: GEMM
@@ -492,7 +480,7 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = 
             const int64_t tiles = (int64_t)((d->W + C - 1) / C) * ((d->H + R - 1) / R) * d->T;
             // useful pixels per CU-slot-round: rounds of 256 workgroups (one per CU), each costing nbt blocks
             // (K-sliced launches of small maps fill the chip through the slices: there only the ragged tile edges count)
-            const int64_t cus = conv5_cus();
+            const int64_t cus = ppms_num_cus();
             const double eff = sliced ? (double)d->T * d->H * d->W / ((double)tiles * 32 * nbt)
                                       : (double)d->T * d->H * d->W / ((double)((tiles + cus - 1) / cus) * cus * 32 * nbt);
             if (eff > best + 1e-9 || (eff > best - 1e-9 && Wr < bestWr)) best = eff, bestC = C, bestN = nbt, bestWr = Wr;
@@ -546,7 +534,7 @@ extern "C" int ppms_conv_gemm5_applicable(const ppms_conv* d) {
         if (d->seg[s].c <= 0 || d->seg[s].c % 16 != 0) return 0;
     Geo5 g;
     if (!plan5(d, g)) return 0;                     // (kh = kw = 1: GEMM mode, segments in multiples of 64 / 32 channels)
-    return (int64_t)g.tiles_x * g.tiles_y * d->T >= conv5_cus() * 25 / 32 ? 1 : 0;   // (200 of 256) fewer workgroups than CUs: conv_gemm2's K slicing fills the chip better
+    return (int64_t)g.tiles_x * g.tiles_y * d->T >= ppms_num_cus() * 25 / 32 ? 1 : 0;   // (200 of 256) fewer workgroups than CUs: conv_gemm2's K slicing fills the chip better
 }
 
 // smallest number of windows any (tile, K-group) pair of the launch sweeps: frames at the ends of the volume skip the temporal taps
@@ -573,7 +561,7 @@ extern "C" int ppms_conv_gemm5_slices(const ppms_conv* d) {
     Geo5 g;
     if (!plan5(d, g, 0, true) || g.nsweep < 3) return 0;
     const int64_t tiles = (int64_t)g.tiles_x * g.tiles_y * d->T;
-    const int cus = conv5_cus();
+    const int cus = ppms_num_cus();
     if (tiles >= cus * 25 / 32 || tiles < 8) return 0;
     int ns = (int)((cus + tiles - 1) / tiles);                        // one workgroup per CU, one round
     if (tiles * ns > cus * 9 / 8) --ns;

@@ -592,18 +592,6 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 
 }  // namespace
 
-static int attn_cus() {                          // CUs of the current device (cached per device)
-    static int cached[64] = {0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    int& c = cached[(unsigned)dev % 64];
-    if (c == 0) {
-        int n = 0;
-        c = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
-    }
-    return c;
-}
-
 static int g_attn_frames_per_wg = 0;             // 0 = automatic; 1 / 2 = forced (ppms_debug_mem_attn_frames_per_workgroup: tests)
 extern "C" void ppms_debug_mem_attn_frames_per_workgroup(int frames) { g_attn_frames_per_wg = (frames == 1 || frames == 2) ? frames : 0; }
 
@@ -633,7 +621,7 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         const int g64 = (int)ceil_div(n, 64 * NW);
         int32_t* redo = (int32_t*)(part_ml + (size_t)T * ksel * n * 2);
         // two picked frames per workgroup where the one-frame grid is at least two rounds of the chip (the 1/4 scale: 1000 workgroups)
-        const int sps = g_attn_frames_per_wg ? g_attn_frames_per_wg : ((g64 * T * ksel >= 2 * attn_cus() && ksel > 1) ? 2 : 1);
+        const int sps = g_attn_frames_per_wg ? g_attn_frames_per_wg : ((g64 * T * ksel >= 2 * ppms_num_cus() && ksel > 1) ? 2 : 1);
         nsp = (int)ceil_div(ksel, sps);
         dim3 grid64(g64, T, nsp), grid32(ceil_div(n, QW * NW), T, nsp);
         hipLaunchKernelGGL(mem_attn64_kernel, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
