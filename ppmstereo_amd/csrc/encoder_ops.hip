@@ -304,24 +304,71 @@ __global__ __launch_bounds__(256) void dwconv_plain_kernel(ppms_sp x, float* __r
 // channel-last data): x fp32 [pixel][ld] -> split planes.  One wave per pixel, lanes stride the channels.
 __global__ __launch_bounds__(256) void layernorm_any_kernel(const float* __restrict__ x, int ld, const float* __restrict__ w, const float* __restrict__ b,
                                                             float eps, ppms_sp out, int64_t pixels, int C) {
+    // a wave per pixel; a lane owns 8 consecutive channels per round of 512 (two 16-byte loads, one 16-byte store per plane); the pixel's
+    // values stay in registers between the three passes (C <= 1024: the host checks); sums in lane order, then a butterfly: deterministic
     const int lane = threadIdx.x & 63;
     const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (pix >= pixels) return;
     const float* xp = x + pix * ld;
+    const bool vec = (ld & 3) == 0 && (C & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)w) | ((uintptr_t)b)) & 15) == 0;
+    float v[2][8];
     float s = 0.0f;
-    for (int c = lane; c < C; c += 64) s += xp[c];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int c0 = r * 512 + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[r][j] = 0.0f;
+        if (c0 < C) {
+            if (vec) {
+                const f32x4 a = *(const f32x4*)(xp + c0), a2 = *(const f32x4*)(xp + c0 + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[r][j] = a[j], v[r][4 + j] = a2[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c0 + j < C) v[r][j] = xp[c0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[r][j];
+        }
+    }
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
     const float mean = s / (float)C;
     float q = 0.0f;
-    for (int c = lane; c < C; c += 64) q += (xp[c] - mean) * (xp[c] - mean);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int c0 = r * 512 + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (c0 + j < C) q += (v[r][j] - mean) * (v[r][j] - mean);
+    }
     for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
     const float rstd = 1.0f / sqrtf(q / (float)C + eps);
-    for (int c = lane; c < out.c; c += 64) {
-        const float y = c < C ? (xp[c] - mean) * rstd * w[c] + b[c] : 0.0f;
-        bf16_t hi, lo;
-        split_bf16(y, hi, lo);
-        ((bf16_t*)out.hi)[pix * out.ld + c] = hi;
-        ((bf16_t*)out.lo)[pix * out.ld + c] = lo;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int c0 = r * 512 + lane * 8;
+        if (c0 >= out.c) continue;
+        bf16x8 oh, ol;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            const float y = c < C ? (v[r][j] - mean) * rstd * w[c] + b[c] : 0.0f;
+            bf16_t hi, lo;
+            split_bf16(y, hi, lo);
+            oh[j] = hi;
+            ol[j] = lo;
+        }
+        if (c0 + 8 <= out.c && (out.ld & 7) == 0 && ((((uintptr_t)out.hi) | ((uintptr_t)out.lo)) & 15) == 0) {
+            *(bf16x8*)((bf16_t*)out.hi + pix * out.ld + c0) = oh;
+            *(bf16x8*)((bf16_t*)out.lo + pix * out.ld + c0) = ol;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (c0 + j < out.c) {
+                    ((bf16_t*)out.hi)[pix * out.ld + c0 + j] = oh[j];
+                    ((bf16_t*)out.lo)[pix * out.ld + c0 + j] = ol[j];
+                }
+        }
     }
 }
 
@@ -329,25 +376,34 @@ __global__ __launch_bounds__(256) void layernorm_any_kernel(const float* __restr
 // out = gamma * (h * Nx) + beta + h.  Squares summed per pixel slice (part kernel), slices merged in order + the channel mean
 // (one workgroup per sample), then the apply kernel.  Deterministic.
 __global__ __launch_bounds__(256) void grn_part_kernel(const float* __restrict__ x, int ld, int HW, int C, int S, float* __restrict__ part) {
-    __shared__ float red[8][32];
+    __shared__ float red[32][33];
     const int n = blockIdx.y, c0 = blockIdx.x * 32, s = blockIdx.z;
-    const int lane = threadIdx.x & 31, row = threadIdx.x >> 5;
-    const int c = c0 + lane;
+    const int q = threadIdx.x & 7, row = threadIdx.x >> 3;                // thread = 4 channels (one 16-byte load) of every 32nd pixel of the slice
+    const int c = c0 + 4 * q;
     const int chunk = (HW + S - 1) / S;
     const int p0 = s * chunk, p1 = (p0 + chunk < HW) ? p0 + chunk : HW;
-    const float* xp = x + (int64_t)n * HW * ld;
-    float acc = 0.0f;
-    if (c < C)
-        for (int p = p0 + row; p < p1; p += 8) {
-            const float v = xp[(int64_t)p * ld + c];
-            acc += v * v;
+    const float* xp = x + (int64_t)n * HW * ld + c;
+    const bool vec = (ld & 3) == 0 && c + 4 <= C && (((uintptr_t)x) & 15) == 0;
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int p = p0 + row; p < p1; p += 32) {
+        float v[4];
+        if (vec) {
+            const f32x4 t = *(const f32x4*)(xp + (int64_t)p * ld);
+            v[0] = t[0], v[1] = t[1], v[2] = t[2], v[3] = t[3];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (c + j < C) ? xp[(int64_t)p * ld + j] : 0.0f;
         }
-    red[row][lane] = acc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] += v[j] * v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[row][4 * q + j] = acc[j];
     __syncthreads();
-    if (row == 0 && c < C) {
+    if (threadIdx.x < 32 && c0 + (int)threadIdx.x < C) {
         float t = 0.0f;
-        for (int r = 0; r < 8; ++r) t += red[r][lane];
-        part[((int64_t)n * S + s) * C + c] = t;
+        for (int r = 0; r < 32; ++r) t += red[r][threadIdx.x];
+        part[((int64_t)n * S + s) * C + c0 + threadIdx.x] = t;
     }
 }
 __global__ __launch_bounds__(256) void grn_merge_kernel(const float* __restrict__ part, int C, int S, float* __restrict__ nx) {
@@ -387,11 +443,23 @@ __global__ __launch_bounds__(256) void grn_apply_kernel(const float* __restrict_
     const int64_t p = idx / groups;
     const int64_t n = p / HW;
     bf16x8 oh, ol;
+    float xv[8], nv[8], gv[8], bv[8];
+    if ((ld & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)nx) | ((uintptr_t)gamma) | ((uintptr_t)beta)) & 15) == 0) {      // (C % 8 == 0: the host checks)
+#pragma unroll
+        for (int h4 = 0; h4 < 2; ++h4) {
+            const f32x4 a = *(const f32x4*)(x + p * ld + c0 + 4 * h4), b4 = *(const f32x4*)(nx + n * C + c0 + 4 * h4);
+            const f32x4 g4 = *(const f32x4*)(gamma + c0 + 4 * h4), e4 = *(const f32x4*)(beta + c0 + 4 * h4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[4 * h4 + j] = a[j], nv[4 * h4 + j] = b4[j], gv[4 * h4 + j] = g4[j], bv[4 * h4 + j] = e4[j];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xv[e] = x[p * ld + c0 + e], nv[e] = nx[n * C + c0 + e], gv[e] = gamma[c0 + e], bv[e] = beta[c0 + e];
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const int c = c0 + e;
-        const float v = x[p * ld + c];
-        const float y = gamma[c] * (v * nx[n * C + c]) + beta[c] + v;
+        const float v = xv[e];
+        const float y = gv[e] * (v * nv[e]) + bv[e] + v;
         bf16_t hh, ll;
         split_bf16(y, hh, ll);
         oh[e] = hh;
@@ -426,6 +494,7 @@ extern "C" int ppms_dwconv(ppms_sp x, float* y, int ldy, const float* w, const f
 
 extern "C" int ppms_layernorm_any(const float* x, int ld, const float* w, const float* b, float eps, ppms_sp out, int64_t pixels, int C, void* stream) {
     PPMS_REQUIRE(x && w && b && out.hi && out.lo && pixels > 0 && C > 0 && ld >= C && out.c >= C && eps > 0.0f, "layernorm_any: bad arguments");
+    PPMS_REQUIRE(out.c <= 1024, "layernorm_any: at most 1024 channels (got %d)", out.c);
     hipLaunchKernelGGL(layernorm_any_kernel, dim3(ceil_div(pixels, 4)), dim3(256), 0, (hipStream_t)stream, x, ld, w, b, eps, out, pixels, C);
     return ppms_check_launch("layernorm_any");
 }
