@@ -41,7 +41,6 @@ for _ in range(3):
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     print(f"H2D from pinned memory: {1e3 * (t1 - t0):.2f} ms")
-hp = m.hot if hasattr(m, "hot") else m
 from ppmstereo_amd.synth import synth_cascade_feats
 feats = {k: v.to(dev) for k, v in synth_cascade_feats(T, H, W).items()}
 for _ in range(3):
