@@ -5,7 +5,8 @@ The reference lives read-only at /root/reference and never travels: this script 
 ``ppmstereo_amd.weights`` and the synthetic inputs of ``ppmstereo_amd.synth`` and stores only
 OUTPUT vectors (inputs and weights are regenerated from their seeds by the tests).
 
-    python tools/gen_golden.py            # rewrites tests/golden/
+    python tools/gen_golden.py                     # rewrites tests/golden/
+    python tools/gen_golden.py it10 --out /tmp/g   # only the iters=10 fixtures, into another directory
 
 Nothing in tests/, bench.py or smoke() reads /root/reference at run time.
 """
@@ -70,6 +71,14 @@ from models.core import extractor as rext                  # noqa: E402
 from models.core import attention as ratt                  # noqa: E402
 from models.core import convnext as rcnx                    # noqa: E402
 
+# The fixtures must come from the REFERENCE: this repository ships same-named modules (models/core/{corr,ppmstereo,
+# ppmtereo_update}.py, the drop-in import path) as portions of the same PEP 420 namespace, and only the sys.path order above
+# (REF first) decides which portion a name binds to.  Refuse to generate anything if one of them is the build's.
+for _m in (rcorr, rupd, rppm, rext, ratt, rcnx):
+    _f = os.path.realpath(_m.__file__)
+    assert _f.startswith(REF + os.sep), f"{_m.__name__} was imported from {_f}, not from the reference under {REF}"
+assert rppm.PPMStereo.__module__ == "models.core.ppmstereo" and not hasattr(rppm.PPMStereo, "hot"), "PPMStereo is not the reference's"
+
 from ppmstereo_amd import weights as Wm                    # noqa: E402
 from ppmstereo_amd.synth import T40_CASES, synth_scale_inputs   # noqa: E402
 from ppmstereo_amd.weights import hash_normal, hash_uniform  # noqa: E402
@@ -91,6 +100,8 @@ rppm.flash_attn_func = flash_attn_func
 torch.manual_seed(0)
 torch.set_num_threads(8)
 OUT = os.path.join(ROOT, "tests", "golden")
+if "--out" in sys.argv:                          # e.g. the CPU test that regenerates fixtures into a temp dir and compares
+    OUT = os.path.abspath(sys.argv[sys.argv.index("--out") + 1])
 os.makedirs(OUT, exist_ok=True)
 
 
