@@ -1,6 +1,7 @@
 """Benchmark of the PPMStereo hot path on MI355X (contract: see the round prompt / DESIGN.md section 5).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8 --steps 10 --warmup 3          # no launcher around it: starts the 8 ranks itself (launch_ranks), exit code = theirs
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = one pass of the hot path over one clip of BASELINE config 2: T=5 frames, 320x512, iters=10
@@ -69,6 +70,45 @@ def cpu_baseline(T, H, W, iters, threads):
                 seconds_per_clip=total)
 
 
+def launch_ranks(n, argv):
+    """One process per GPU on this node through torch.distributed.run (the same command line the driver uses), rendezvous on 127.0.0.1 at a free
+    port; rank 0's JSON line goes to this process's stdout.  Returns the launcher's exit code (non-zero if any rank failed)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL's device-buffer sharing needs it on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, D, rank, world):
+    """--dry-run: everything around the measurement (rendezvous, barrier, max-over-ranks, frame-shard planning, the one JSON line from rank 0)
+    with a stub in place of the step.  No GPU, no kernels, value = null: a rehearsal of the launch path, never a measurement."""
+    T = args.T
+    sharded = world > 1 and not args.replicas and T % world == 0 and T // world >= 2
+    shard = D.FrameShard(rank, world, T) if sharded else None
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(1e-3 * (1 + rank))                 # ranks differ: max-over-ranks must pick the slowest
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0)
+    frames = D.sum_over_ranks(float(shard.f if sharded else T))
+    if rank == 0:
+        print(json.dumps(dict(metric="disparity-px/s", value=None, unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                              ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="strong" if sharded else "weak",
+                              dry_run=True, backend=torch.distributed.get_backend() if world > 1 else None, frames_over_ranks=frames,
+                              config=dict(workload="dry run: stub step, no GPU work", T=T, H=args.H, W=args.W, iters=args.iters,
+                                          parallelism=(f"frames sharded {T // world}/GPU x{world}" if sharded else f"replicas x{world}")))))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 TIMING_EVERY = 10         # per-launch events in steps 0, 10, 20, ... of the timed region (one step's launches: 117 convs, 20 attention calls)
 
 
@@ -90,10 +130,21 @@ def main():
                     "ppmstereo_amd.ppmstereo.ClipPipeline; measured 40.8 vs 41.8 ms per clip -- the 1/4 scale leaves ~16 CUs to the second stream); off by "
                     "default: the headline number is one clip after the other.  latency_ms_per_clip (one clip alone) is reported either way")
     ap.add_argument("--replicas", action="store_true", help="N > 1: force clip replicas even when T divides over the ranks")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / argument plumbing only: the ranks form the process group, run a stub step "
+                    "(no GPU work), take the barrier + max-over-ranks path and rank 0 prints a line with value = null (CPU rehearsal, tests/test_bench_launch.py)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) and hand back their exit code.
+        # Nothing has touched the GPU in this process (importing torch does not), and it never does: it only waits for the children.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     from ppmstereo_amd import dist as D
     rank, world, local = D.init_from_env()
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.dry_run:
+        return dry_run(args, D, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (the product has no CPU path)"
     torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
     dev = torch.device("cuda", torch.cuda.current_device())

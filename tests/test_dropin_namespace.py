@@ -63,14 +63,16 @@ print("ok")
 
 
 @needs_ref
-def test_fixture_generator_reproduces_committed_iters10_fixtures(tmp_path):
-    """`python tools/gen_golden.py it10` as committed: runs the reference's own PPMStereo.forward / forward_update_block and reproduces the two
-    committed north-star fixtures bit for bit."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden.py"), "it10", "--out", str(tmp_path)],
-                       capture_output=True, text=True, cwd=ROOT, timeout=900, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+def test_fixture_generator_reproduces_every_committed_fixture(tmp_path):
+    """`python tools/gen_golden.py` as committed (~40 s): runs the reference's own modules and reproduces ALL committed fixtures bit for bit --
+    the recipe that pins the oracle works, and tests/golden/ holds nothing but its output."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden.py"), "--out", str(tmp_path)],
+                       capture_output=True, text=True, cwd=ROOT, timeout=1500, env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
     assert r.returncode == 0, r.stderr[-2000:]
-    for name in ("cascade_it10", "fub04_it10"):
-        new, old = np.load(tmp_path / f"{name}.npz"), np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))
-        assert set(new.files) == set(old.files)
+    committed = sorted(f for f in os.listdir(os.path.join(ROOT, "tests", "golden")) if f.endswith(".npz"))
+    assert sorted(os.listdir(tmp_path)) == committed and len(committed) >= 29
+    for f in committed:
+        new, old = np.load(tmp_path / f), np.load(os.path.join(ROOT, "tests", "golden", f))
+        assert set(new.files) == set(old.files), f
         for k in new.files:
-            assert np.array_equal(new[k], old[k], equal_nan=True), (name, k)
+            assert np.array_equal(new[k], old[k], equal_nan=True), (f, k)
