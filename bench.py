@@ -357,7 +357,7 @@ def main():
         # tensor -> pad, host->device copy, fnet + cnet + SST, the cascade, unpad, device->host copy.  PCIe inclusive; never `value`.
         from ppmstereo_amd.ppmstereo import PPMStereo
         del fnet, cnet, sst
-        whole = PPMStereo()
+        whole = PPMStereo.shipped()
         whole.load_hot_path_weights(Wm.hot_path_weights())
         whole.fnet.load_state_dict(Wm.fnet_weights(), strict=True), whole.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
         sd = whole.state_dict()

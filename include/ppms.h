@@ -24,7 +24,7 @@ extern "C" {
 #define PPMS_ELAUNCH (-2)  /* HIP launch error */
 #define PPMS_ENODEV (-3)   /* no gfx950 device */
 
-#define PPMS_ABI_VERSION 3
+#define PPMS_ABI_VERSION 4
 
 int ppms_version(void);
 const char* ppms_last_error(void);
@@ -259,17 +259,16 @@ int ppms_attn_prep_k(const float* key, int ld, const float* pe, const int32_t* s
  * qb: bf16 [T][n][128]; kb: bf16 [T][ksel][n][128]; vt: bf16 [T][128][n] (per-frame transposed values, picked through
  * sel); mf / mfg: SP views (128 channels).  out_bf16 (optional): bf16 [T][n][128] raw attention output. */
 int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
-                  ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, void* stream);
+                  ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, void* stream);
 /* split_ws (optional, caller-owned, ppms_mem_attn_workspace_bytes(T, ksel, n) bytes, contents need not be
  * initialised): when given, every picked frame (or pair of picked frames) is processed by its own workgroups, which leave fp32 partials
  * (O, m, l) in the workspace, and a combine kernel merges them; with n % 64 == 0 this is the 64-queries-per-wave
  * LDS-DMA kernel (rescale-free accumulation + a fix-up pass for tiles it flags, see mem_attn.hip).  NULL = one fused
- * launch of the 32-query online-softmax kernel. */
+ * launch of the 32-query online-softmax kernel.
+ * frames_per_workgroup: the 64-query kernel gives a workgroup ONE picked frame, or TWO consecutive ones where the one-frame grid would
+ * run at least two rounds on the chip (fewer partials to write and combine).  0 = the library's choice, 1 / 2 = this call uses that
+ * many (a per-call argument: the library keeps no mutable state).  The same softmax either way (different summation order). */
 int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
-/* Test hook: the 64-query kernel gives a workgroup ONE picked frame, or TWO consecutive ones where the one-frame grid would run
- * at least two rounds on the chip (fewer partials to write and combine).  frames = 1 / 2 forces the choice (process-wide, not
- * thread-safe), anything else restores the automatic one.  Results are the same softmax either way (different summation order). */
-void ppms_debug_mem_attn_frames_per_workgroup(int frames);
 
 /* Fused chain of up to three per-pixel (1x1, <= 64 input channels) layers with GELU, optional residual from the chain
  * input and optional depthwise-1x1 post step: the ffn1 / pw / ffn2 parts of PCBlock4_Deep_nopool_res

@@ -106,9 +106,8 @@ _SIGS = {
     "ppms_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, SP, SP, c_int64, c_int, c_void_p]),
     "ppms_linear_attention_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "ppms_linear_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, SP, c_int, c_int, c_int, c_int, c_void_p]),
-    "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "ppms_mem_attn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
-    "ppms_debug_mem_attn_frames_per_workgroup": (None, [c_int]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -133,7 +132,7 @@ def load() -> C.CDLL:
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.ppms_version() != 3:
+    if lib.ppms_version() != 4:
         raise RuntimeError("ppmstereo_amd: libppms.so ABI version mismatch")
     a, b, c = c_int(), c_int(), c_int()
     lib.ppms_struct_sizes(C.byref(a), C.byref(b), C.byref(c))

@@ -101,6 +101,9 @@ extern "C" int ppms_time_attn(ppms_sp x, const float* ln_w, const float* ln_b, p
     PPMS_REQUIRE((x.c == 384 || x.c == 256) && out.c == x.c && heads == 8,
                  "time_attn: C = 384 (update_block16) or 256 (SST block), 8 heads expected, got C=%d heads=%d", x.c, heads);
     PPMS_REQUIRE(T >= 1 && T <= 64 && n >= 1, "time_attn: bad T=%d n=%d", T, n);
+    // the kernel reads a lane's channels as 32-bit pairs: rows must start on 4-byte boundaries
+    PPMS_REQUIRE(x.ld % 2 == 0 && out.ld % 2 == 0 && ((uintptr_t)x.hi & 3) == 0 && ((uintptr_t)x.lo & 3) == 0,
+                 "time_attn: x must be a 4-byte aligned SP view with an even row stride (ld=%d)", x.ld);
     const int lanes_per_head = 64 / heads;
     const float scale = 1.0f / sqrtf((float)(x.c / heads));
     if (x.c == 384)

@@ -592,16 +592,14 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 
 }  // namespace
 
-static int g_attn_frames_per_wg = 0;             // 0 = automatic; 1 / 2 = forced (ppms_debug_mem_attn_frames_per_workgroup: tests)
-extern "C" void ppms_debug_mem_attn_frames_per_workgroup(int frames) { g_attn_frames_per_wg = (frames == 1 || frames == 2) ? frames : 0; }
-
 #ifdef PPMS_ATTN_TIMING
 extern "C" void ppms_debug_attn_timing(long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg_dev), &p, sizeof(p)); }   // tools/attn_phase_probe.py
 #endif
 extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
-                             ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, void* stream) {
+                             ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, void* stream) {
     PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
     PPMS_REQUIRE(ksel >= 1 && ksel <= 5 && T >= 1 && n >= 1, "mem_attn: bad sizes ksel=%d T=%d n=%d", ksel, T, n);
+    PPMS_REQUIRE(frames_per_workgroup >= 0 && frames_per_workgroup <= 2, "mem_attn: frames_per_workgroup must be 0 (automatic), 1 or 2, got %d", frames_per_workgroup);
     PPMS_REQUIRE(mf.hi && mf.lo && mfg.hi && mfg.lo && mf.ld % 8 == 0 && mfg.ld % 8 == 0, "mem_attn: mf / mfg must be 16-B aligned SP views");
     static ppms_device_once once;
     once.run([] {
@@ -621,7 +619,7 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         const int g64 = (int)ceil_div(n, 64 * NW);
         int32_t* redo = (int32_t*)(part_ml + (size_t)T * ksel * n * 2);
         // two picked frames per workgroup where the one-frame grid is at least two rounds of the chip (the 1/4 scale: 1000 workgroups)
-        const int sps = g_attn_frames_per_wg ? g_attn_frames_per_wg : ((g64 * T * ksel >= 2 * ppms_num_cus() && ksel > 1) ? 2 : 1);
+        const int sps = frames_per_workgroup ? frames_per_workgroup : ((g64 * T * ksel >= 2 * ppms_num_cus() && ksel > 1) ? 2 : 1);
         nsp = (int)ceil_div(ksel, sps);
         dim3 grid64(g64, T, nsp), grid32(ceil_div(n, QW * NW), T, nsp);
         hipLaunchKernelGGL(mem_attn64_kernel, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,

@@ -586,7 +586,16 @@ class ScaleEngine:
         L.check(self.lib.ppms_sp_to_nchw(src, out.data_ptr(), self.T, c, self.n, self._s()))
         return out
 
+    def _drain_xa_halo(self):
+        """A halo exchange of x left in flight by attend() with no update() behind it (an exception mid-iteration, a probe that calls
+        attend() alone, the engine re-used for another clip): wait for it and forget it, so that the next update() exchanges the
+        CURRENT x instead of consuming the stale handle.  attend() is a collective call on a sharded engine: every rank must make it."""
+        if self._xa_halo is not None:
+            self._xa_halo.wait()
+            self._xa_halo = None
+
     def set_inp(self, inp: torch.Tensor):
+        self._drain_xa_halo()
         self.load_nchw(inp, self.X.view(0, 128))
         self._halo_sp(self.X, 2)                    # (sharded window) inp's +-2 frames: read by the hoisted (5,1,1) gate convs
         if self.pk.hoist:                          # inp share of the GRU gate pre-activations, once per scale, on its own stream
@@ -666,6 +675,7 @@ class ScaleEngine:
     def begin(self, pyramid: List[torch.Tensor], qk_pack):
         """q/k projection, Q operand, frame similarity, usage counter (ppmstereo.py:447-475).
         pyramid: levels of CorrBlock1D; qk_pack: Attention_qk.packed(device)."""
+        self._drain_xa_halo()
         self.pyr = pyramid
         self.pyr_ptrs = (C.c_void_p * 4)(*[p.data_ptr() for p in pyramid[:4]])
         key = qk_pack[0].data_ptr()
@@ -759,10 +769,11 @@ class ScaleEngine:
             ev[0].record()
         L.check(self.lib.ppms_mem_attn(self.QB.data_ptr(), self.KB.data_ptr(), self.VTG.data_ptr(), sel, self.ksel, self.scale,
                                        self.pk.beta.data_ptr(), self.X.view(128, 128), self.X.view(256, 128), L.ptr(out_bf16), self.T, self.n,
-                                       self.ATT_WS.data_ptr(), s))
+                                       self.ATT_WS.data_ptr(), 0, s))
         if ev is not None:
             ev[1].record()
         if self.shard is not None and self.pk.attn is None:
+            self._drain_xa_halo()                                     # (attend() twice without update(): the older exchange is obsolete)
             # x = [inp | mf, mfg] is final here: its +-2 frames (read by the temporal GRU pass at the END of update()) start travelling
             # now and arrive under the W and H passes
             self._xa_halo = self._halo_sp(self.XA, 2, async_op=True)

@@ -188,10 +188,19 @@ class ClipPipeline:
         self.done_events: List[torch.cuda.Event] = []         # (timing: one per clip when ``record_done`` is set)
         self.record_done = False
 
+        self._results: List[torch.Tensor] = []                # tensors handed out by cascade() since the last wait()
+
     def wait(self, handle: Optional[torch.cuda.Event] = None):
+        """Orders the current stream behind the clips enqueued so far AND tells the caching allocator that the tensors ``cascade`` returned
+        (allocated on ``large``) are now used on the current stream: a caller may launch asynchronous kernels on them and drop them
+        without the block being handed to the next clip's 1/4 scale while such a kernel still reads it."""
         ev = self.last if handle is None else handle
+        cur = torch.cuda.current_stream(self.device)
         if ev is not None:
-            torch.cuda.current_stream(self.device).wait_event(ev)
+            cur.wait_event(ev)
+        for t in self._results:
+            t.record_stream(cur)
+        self._results.clear()
 
 
 class PPMStereoHotPath(nn.Module):
@@ -254,7 +263,9 @@ class PPMStereoHotPath(nn.Module):
         dev = feats["f1_16"].device
         tl = feats["f1_16"].shape[0]                      # frames on this rank (== t without sharding)
         if shard is None and tl != t:
-            raise NotImplementedError("cascade: batch size 1 only (frames == t)")
+            if tl % t or pipeline is not None:
+                raise RuntimeError(f"cascade: {tl} frames do not divide into clips of t = {t} (or a pipeline was given for a batch)")
+            return self._cascade_batched(feats, iters, t, preds, uncs)
         if t == 1:
             warnings.warn("PPMStereo with a single frame produces NaN disparities (reference behaviour, T must be >= 2)")
         lib = L.load()
@@ -302,7 +313,31 @@ class PPMStereoHotPath(nn.Module):
                 pipeline.last.record(pipeline.large)
                 if pipeline.record_done:
                     pipeline.done_events.append(pipeline.last)
+                pipeline._results += [preds[-1], uncs[-1]]         # (ClipPipeline.wait records the consuming stream on them)
             return preds[-1], uncs[-1]
+
+
+def _cascade_batched(self, feats, iters: int, t: int, preds: list, uncs: list):
+    """cascade for b > 1 clips (frame index = bi * t + ti, ppmstereo.py:443-449): the reference's glue between the three
+    forward_update_block calls (:696-791) on NCHW tensors -- every iteration's prediction is produced, as test_mode=False does.  The batch
+    elements meet in one scalar per clip index only (the mean of the picked scores, :533), which forward_update_block reproduces; b = 1 --
+    the reference's inference entry -- takes the device-resident path above instead."""
+    f16 = feats["f1_16"]
+    fo, net16, mhs16 = self.forward_update_block(None, self.update_block16, CorrBlock1D(f16, feats["f2_16"]), self.zero_init(f16), feats["net_16"],
+                                                 feats["inp_16"], None, self.att[0], preds, uncs, iters // 2, 4, t)                 # :707-722
+    nets, mhs = {16: net16}, {16: mhs16}
+    for s_, blk, ai, n_it, isc in ((8, self.update_block08, 1, iters // 2, 2), (4, self.update_block04, 2, iters, 1)):
+        f1, f2 = feats[f"f1_{s_}"], feats[f"f2_{s_}"]
+        h, w = f1.shape[2:]
+        flow = bilinear(fo, (h, w), True, -(h / fo.shape[2]))                                                                       # :724-725, :760-761
+        m_up = bilinear(mhs[2 * s_], (h, w), True)                                                                                   # :726-727, :763-764
+        net = (feats[f"net_{s_}"] + bilinear(nets[2 * s_], (h, w), True)) / 2.0                                                     # :729-732, :765-767
+        fo, nets[s_], mhs[s_] = self.forward_update_block(None, blk, CorrBlock1D(f1, f2), flow, net, feats[f"inp_{s_}"], m_up, self.att[ai],
+                                                          preds, uncs, n_it, isc, t)                                                # :743-758, :776-791
+    return preds[-1], uncs[-1]
+
+
+PPMStereoHotPath._cascade_batched = _cascade_batched
 
 
 def position_encoding_sine(d_model: int, h: int, w: int) -> torch.Tensor:
@@ -357,11 +392,26 @@ class PPMStereo(PPMStereoHotPath):
     ``None`` = the ``attention_type=None`` behaviour (positional encoding only); or any callable ``(f1_16, f2_16, T)``.
     Everything between the images (minus cnet) and the returned disparity runs on the gfx950 kernels."""
 
-    def __init__(self, max_disp: int = 192, mixed_precision: bool = False, num_frames: int = 5,
-                 attention_type: Optional[str] = "self_stereo_temporal_update_time_update_space", use_3d_update_block: bool = True,
-                 different_update_blocks: bool = True, use_convex_3d: bool = False, init_flow: bool = False, *, fnet=None, cnet=None, sst="auto"):
-        """Parameter names and order of the reference's constructor (ppmstereo.py:45-55); the defaults are the values its wrapper passes
-        (models/ppm_stereo_model.py:27-33) -- the reference's own defaults select the 2-D update block, which its forward cannot drive."""
+    # what models/ppm_stereo_model.py:27-33 passes: the configuration of the released model, and the one this implementation serves
+    WRAPPER_CONFIG = dict(mixed_precision=True, num_frames=5, attention_type="self_stereo_temporal_update_time_update_space",
+                          use_3d_update_block=True, different_update_blocks=True)
+
+    @classmethod
+    def shipped(cls, **overrides):
+        """PPMStereo(**WRAPPER_CONFIG, **overrides): the model as the reference's wrapper builds it (models/ppm_stereo_model.py:27-33)."""
+        return cls(**{**cls.WRAPPER_CONFIG, **overrides})
+
+    def __init__(self, max_disp: int = 192, mixed_precision: bool = False, num_frames: int = 5, attention_type: Optional[str] = None,
+                 use_3d_update_block: bool = False, different_update_blocks: bool = False, use_convex_3d: bool = False, init_flow: bool = False,
+                 *, fnet=None, cnet=None, sst="auto"):
+        """Parameter names, order AND defaults of the reference's constructor (ppmstereo.py:45-55).  The reference's defaults select the 2-D
+        update block (use_3d_update_block=False), which this implementation does not serve (and the reference's own forward cannot drive,
+        SURVEY.md hazard 7): a default-constructed PPMStereo() therefore raises NotImplementedError naming the supported configuration
+        instead of silently building another module tree -- pass the wrapper's arguments, or use ``PPMStereo.shipped()``."""
+        if not (use_3d_update_block and different_update_blocks):
+            raise NotImplementedError("PPMStereo: the gfx950 implementation serves the released configuration, models/ppm_stereo_model.py:27-33 -- "
+                                      "use_3d_update_block=True, different_update_blocks=True (PPMStereo.shipped() / PPMStereo.WRAPPER_CONFIG); the "
+                                      "2-D update block selected by the reference's constructor defaults is outside the hot path")
         super().__init__(max_disp, mixed_precision, num_frames, attention_type, use_3d_update_block, different_update_blocks, use_convex_3d, init_flow)
         at = attention_type
         if isinstance(sst, str) and sst == "auto":
@@ -449,7 +499,8 @@ class PPMStereo(PPMStereoHotPath):
 
     @torch.no_grad()
     def forward(self, image1: torch.Tensor, image2: torch.Tensor, flow_init=None, iters: int = 10, test_mode: bool = False, pipeline=None):
-        """PPMStereo.forward (ppmstereo.py:601-804): image (b, T, 3, H, W) in [0, 255], H, W multiples of 32, b = 1.
+        """PPMStereo.forward (ppmstereo.py:601-804): image (b, T, 3, H, W) in [0, 255], H, W multiples of 32 (b = 1: the device-resident
+        cascade; b > 1: the reference's glue around the batched forward_update_block).
         test_mode: (flow_up, uncertainty), each (b, T, 1, H, W); else (predictions (D, b, T, 1, H, W), uncertainties).
         pipeline (test_mode only): a ``ClipPipeline`` -- the result is valid once ``pipeline.wait()`` has been called."""
         if flow_init is not None:
@@ -457,19 +508,23 @@ class PPMStereo(PPMStereoHotPath):
         if self.fnet is None or self.cnet is None:
             raise RuntimeError("PPMStereo.forward needs the encoders: pass fnet= / cnet= (outside the hot path, SURVEY.md section 8 f3-f5)")
         b, T, c, h, w = image1.shape
-        if b != 1:
-            raise NotImplementedError("PPMStereo.forward: batch size 1 (inference)")
+        if b != 1 and pipeline is not None:
+            raise NotImplementedError("PPMStereo.forward: a ClipPipeline overlaps consecutive batch-1 clips")
         with torch.cuda.device(image1.device):
             im1 = (2 * (image1 / 255.0) - 1.0).contiguous().reshape(b * T, c, h, w)
             im2 = (2 * (image2 / 255.0) - 1.0).contiguous().reshape(b * T, c, h, w)
             fmap1, fmap2 = self.fnet([im1, im2])
             c4, c8, c16 = self.cnet(im1)
-            feats = self.pre_loop(fmap1, fmap2, c4, c8, c16, T)
+            if b == 1:
+                feats = self.pre_loop(fmap1, fmap2, c4, c8, c16, T)
+            else:                                              # the glue in front of the loop is per clip (the SST block's time attention sees T frames)
+                per = [self.pre_loop(*(x[bi * T:(bi + 1) * T] for x in (fmap1, fmap2, c4, c8, c16)), T) for bi in range(b)]
+                feats = {k: torch.cat([p_[k] for p_ in per]) for k in per[0]}
             preds, uncs = [], []
             self.cascade(feats, iters, T, preds, uncs, test_mode=test_mode, pipeline=pipeline if test_mode else None)
             if test_mode:
-                return preds[-1][None], uncs[-1][None]
-            return torch.stack(preds)[:, None], torch.stack(uncs)[:, None]
+                return preds[-1].reshape(b, T, 1, h, w), uncs[-1].reshape(b, T, 1, h, w)
+            return torch.stack(preds).reshape(-1, b, T, 1, h, w), torch.stack(uncs).reshape(-1, b, T, 1, h, w)
 
     @torch.no_grad()
     def forward_batch_test(self, batch_dict: Dict, kernel_size: int = 20, iters: int = 20, device=None, shard_ranks: bool = False):

@@ -22,7 +22,7 @@ def test_library_builds_and_exports_the_declared_abi():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/ppms.h but not exported by libppms.so"
     assert set(L.EXPORTS) == set(names), set(L.EXPORTS) ^ set(names)
-    assert lib.ppms_version() == 3
+    assert lib.ppms_version() == 4
     assert os.path.dirname(L.lib_path()) == os.path.join(ROOT, "ppmstereo_amd"), "the .so must live in-tree"
 
 

@@ -123,6 +123,26 @@ def test_forward_update_block_batch_of_two(model, tag, ai, isc, mh):
     assert 0 < (fo1 - fo[:T]).abs().max().item() < 0.5
 
 
+def test_cascade_batch_of_two_vs_oracle(model):
+    """b = 2 clips through the whole 3-scale cascade (ppmstereo.py:696-791 with frame index bi * t + ti): the glue between the three
+    batched forward_update_block calls, against the oracle's cascade on the same 2 x T frames; every prediction of every scale."""
+    b, T, H, Wd, iters = 2, 3, 64, 256, 2
+    per = [synth_cascade_feats(T, H, Wd, seed=31 + i) for i in range(b)]
+    feats = {k: torch.cat([p_[k] for p_ in per]) for k in per[0]}
+    preds, uncs, rp, ru = [], [], [], []
+    disp, unc = model.cascade({k: v.to(DEV) for k, v in feats.items()}, iters, T, preds, uncs)
+    rdisp, runc = O.cascade(W, feats, iters, T, rp, ru)
+    assert disp.shape == rdisp.shape == (b * T, 1, H, Wd) and len(preds) == len(rp) == 4
+    epe = (disp.cpu() - rdisp).abs().mean().item()
+    print(f"batched cascade vs oracle: EPE {epe:.3e} px, max {maxdiff(disp, rdisp):.3e}")
+    assert epe < 3e-4 and maxdiff(disp, rdisp) < 3e-3 and maxdiff(unc, runc) < 5e-4
+    for a, r in zip(preds, rp):
+        assert (a.cpu() - r).abs().mean().item() < 3e-4
+    # the batch elements are coupled (the mean of the picked scores, :533): clip 0 alone gives a slightly different answer
+    d1, _ = model.cascade({k: v.to(DEV) for k, v in per[0].items()}, iters, T)
+    assert 0 < (d1 - disp[:T]).abs().max().item() < 1.0
+
+
 def test_cascade_golden(model):
     """Three-scale cascade vs the reference's PPMStereo.forward output (stub encoders) -- the 1e-3 EPE gate."""
     T, H, Wd = 3, 64, 256
@@ -186,7 +206,7 @@ def test_forward_batch_test_vs_reference():
     branch (7 frames < kernel_size)."""
     from ppmstereo_amd.ppmstereo import PPMStereo
     from stub_encoders import StubCNet, StubFNet, frame_video
-    m = PPMStereo(fnet=StubFNet(), cnet=StubCNet(), sst=None).load_hot_path_weights(W).to(DEV).eval()      # (the G8 fixtures: attention_type None at model level)
+    m = PPMStereo.shipped(fnet=StubFNet(), cnet=StubCNet(), sst=None).load_hot_path_weights(W).to(DEV).eval()      # (the G8 fixtures: attention_type None at model level)
     for name, N in (("fbt_N25_k20", 25), ("fbt_N7_k20", 7)):
         out = m.forward_batch_test({"stereo_video": frame_video(N, 60, 250)}, kernel_size=20, iters=4)
         assert tuple(out["disparity"].shape) == (N, 1, 60, 250) and not out["disparity"].is_cuda
@@ -214,7 +234,7 @@ def test_forward_with_hip_encoders_and_sst_vs_oracle():
     (tests/test_gpu_encoder.py, tests/test_gpu_sst.py: 2e-4 / 5e-4 of the reference's features)."""
     from ppmstereo_amd.ppmstereo import PPMStereo
     from stub_encoders import StubCNet
-    m = PPMStereo()
+    m = PPMStereo.shipped()
     keys = list(m.state_dict().keys())
     assert keys[0] == "time_embed" and not any(k.startswith(("sst.", "_sst")) for k in keys)
     expect = (["time_embed"] + ["fnet." + k for k in Wm.fnet_param_shapes()] + ["cnet." + k for k in Wm.cnet_param_shapes()] +
@@ -271,7 +291,7 @@ def test_whole_model_parity_decomposition_on_structured_video():
     epe = {}
     for tag, fn, cn, ss in (("oracle encoders", o_fnet, o_cnet, o_sst), ("HIP fnet", h_fnet, o_cnet, o_sst), ("HIP cnet", o_fnet, h_cnet, o_sst),
                             ("HIP SST", o_fnet, o_cnet, h_sst), ("all HIP", h_fnet, h_cnet, h_sst)):
-        m = PPMStereo(fnet=fn, cnet=cn, sst=ss).load_hot_path_weights(W).to(dev).eval()
+        m = PPMStereo.shipped(fnet=fn, cnet=cn, sst=ss).load_hot_path_weights(W).to(dev).eval()
         d, u = m.forward(img1.to(dev), img2.to(dev), iters=iters, test_mode=True)
         err = (d.cpu() - rd).abs()
         epe[tag] = err.mean().item()
@@ -284,7 +304,7 @@ def test_forward_batch_test_whole_model():
     (padded to 64 x 256 by InputPadder, one window since kernel_size > num_ims), fnet + cnet + SST block + the 3-scale cascade, against the
     oracle's forward_batch_test with its encoder restatements.  Sanity bound (see the conditioning note above); also deterministic."""
     from ppmstereo_amd.ppmstereo import PPMStereo
-    m = PPMStereo()
+    m = PPMStereo.shipped()
     m.load_hot_path_weights(W)
     m.fnet.load_state_dict(Wm.fnet_weights(), strict=True)
     m.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
@@ -439,7 +459,7 @@ def test_attention_is_a_convex_combination(model):
     raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
     ws = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, 5, n)), dtype=torch.uint8, device=DEV)
     L.check(L.load().ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 5, 0.05, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                                   raw.data_ptr(), T, n, ws.data_ptr(), L.stream_ptr()))
+                                   raw.data_ptr(), T, n, ws.data_ptr(), 0, L.stream_ptr()))
     want = cvec.to(torch.bfloat16).float()
     got = raw.float().cpu()
     assert (got - want).abs().max() <= 0.01 * want.abs().max(), "softmax weights do not sum to one"

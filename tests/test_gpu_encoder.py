@@ -117,7 +117,7 @@ def test_large_batches_run_and_match_small_ones(fnet):
     del a4, a8, a16, b4, b8, b16, c
     torch.cuda.empty_cache()
     from ppmstereo_amd.ppmstereo import PPMStereo
-    whole = PPMStereo()
+    whole = PPMStereo.shipped()
     whole.load_hot_path_weights(Wm.hot_path_weights())
     whole.fnet.load_state_dict(Wm.fnet_weights(), strict=True), whole.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
     sd = whole.state_dict()

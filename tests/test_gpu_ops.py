@@ -573,15 +573,8 @@ def _attn_check(got, ref, operands, scale):
         assert err.mean().item() <= 0.2 * bound.mean().item(), (err.mean().item(), bound.mean().item())
 
 
-@pytest.fixture
-def attn_frames(lib, request):
-    """forces the 64-query kernel's frames per workgroup for one test (the automatic choice needs a 1/4-scale-sized grid to pick 2)"""
-    lib.load().ppms_debug_mem_attn_frames_per_workgroup(request.param)
-    yield request.param
-    lib.load().ppms_debug_mem_attn_frames_per_workgroup(0)
-
-
-@pytest.mark.parametrize("attn_frames", [0, 2], indirect=True)
+# attn_frames: ppms_mem_attn's frames_per_workgroup argument (0 = the library's choice, which needs a 1/4-scale-sized grid to pick 2)
+@pytest.mark.parametrize("attn_frames", [0, 2])
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5), (5, 320, 5)])      # (320: a partly filled 256-query block)
 def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
@@ -624,7 +617,7 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
     raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
     ws = torch.empty(int(lib_.ppms_mem_attn_workspace_bytes(T, ksel_frames, n)), dtype=torch.uint8, device=DEV) if split else None
     L.check(lib_.ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), seld.data_ptr(), ksel_frames, scale, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                               raw.data_ptr(), T, n, L.ptr(ws), s))
+                               raw.data_ptr(), T, n, L.ptr(ws), attn_frames, s))
     torch.cuda.synchronize()
     # operands: bit-exact bf16 of the oracle's fp32 operands
     Q0, K0, _, _, _ = O.play_inputs(q, key, pe, value, score, mask, 0)
@@ -638,7 +631,7 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
     assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 1e-4
 
 
-@pytest.mark.parametrize("attn_frames", [0, 2], indirect=True)
+@pytest.mark.parametrize("attn_frames", [0, 2])
 @pytest.mark.parametrize("boost", [40.0, 3.0])
 def test_mem_attn_sharp_softmax(lib, boost, attn_frames):
     """(attn_frames = 2: the dominating key sits in the SECOND frame of the workgroup's pair, whose scores are taken relative to the first
@@ -661,7 +654,7 @@ def test_mem_attn_sharp_softmax(lib, boost, attn_frames):
     scale = 1.0
     ws = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, 2, n)), dtype=torch.uint8, device=DEV)
     L.check(L.load().ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 2, scale, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                                   raw.data_ptr(), T, n, ws.data_ptr(), L.stream_ptr()))
+                                   raw.data_ptr(), T, n, ws.data_ptr(), attn_frames, L.stream_ptr()))
     for i in range(T):
         K = kb[i].reshape(-1, 128).float().cpu()
         V = torch.cat([vt[0].float().cpu().t(), vt[1].float().cpu().t()], 0)

@@ -80,7 +80,7 @@ def _window_worker(rank, world, port, out):
     D.init_from_env("gloo")
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    m = PPMStereo(fnet=StubFNet(), cnet=StubCNet(), sst=None).load_hot_path_weights(Wm.hot_path_weights()).to(dev).eval()
+    m = PPMStereo.shipped(fnet=StubFNet(), cnet=StubCNet(), sst=None).load_hot_path_weights(Wm.hot_path_weights()).to(dev).eval()
     video = frame_video(45, 60, 250)                        # kernel_size 20: windows [0,20) [10,30) [20,40) [30,45)
     sharded = m.forward_batch_test({"stereo_video": video}, kernel_size=20, iters=2, shard_ranks=True)
     torch.cuda.synchronize()

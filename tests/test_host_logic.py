@@ -314,3 +314,35 @@ def test_pack_gemm1_round_trip():
     packed, b, meta = pack_gemm1(hash_normal((20, 64, 1, 1), 79), None, [64], None, rows)
     full = unpack_gemm1_reference(packed, meta["M"], meta["nk"])
     assert meta["M"] == 64 and (full[1::2][:20] == 0).all() and full[0::2][:20].abs().max() > 0
+
+
+@pytest.mark.parametrize("tool,header", [("gen_conv5_asm", "conv5_asm.h"), ("gen_attn_asm", "attn64_asm.h")])
+def test_committed_asm_headers_are_the_generators_default_output(tool, header):
+    """The hand-scheduled loops are generated files and the ablation scripts (tools/abl_*_phase.sh) rewrite them in place with wrong-results
+    settings: the committed header must be exactly what the generator emits with no knob set."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    saved = {k: os.environ.pop(k) for k in list(os.environ) if k.startswith(("PPMS_CONV5_", "PPMS_ATTN_"))}
+    try:
+        spec = importlib.util.spec_from_file_location(f"_{tool}", os.path.join(root, "tools", tool + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert mod.gen() == open(os.path.join(root, "ppmstereo_amd", "csrc", header)).read()
+    finally:
+        os.environ.update(saved)
+
+
+def test_drop_in_constructor_keeps_the_reference_defaults():
+    """ppmstereo.py:45-55: attention_type=None, use_3d_update_block=False, different_update_blocks=False -- a configuration outside the hot
+    path, refused loudly; the wrapper's arguments (models/ppm_stereo_model.py:27-33) build the model."""
+    import inspect
+
+    from ppmstereo_amd.ppmstereo import PPMStereo
+    d = {k: v.default for k, v in inspect.signature(PPMStereo.__init__).parameters.items() if v.default is not inspect.Parameter.empty}
+    assert (d["max_disp"], d["mixed_precision"], d["num_frames"], d["attention_type"], d["use_3d_update_block"], d["different_update_blocks"],
+            d["use_convex_3d"], d["init_flow"]) == (192, False, 5, None, False, False, False, False)
+    with pytest.raises(NotImplementedError, match="use_3d_update_block=True"):
+        PPMStereo()
+    assert PPMStereo.WRAPPER_CONFIG == dict(mixed_precision=True, num_frames=5, attention_type="self_stereo_temporal_update_time_update_space",
+                                            use_3d_update_block=True, different_update_blocks=True)

@@ -21,13 +21,12 @@ sel = torch.arange(5, dtype=torch.int32)[None].expand(T, 5).contiguous().to(dev)
 X = L.SPTensor(T * n, 256, dev)
 beta = torch.tensor([0.5], device=dev)
 lib = L.load()
-lib.ppms_debug_mem_attn_frames_per_workgroup(frames)
 ws = torch.empty(int(lib.ppms_mem_attn_workspace_bytes(T, 5, n)), dtype=torch.uint8, device=dev) if split else None
 ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
 for a, b in ev:
     a.record()
     L.check(lib.ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 5, 0.0522, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                              None, T, n, L.ptr(ws), L.stream_ptr()))
+                              None, T, n, L.ptr(ws), frames, L.stream_ptr()))
     b.record()
 torch.cuda.synchronize()
 ts = sorted(a.elapsed_time(b) for a, b in ev)

@@ -7,7 +7,7 @@ from ppmstereo_amd import weights as Wm
 from ppmstereo_amd.ppmstereo import PPMStereo
 dev = torch.device("cuda:0")
 T, H, W, iters = 5, 320, 512, 10
-m = PPMStereo()
+m = PPMStereo.shipped()
 m.load_hot_path_weights(Wm.hot_path_weights())
 m.fnet.load_state_dict(Wm.fnet_weights(), strict=True), m.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
 sd = m.state_dict()
