@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BF16_DENSE_PEAK_TFLOPS = 2500.0        # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: HBM3E 8 TB/s peak (~6.3 TB/s achievable by a streaming copy)
 CONV_BOUND_TFLOPS = BF16_DENSE_PEAK_TFLOPS / 3.0     # bf16x3 split (hi*hi + hi*lo + lo*hi): 3 MFMAs per algorithmic product
 BASELINE_CONFIGS = {(5, 320, 512, 10): "BASELINE config 2", (5, 736, 1280, 20): "BASELINE config 3 (720x1280 padded to 736x1280)",
                     (40, 320, 512, 20): "BASELINE config 4 (one T=40 window)", (40, 736, 1280, 20): "BASELINE config 5 (one T=40 window)"}
@@ -234,6 +235,42 @@ def main():
             fam_events[k] = [a.elapsed_time(b) for a, b in op.events]
             op.events = saved[k]
 
+    hbm_roof = None
+    if not args.no_kernel_timing:                     # another extra step: the HBM-bound kernels of the path (SURVEY 8d "report both")
+        from ppmstereo_amd import corr as _corr
+        for e, _ in engs:
+            for op in e.hbm.values():
+                op.events = []
+        _corr.BUILD_EVENTS = []
+        _engine.KERNEL_TIMING["on"] = True
+        step()
+        _engine.KERNEL_TIMING["on"] = False
+        torch.cuda.synchronize()
+        kernels = {}
+        for (e, _), sc in zip(engs, (16, 8, 4)):
+            by = e.hbm_bytes()
+            rows = {k: [a.elapsed_time(b) for a, b in op.events] for k, op in e.hbm.items()}
+            rows["corr_build"] = [a.elapsed_time(b) for (shp, (a, b)) in _corr.BUILD_EVENTS if shp == (e.T, e.h, e.w)]
+            for k, ms in rows.items():
+                if ms:
+                    avg = sum(ms) / len(ms)
+                    gbs = by[k] / (avg * 1e-3) / 1e9
+                    kernels.setdefault(k, {})[f"1/{sc}"] = dict(launches=len(ms), avg_us=round(avg * 1e3, 2), algorithmic_mb=round(by[k] / 1e6, 2),
+                                                                gb_per_s=round(gbs, 1), frac=round(gbs / HBM_PEAK_GBS, 4))
+            for op in e.hbm.values():
+                op.events = None
+        _corr.BUILD_EVENTS = None
+        lead = kernels.get("corr_build", {}).get("1/4")
+        tfile = _latest_profile("corr_traffic.json")
+        hbm_roof = dict(bound="hbm", kernel="corr_build_line_kernel at the 1/4 scale (the all-pairs correlation pyramid build: fp32-MFMA contraction over 256 channels + 4 pooled "
+                                            "levels; one launch per scale and clip), HIP events around every launch of ONE extra step behind the timed region; `kernels` lists the "
+                                            "other HBM-bound launches of the path per scale (multi-level lookup, key modulation K' = bf16(K s + PE), convex upsampling) the same way; "
+                                            "algorithmic bytes = SURVEY 8d's formulas, every tensor touched once",
+                        achieved=None if lead is None else lead["gb_per_s"], peak=HBM_PEAK_GBS, unit="GB/s", frac=None if lead is None else lead["frac"],
+                        traffic=(json.load(open(tfile)).get("hbm_bytes_per_launch") if tfile and (T, H, W) == (5, 320, 512) else None),
+                        traffic_note="HBM bytes of ONE 1/4-scale corr_build launch, profiles/rNN_corr_traffic.json (FETCH_SIZE x 2 + WRITE_SIZE)",
+                        avg_ms=None if lead is None else round(lead["avg_us"] / 1e3, 5), algorithmic_bytes_per_launch=None if lead is None else lead["algorithmic_mb"] * 1e6,
+                        kernels=kernels)
     n_sampled = len(range(0, args.steps, TIMING_EVERY))                # steps whose launches carried events
     px = T * H * W
     value = (1 if sharded else world) * args.steps * px / elapsed
@@ -405,7 +442,7 @@ def main():
                    pipeline=("consecutive clips overlap: 1/16 + 1/8 scales of clip k + 1 on a second stream under the 1/4 scale of clip k (ClipPipeline); "
                              "latency_ms_per_clip = one clip alone" if pipe is not None else "off: clips strictly one after the other"),
                    roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None,
-                   roofline_3=family_roof if (not args.no_kernel_timing and family) else None, cpu_baseline=cpu,
+                   roofline_3=family_roof if (not args.no_kernel_timing and family) else None, roofline_hbm=hbm_roof, cpu_baseline=cpu,
                    whole_call_ms=None if not encoders else encoders["whole_call_ms"],
                    library=os.path.relpath(L.lib_path(), ROOT), **({"encoders": encoders} if encoders else {}))
         print(json.dumps(out))

@@ -10,6 +10,9 @@ import torch
 from . import _lib as L
 
 
+BUILD_EVENTS = None        # a list while bench.py times the pyramid builds: ((B, H, W), (start, stop)) per launch
+
+
 def coords_grid(batch: int, ht: int, wd: int, device) -> torch.Tensor:
     """corr.py:47-52 -- (B,2,H,W), channel 0 = x, channel 1 = y."""
     ys, xs = torch.meshgrid(torch.arange(ht, device=device), torch.arange(wd, device=device), indexing="ij")
@@ -34,7 +37,14 @@ def build_pyramid(fmap1: torch.Tensor, fmap2: torch.Tensor) -> List[torch.Tensor
         levels.append(store[off:off + rows * wl].view(rows, wl))
         off += rows * wl
     ptrs = (C.c_void_p * 5)(*[t.data_ptr() for t in levels])
+    ev = BUILD_EVENTS
+    if ev is not None:                      # bench.py: HIP events on the launch stream around the pyramid build (roofline_hbm)
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        pair[0].record()
     L.check(L.load().ppms_corr_build(f1.data_ptr(), f2.data_ptr(), ptrs, B, Cc, H, W, L.stream_ptr()))
+    if ev is not None:
+        pair[1].record()
+        ev.append(((B, H, W), pair))
     return levels
 
 

@@ -400,6 +400,8 @@ class ScaleEngine:
         self._xa_halo = None        # handle of x's +-2-frame halo while it is in flight (sharded window)
         # independent branches of an iteration (flow encoder || correlation encoder, r-gate || z-gate, mask head || flow
         # head) run on a second HIP stream, fork/joined with events: they fill each other's launch tails
+        # the HBM-bound launches of an iteration, bracketable by bench.py like the convolutions (roofline_hbm)
+        self.hbm = {"corr_lookup": TimedCall(self._lookup), "attn_prep_k": TimedCall(self._prep_k), "convex_upsample": TimedCall(self._upsample)}
         self._side = torch.cuda.Stream(device=device)
         self._ev_fork, self._ev_join = torch.cuda.Event(), torch.cuda.Event()
         self._build_descriptors()
@@ -697,10 +699,22 @@ class ScaleEngine:
 
     # ------------------------------------------------------------------ iteration stages
     def lookup(self):
+        self.hbm["corr_lookup"]()
+
+    def _lookup(self):
         X = self.X
         fl = X.view(254, 2)
         L.check(self.lib.ppms_corr_lookup(self.pyr_ptrs, self.FLOW.data_ptr(), 1, None, self.CORR.view().hi, self.CORR.view().lo, 64,
                                           fl.hi, fl.lo, 384, self.T, self.h, self.w, self._s()))
+
+    def hbm_bytes(self) -> Dict[str, float]:
+        """Algorithmic HBM bytes of one launch of the HBM-bound kernels of this scale, every tensor touched once:
+        lookup T n (4 levels x 10 taps x 4 B in + 36 x 4 B out + 8 B flow); key modulation K' = bf16(K s + PE): the fp32 keys of the
+        window's frames once (Tg n 128 x 4 B) + T k n 128 x 2 B of bf16 K' out; convex upsampling T n (144 + 2) 4 B in + T 16 n 2 x 4 B out; pyramid build 2 x 256 T n 4 B in + 1.875 T n w 4 B out."""
+        T, n, w = self.T, self.n, self.w
+        return dict(corr_lookup=T * n * (4 * 10 * 4 + 36 * 4 + 8.0), attn_prep_k=self.Tg * n * 128 * 4.0 + T * self.ksel * n * 128 * 2.0,
+                    convex_upsample=T * n * (self.pk.mask_ch + 2) * 4.0 + T * 16 * n * 2 * 4.0,
+                    corr_build=2 * 256 * T * n * 4.0 + 1.875 * T * n * w * 4.0)
 
     def _fork(self):
         self._ev_fork.record()
@@ -761,7 +775,8 @@ class ScaleEngine:
             key, key_ld = self.QK.data_ptr() + 128 * 4, 256
         else:
             key, key_ld = self.KG.data_ptr(), 128                      # (the values of every frame arrived with the confidences: pick())
-        L.check(self.lib.ppms_attn_prep_k(key, key_ld, self.PE.data_ptr(), sel, shat, self.KB.data_ptr(), self.T, self.ksel, self.n, s))
+        self._prep_k_args = (key, key_ld, sel, shat)
+        self.hbm["attn_prep_k"]()
         ev = None
         if KERNEL_TIMING["on"] and self._ev is not None and self._ev_i < len(self._ev):
             ev = self._ev[self._ev_i]
@@ -864,6 +879,14 @@ class ScaleEngine:
             self._join()
 
     def upsample(self) -> torch.Tensor:
+        self.hbm["convex_upsample"]()
+        return self.FLOW_OUT
+
+    def _prep_k(self):
+        key, key_ld, sel, shat = self._prep_k_args
+        L.check(self.lib.ppms_attn_prep_k(key, key_ld, self.PE.data_ptr(), sel, shat, self.KB.data_ptr(), self.T, self.ksel, self.n, self._s()))
+
+    def _upsample(self):
         if self.pk.convex_3d:                       # ppmstereo.py:573-576
             self._halo_f32(self._FLOW_full, 1)      # 27 spatio-temporal neighbours: +-1 frame of the flow
             L.check(self.lib.ppms_convex_upsample_3d(self.FLOW.data_ptr(), self.MASK.data_ptr(), self.pk.mask_ch, self.FLOW_OUT.data_ptr(), self.T,
@@ -871,7 +894,6 @@ class ScaleEngine:
         else:
             L.check(self.lib.ppms_convex_upsample(self.FLOW.data_ptr(), self.MASK.data_ptr(), self.pk.mask_ch, self.FLOW_OUT.data_ptr(), self.T,
                                                   self.h, self.w, self._s()))
-        return self.FLOW_OUT
 
     def iterate(self, need_up: bool = True):
         """One refinement iteration (ppmstereo.py:482-576).  need_up False: the iteration's upsampled prediction is not wanted (test_mode

@@ -33,8 +33,12 @@ def maxdiff(a, b):
 
 
 # ------------------------------------------------------------------------------------------------ correlation
+# widths: 32 / 24 / 20 (one 32-pixel block per line; 24, 20: ragged pyramid widths 3, 1 / 5, 2, 1), 64 / 48 (64-pixel blocks), 80 / 128 / 160 /
+# 320 / 352 (128-pixel blocks: partial, exact, 2 blocks, 3 blocks with a 64- and a 96-pixel remainder), 18 (W % 4 != 0: the general kernel)
 @pytest.mark.parametrize("B,H,W,seed,gold", [(2, 4, 32, 11, "corr_small"), (1, 3, 24, 12, "corr_odd"), (5, 20, 32, 14, None),
-                                              (2, 5, 80, 15, None), (1, 2, 320, 16, None)])
+                                              (2, 5, 80, 15, None), (1, 2, 320, 16, None), (1, 3, 128, 17, None), (2, 2, 64, 18, None),
+                                              (1, 2, 48, 19, None), (1, 3, 20, 20, None), (1, 2, 18, 21, None), (1, 9, 160, 22, None),
+                                              (1, 1, 352, 23, None)])
 def test_corr_build_and_lookup(lib, B, H, W, seed, gold):
     from ppmstereo_amd.corr import CorrBlock1D
     d = synth_scale_inputs(B, H, W, seed=seed)
