@@ -76,6 +76,9 @@ __device__ __forceinline__ void vm_wait5(int n) {
 #ifndef CONV5_NOSYNC
 #define CONV5_NOSYNC 0       // ablation builds: 1 drops wait + barrier + DMA at the window switches, 2 the DMA, 3 the barrier: wrong results, timing only
 #endif
+#ifndef CONV5_PRIO
+#define CONV5_PRIO 0         // experiment builds: static issue priority for one of the two waves of a SIMD during the K loop (1: waves 0-3, 2: waves 4-7, 3: the 4-block waves)
+#endif
 #ifndef CONV5_ABL_A
 #define CONV5_ABL_A 0        // ablation builds (-DCONV5_ABL_A=1): every k-step loads the FIRST step's weights (L1 hits): wrong results, timing only
 #endif
@@ -301,7 +304,17 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
     }
     static_assert(DEPTH5 == 2, "two A stages: U and U ^ 1; the step loop is unrolled twice");
     CONV5_STAMP(1)
+#if CONV5_PRIO == 1
+    if (wave < 4) __builtin_amdgcn_s_setprio(1);
+#elif CONV5_PRIO == 2
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#elif CONV5_PRIO == 3
+    if (nbw == 4) __builtin_amdgcn_s_setprio(1);
+#endif
     if (nbw == 4) CONV5_LOOP(4) else CONV5_LOOP(3)
+#if CONV5_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     CONV5_STAMP(2)
 #undef CONV5_LOOP
 #undef CONV5_STEP

@@ -191,6 +191,13 @@ def _gen(name: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
     leaf = name.rsplit(".", 1)[-1]
     if name.endswith("aggregator.beta"):
         return np.full(shape, 0.5, np.float32)               # zero-init in the reference: would mute attention
+    if "attn_blocks" in name and ".norm2." in name:
+        # SST block, LoFTR layers (attention.py:186-190): every layer adds norm2(mlp(...)) to the feature stream, so with unit LayerNorm
+        # weights the 8 self / cross layers of the block take O(1) features to rms ~3.3 and the 1/16 correlation volume (which is
+        # quadratic in them) to values of several hundred -- far from a trained network's operating point and, through the bf16 ulp of
+        # the attention operands, the reason the whole-model parity tests could only be sanity bounds.  A quarter
+        # of that keeps the block's output at the magnitude of its input.
+        return (0.25 * (1.0 + 0.1 * x) if leaf == "weight" else 0.005 * x).astype(np.float32)
     if ("norm" in name and leaf == "weight") or (name.startswith("cnet.") and leaf == "weight" and len(shape) == 1):
         return (1.0 + 0.1 * x).astype(np.float32)            # (cnet: the LayerNorms inside downsample_layers carry no "norm" in their names)
     if name.endswith("grn.gamma"):

@@ -228,10 +228,11 @@ def test_forward_with_hip_encoders_and_sst_vs_oracle():
     (sst.py) -- the whole model, nothing stubbed -- against the oracle's forward with its own BasicEncoder / Feature / forward_sst_block
     restatements (all pinned to the reference by the fnet_* / cnet_* / sst_* fixtures).  Also: the model's state_dict IS the
     reference's: same keys in the same order for every sub-module.
-    Tolerance: the loop is ill-conditioned in its inputs -- perturbing the ORACLE's own fnet output by 1e-5 of its range moves the
-    oracle's disparity by 7.5e-4 px on average (3.7e-3 max), 1e-4 by 1.2e-3 px (bf16 rounding flips of the attention operands) --
-    so the end-to-end check from the images is a sanity bound; the encoders' parity is asserted at feature level
-    (tests/test_gpu_encoder.py, tests/test_gpu_sst.py: 2e-4 / 5e-4 of the reference's features)."""
+    Tolerance: north_star's 1e-3 px, asserted FROM THE IMAGES since round 4.  Rounds 2-3 could only keep a sanity bound here (1.6e-3 px
+    measured): the procedural SST weights had unit LayerNorm gains on the eight residual LoFTR layers, which took O(1) features to
+    rms 3.3 and the 1/16 correlation volume (quadratic in them) to values of several hundred -- a bf16 ulp of the attention operands
+    was 0.15 there.  With those gains at a quarter (ppmstereo_amd.weights._gen; the sst_* fixtures regenerated from the reference with
+    the same weights) the block returns features at the magnitude it received and the same code measures 5.8e-4 px."""
     from ppmstereo_amd.ppmstereo import PPMStereo
     from stub_encoders import StubCNet
     m = PPMStereo.shipped()
@@ -256,8 +257,8 @@ def test_forward_with_hip_encoders_and_sst_vs_oracle():
     rd, ru = O.forward(W, lambda x: O.basic_encoder(Wf, x), lambda im: O.feature_cnet(Wc, im), img1, img2, 4, sst_fn=lambda a, b: O.sst_block(Ws, a, b, T))
     err = (d.cpu() - rd).abs()
     print(f"forward with HIP fnet + cnet + SST: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px")
-    # measured 1.6e-3 / 8.7e-3: the loop's own sensitivity on these inputs (see the decomposition test below: the encoders add nothing measurable)
-    assert tuple(d.shape) == (1, T, 1, H, Wd) and err.mean().item() < 3e-3 and err.max().item() < 3e-2
+    # measured 5.8e-4 / 2.5e-3 (see the decomposition test below: the encoders add nothing measurable to the loop's own 6.8e-4)
+    assert tuple(d.shape) == (1, T, 1, H, Wd) and err.mean().item() < 1e-3 and err.max().item() < 1e-2
     assert maxdiff(u, ru) < 1e-2
 
 
@@ -296,7 +297,7 @@ def test_whole_model_parity_decomposition_on_structured_video():
         err = (d.cpu() - rd).abs()
         epe[tag] = err.mean().item()
         print(f"structured video, {tag:16s}: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px (mean |disparity| {rd.abs().mean().item():.2f} px)")
-    assert all(v < 3e-3 for v in epe.values()), epe
+    assert all(v < 1e-3 for v in epe.values()), epe             # north_star's budget, from the images (measured 5.2e-4 .. 7.0e-4)
 
 
 def test_forward_batch_test_whole_model():
@@ -322,7 +323,7 @@ def test_forward_batch_test_whole_model():
                                sst_fn=lambda a, b: O.sst_block(Ws, a, b, N))
     err = (out["disparity"] - ref["disparity"]).abs()
     print(f"forward_batch_test, whole model: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px")
-    assert torch.isfinite(out["disparity"]).all() and err.mean().item() < 3e-3 and err.max().item() < 3e-2          # measured 1.4e-3 / 9.1e-3
+    assert torch.isfinite(out["disparity"]).all() and err.mean().item() < 1e-3 and err.max().item() < 1e-2          # measured 7.4e-4 / 3.0e-3 (1.4e-3 / 9.1e-3 with the unconditioned SST weights of rounds 2-3)
     assert (out["uncertainties"] - ref["uncertainties"]).abs().max().item() < 2e-2
 
 

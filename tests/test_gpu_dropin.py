@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _procedural_checkpoint():
     """state_dict of the whole model (the reference's keys, in its order) filled with the procedural weights."""
     from ppmstereo_amd.ppmstereo import PPMStereo as Donor
-    m = Donor()
+    m = Donor.shipped()
     m.load_hot_path_weights(Wm.hot_path_weights())
     m.fnet.load_state_dict(Wm.fnet_weights(), strict=True)
     m.cnet.load_state_dict(Wm.cnet_weights(), strict=True)
@@ -51,7 +51,7 @@ def test_model_built_loaded_and_called_like_the_reference_wrapper(tmp_path):
                                sst_fn=lambda a, b: O.sst_block(Ws, a, b, N))
     err = (out["disparity"] - ref["disparity"]).abs()
     print(f"wrapper-style model: EPE vs oracle {err.mean().item():.3e} px, max {err.max().item():.3e} px")
-    assert err.mean().item() < 5e-3 and (out["uncertainties"] - ref["uncertainties"]).abs().max().item() < 2e-2
+    assert err.mean().item() < 1e-3 and (out["uncertainties"] - ref["uncertainties"]).abs().max().item() < 2e-2      # measured 6.2e-4 px
     # a checkpoint in the other format the wrapper accepts ({"state_dict": ...} gets a "module." prefix there and, with strict=False,
     # then loads NOTHING: reference behaviour, ppm_stereo_model.py:37-41): every key is reported as unexpected, no exception
     other = PPMStereo(mixed_precision=True, num_frames=5, attention_type="self_stereo_temporal_update_time_update_space",
