@@ -314,8 +314,12 @@ class PackedBlock:
             self.attn = {k: g(k) for k in sd if k.startswith("time_attn.") or k.startswith("space_attn.")}
             lin = lambda k: g(k)[:, :, None, None]                       # nn.Linear (out, in) as a 1x1 conv
             ta, sa = "time_attn.", "space_attn.encoder_layer."
-            put("ta_proj", lin(ta + "temporal_attn.proj.weight"), g(ta + "temporal_attn.proj.bias"), [384])
-            put("ta_fc", lin(ta + "temporal_fc.weight"), g(ta + "temporal_fc.bias"), [384])
+            # temporal_fc(proj(o)) (ppmtereo_update.py:606-617, Attention.forward :418): two Linear layers with nothing in between are ONE
+            # Linear layer -- W = W_fc W_proj, b = W_fc b_proj + b_fc, formed once in fp64 (one launch per iteration instead of two)
+            w_fc, w_pj = g(ta + "temporal_fc.weight").double(), g(ta + "temporal_attn.proj.weight").double()
+            w_ta = (w_fc @ w_pj).float().contiguous()
+            b_ta = (w_fc @ g(ta + "temporal_attn.proj.bias").double() + g(ta + "temporal_fc.bias").double()).float().contiguous()
+            put("ta_fc", w_ta[:, :, None, None], b_ta, [384])
             # q, k and v projections of the linear attention read the same x: ONE launch with two epilogue halves (rows 0..767: elu + 1 for q | k,
             # rows 768..1151: v / n)
             put("sa_qkv", torch.cat([lin(sa + "q_proj.weight"), lin(sa + "k_proj.weight"), lin(sa + "v_proj.weight")], 0), None, [384])
@@ -358,7 +362,7 @@ class ScaleEngine:
         # local of SequenceUpdateBlock3D.forward, ppmtereo_update.py:976-983: inp itself must survive the iteration)
         self.XA = sp(384) if pk.attn is not None else self.X
         if pk.attn is not None:
-            self.O2, self.XT, self.MSG, self.MSGN, self.H1 = sp(384), sp(384), sp(384), sp(384), sp(768)
+            self.XT, self.MSG, self.MSGN, self.H1 = sp(384), sp(384), sp(384), sp(768)
             # the temporal attention needs all frames of a pixel: gathered copy of x and its output for every frame of the
             # window; the own block of O1 feeds the (per-frame) layers behind it
             self.O1 = L.SPTensor(P, 384, device, before=self.f0 * n, after=(Tg - self.f0 - T) * n)
@@ -539,8 +543,7 @@ class ScaleEngine:
         o["to_v"] = self._conv("to_v", [mf], k1, E(n_valid=128, out_sp=self.VAL.view(), out_vt=self.VT))
         o["unc0"] = self._conv("unc0", [H[0].view(), self.VAL.view()], k3, E(act=L.ACT_RELU, n_valid=128, out_sp=self.U1.view()))
         if self.pk.attn is not None:                 # update_block16: time / space attention on x = [inp, mf, mfg]
-            o["ta_proj"] = self._conv("ta_proj", [self.O1.view()], k1, E(n_valid=384, out_sp=self.O2.view()))
-            o["ta_fc"] = self._conv("ta_fc", [self.O2.view()], k1, E(L.EPI_RESID, n_valid=384, out_sp=self.XT.view(), aux_sp=X.view()))
+            o["ta_fc"] = self._conv("ta_fc", [self.O1.view()], k1, E(L.EPI_RESID, n_valid=384, out_sp=self.XT.view(), aux_sp=X.view()))
             o["sa_qkv"] = self._conv("sa_qkv", [self.XT.view()], k1, E(act=L.ACT_ELU1, n_valid=768, out_f32=self.QKF, out_f32_ld=768),
                                      E(scale=1.0 / self.n, n_valid=384, out_f32=self.VF, out_f32_ld=384), m_split=768)
             o["sa_merge"] = self._conv("sa_merge", [self.MSG.view()], k1, E(n_valid=384, out_f32=self.M2, out_f32_ld=384))
@@ -823,8 +826,7 @@ class ScaleEngine:
             self.shard.gather_many([(self.X.own()[pl].view(self.T, self.n, 384), self.XG.data[pl].view(self.Tg, self.n, 384)) for pl in (0, 1)])
         L.check(lib.ppms_time_attn(self.XG.view(all_rows=True), ln["ta"][0].data_ptr(), ln["ta"][1].data_ptr(), self.O1.view(all_rows=True),
                                    self.Tg, self.n, 8, s))
-        o["ta_proj"]()
-        o["ta_fc"]()
+        o["ta_fc"]()                                  # x + fc(proj(.)) as one premultiplied layer
         # SpaceAttnBlock = LoFTR encoder layer with linear attention, x = source                 attention.py:164-190
         o["sa_qkv"]()
         L.check(lib.ppms_linear_attention(self.QKF.data_ptr(), 768, self.QKF.data_ptr() + 384 * 4, 768, self.VF.data_ptr(), 384,

@@ -570,8 +570,14 @@ class PPMStereo(PPMStereoHotPath):
             d, u, handle, padder, keep_from, keep_to = item
             if pipe is not None:
                 pipe.wait(handle)
-            d = padder.unpad(d[0])[:, None].cpu()                                                           # device -> host
-            u = padder.unpad(u[0])[:, None].cpu()
+            # device -> host.  The stream is synchronised FIRST (a spinning wait): a pageable copy issued while the clip's ~900 launches are
+            # still queued blocks inside the runtime on an interrupt-driven wait, and on a loaded host (the GPU boxes: load average 50-60)
+            # the thread was rescheduled 50-150 ms late in every other call (whole call 50 / 100 / 195 ms alternating; with the
+            # synchronisation in front the copy finds an idle stream: 49-50 ms every time, tools/whole_call_probe.py)
+            du = torch.cat([padder.unpad(d[0])[:, None], padder.unpad(u[0])[:, None]])                        # one copy for both results
+            torch.cuda.current_stream(du.device).synchronize()
+            du = du.cpu()
+            d, u = du[:du.shape[0] // 2], du[du.shape[0] // 2:]
             disp_preds.append(d[keep_from:keep_to])
             uncertainties.append(u[keep_from:keep_to])
 

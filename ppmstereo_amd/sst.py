@@ -109,8 +109,9 @@ class SSTBlock(nn.Module):
         ln: Dict[str, tuple] = {}
         for i in range(DEPTH):
             ta = self.time_attn_blocks[i]
-            put(f"ta{i}.proj", ta.temporal_attn.proj.weight, ta.temporal_attn.proj.bias, [DIM])
-            put(f"ta{i}.fc", ta.temporal_fc.weight, ta.temporal_fc.bias, [DIM])
+            # temporal_fc(proj(.)): two Linear layers with nothing in between = one (W_fc W_proj, W_fc b_proj + b_fc; formed in fp64)
+            w_fc, w_pj = ta.temporal_fc.weight.detach().double(), ta.temporal_attn.proj.weight.detach().double()
+            put(f"ta{i}.fc", (w_fc @ w_pj).float(), (w_fc @ ta.temporal_attn.proj.bias.detach().double() + ta.temporal_fc.bias.detach().double()).float(), [DIM])
             ln[f"ta{i}"] = (ta.temporal_norm1.weight.detach().float().to(device).contiguous(), ta.temporal_norm1.bias.detach().float().to(device).contiguous())
             for kind, blocks in (("self", self.self_attn_blocks), ("cross", self.cross_attn_blocks)):
                 ly = blocks[i].layers[0]
@@ -161,7 +162,7 @@ class _SstEngine:
         self.X = [sp(DIM), sp(DIM)]                 # the two views
         self.Y = [sp(DIM), sp(DIM)]                 # ping-pong partners
         self.QF, self.KVF, self.M2, self.M3 = f32(DIM), f32(2 * DIM), f32(DIM), f32(DIM)
-        self.MSG, self.MSGN, self.H1, self.O1, self.O2 = sp(DIM), sp(DIM), sp(2 * DIM), sp(DIM), sp(DIM)
+        self.MSG, self.MSGN, self.H1, self.O1 = sp(DIM), sp(DIM), sp(2 * DIM), sp(DIM)
         self.KVWS = torch.empty(int(lib.ppms_linear_attention_workspace_floats(T, n, HEADS, DIM // HEADS)) + 64, device=device, dtype=torch.float32)
         self.steps: List = []
         none_sp = L.SP(None, None, 0, 0)
@@ -212,8 +213,7 @@ class _SstEngine:
             w_, b_ = ln[f"ta{i}"]
             xv = x.view()
             call(lambda: L.check(lib.ppms_time_attn(xv, w_.data_ptr(), b_.data_ptr(), self.O1.view(), T, n, HEADS, s())))
-            conv(f"ta{i}.proj", [self.O1], epilogue(n_valid=DIM, out_sp=self.O2.view()))
-            conv(f"ta{i}.fc", [self.O2], epilogue(L.EPI_RESID, n_valid=DIM, out_sp=out.view(), aux_sp=x.view()))
+            conv(f"ta{i}.fc", [self.O1], epilogue(L.EPI_RESID, n_valid=DIM, out_sp=out.view(), aux_sp=x.view()))
 
         X, Y = self.X, self.Y
         for i in range(DEPTH):
