@@ -104,3 +104,32 @@ def test_window_sharded_forward_batch_test_on_the_gpu(tmp_path):
     r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
     assert r0["shape"] == r1["shape"] == (45, 1, 60, 250)
     assert r0["equal"] and r0["nonzero"], r0
+
+
+def _bench_line(argv, timeout=560):
+    """python bench.py <argv> with no launcher around it (bench.launch_ranks starts the ranks), gloo between the ranks: both share this box's
+    one GPU, device tensors are staged through the host by dist.FrameShard -- a rehearsal of the N > 1 bench paths with the REAL kernels, never
+    a measurement (on a multi-GPU node the same command line runs over RCCL, one rank per GPU)."""
+    import json
+    import subprocess
+    env = dict(os.environ, PPMS_DIST_BACKEND="gloo", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, cwd=ROOT, env=env, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("T,scaling", [(5, "weak"), (8, "strong")])
+def test_bench_gpus_2_runs_end_to_end_on_one_gpu_over_gloo(T, scaling):
+    """`python bench.py --gpus 2`: two ranks launched by bench.py itself; T = 5 -> clip replicas (what the driver's scaling run does at
+    config 2), T = 8 -> the window's frames sharded 4 + 4 with every exchange of dist.FrameShard inside the timed steps."""
+    out = _bench_line(["--gpus", "2", "--T", str(T), "--H", "64", "--W", "256", "--iters", "4", "--steps", "2", "--warmup", "1",
+                       "--no-cpu-baseline", "--no-encoders"])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0 and out["steps"] == 2
+    px = T * 64 * 256
+    want = (1 if scaling == "strong" else 2) * 2 * px / (out["ms_per_step"] * 2e-3)
+    assert abs(out["value"] - want) <= 1e-3 * want          # value = whole-job pixels over the max-over-ranks time of exactly K steps
+    assert ("sharded" in out["config"]["parallelism"]) == (scaling == "strong")
