@@ -41,5 +41,13 @@ P = 5 * 80 * 128
 conv_alg = P * (512 + 256) * 4 + 256 * 512 * 15 * 4
 conv = summarise("conv", {"conv5_kernel": 3, "conv3_kernel": 3}, "one zr1_0 launch (1,1,15), 512 -> 256 channels, 5x80x128 pixels; mean of the last 3 launches", conv_alg)
 json.dump(conv, open(os.path.join(out, "conv_traffic.json"), "w"), indent=1)
+# pyramid build at the 1/4 scale: both feature maps once + the five pyramid levels once (1.9375 P W values)
+corr_alg = int(2 * 256 * P * 4 + 1.9375 * P * 128 * 4)
+if glob.glob(os.path.join(out, "corr_FETCH_SIZE", "**", "*counter_collection.csv"), recursive=True):
+    corr = summarise("corr", {"corr_build_line_kernel": 10}, "one ppms_corr_build launch at the 1/4 scale (T=5, 256 channels, 80x128): the line-resident kernel, "
+                     "mean of the last 10 of the probe's back-to-back launches (inputs resident in the Infinity Cache between launches: the fetch counter sees "
+                     "what crosses the memory side)", corr_alg)
+    json.dump(corr, open(os.path.join(out, "corr_traffic.json"), "w"), indent=1)
+    print(json.dumps(corr)[:600])
 print(json.dumps(attn)[:600])
 print(json.dumps(conv)[:600])
