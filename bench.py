@@ -110,7 +110,7 @@ def dry_run(args, D, rank, world):
         torch.distributed.destroy_process_group()
 
 
-TIMING_EVERY = 10         # per-launch events in steps 0, 10, 20, ... of the timed region (one step's launches: 117 convs, 20 attention calls)
+TIMING_EVERY = 20         # per-launch events in steps 0, 20, 40, ... of the timed region (one step's launches: 117 convs, 20 attention calls)
 
 
 def main():
@@ -203,7 +203,7 @@ def main():
     t0 = time.perf_counter()
     from ppmstereo_amd import engine as _engine
     for i, (a, b) in enumerate(step_ev):
-        # the per-launch HIP events of the roofline entries are recorded in every TIMING_EVERY-th step of the timed region only (steps 0, 10,
+        # the per-launch HIP events of the roofline entries are recorded in every TIMING_EVERY-th step of the timed region only (steps 0, 20,
         # ...): ~330 event pairs per clip cost ~2 ms of the clip's 43, and `value` is the time of ALL steps
         _engine.KERNEL_TIMING["on"] = (not args.no_kernel_timing) and i % TIMING_EVERY == 0
         if pipe is not None:      # the steps whose launches carry events run un-overlapped (their durations are then the kernels' own): neither
@@ -291,7 +291,7 @@ def main():
         tfile = _latest_profile("attn_traffic.json")
         if tfile and (T, H, W) == (5, 320, 512):
             traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-        roofs.append(dict(bound="mfma", kernel="memory attention = one ppms_mem_attn call (attention kernel + combine), every call in every 10th step of the timed region (step 0, 10, ...) "
+        roofs.append(dict(bound="mfma", kernel="memory attention = one ppms_mem_attn call (attention kernel + combine), every call in every 20th step of the timed region (step 0, 20, ...) "
                                                "(3 scales: 1/16, 1/8, 1/4); algorithmic FLOPs = sum over launches of 4*n*(k*n)*128*T",
                           achieved=round(ach, 2), peak=BF16_DENSE_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / BF16_DENSE_PEAK_TFLOPS, 4),
                           traffic=traffic, traffic_note="HBM bytes of ONE 1/4-scale launch, profiles/rNN_attn_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
@@ -318,7 +318,7 @@ def main():
                 if tfile and (T, H, W) == (5, 320, 512):
                     ctraffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
                 roofs.append(dict(bound="mfma", kernel="conv5_kernel / conv3_kernel (large-map implicit-GEMM convolutions, bf16x3 split MFMA; per_op names the kernel), "
-                                                       "every launch in every 10th step of the timed region (step 0, 10, ...); "
+                                                       "every launch in every 20th step of the timed region (step 0, 20, ...); "
                                                        "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / 3 (three MFMAs per product)",
                                   achieved=round(cach, 2), peak=round(CONV_BOUND_TFLOPS, 1), unit="TFLOP/s", frac=round(cach / CONV_BOUND_TFLOPS, 4),
                                   frac_of_bf16_dense=round(cach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=ctraffic,

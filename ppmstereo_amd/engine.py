@@ -18,6 +18,7 @@ Stage methods mirror the reference calls one to one:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from typing import Dict, List, Optional
@@ -43,6 +44,7 @@ TUNING = dict(
     hoist=True,           # iteration-invariant inp share of the GRU gates computed once per scale
     gemm1=True,           # thin-GEMM kernel (gemm1.hip) for the 1x1 convolutions / Linear layers it serves
     convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
+    fork_min_pixels=0,    # independent branches of an iteration run on the side stream only on maps with at least this many pixels (0: always)
     conv5_pad2x=False,    # conv_gemm5 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 78 us instead of 65 + 143 us
                           # of the K-sliced form, but on the side stream it then competes with convc2 for whole CUs: clip time unchanged, 40.8 ms)
 )
@@ -720,11 +722,15 @@ class ScaleEngine:
                     corr_build=2 * 256 * T * n * 4.0 + 1.875 * T * n * w * 4.0)
 
     def _fork(self):
+        if self.P < TUNING["fork_min_pixels"]:
+            return contextlib.nullcontext()
         self._ev_fork.record()
         self._side.wait_event(self._ev_fork)
         return torch.cuda.stream(self._side)
 
     def _join(self):
+        if self.P < TUNING["fork_min_pixels"]:
+            return
         self._ev_join.record(self._side)
         torch.cuda.current_stream().wait_event(self._ev_join)
 

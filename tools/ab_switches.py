@@ -17,6 +17,8 @@ _MAP = dict(PPMS_CONV5="conv5", PPMS_CONV5_SLICED="conv5_sliced", PPMS_CONV5_GEM
 for _env, _key in _MAP.items():
     if _env in os.environ:
         _engine.TUNING[_key] = os.environ[_env] != "0"
+if "PPMS_FORK_MIN" in os.environ:
+    _engine.TUNING["fork_min_pixels"] = int(os.environ["PPMS_FORK_MIN"])
 if "PPMS_YSWEEP" in os.environ:
     _engine.TUNING["ysweep"] = os.environ["PPMS_YSWEEP"] != "0"
     _engine.TUNING["win2d"] = os.environ["PPMS_YSWEEP"] == "2d"
