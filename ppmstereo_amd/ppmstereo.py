@@ -463,8 +463,10 @@ class PPMStereo(PPMStereoHotPath):
             self._pe_cache[key] = position_encoding_sine(self.dim, h, w).to(device).contiguous()
         return self._pe_cache[key]
 
-    def pre_loop(self, fmap1: torch.Tensor, fmap2: torch.Tensor, c4: torch.Tensor, c8: torch.Tensor, c16: torch.Tensor, t: int):
-        """fmap (BT,256,h,w) at 1/4, context features at 1/4, 1/8, 1/16 -> the dict ``cascade`` consumes."""
+    def pre_loop(self, fmap1: torch.Tensor, fmap2: torch.Tensor, c4: torch.Tensor, c8: torch.Tensor, c16: torch.Tensor, t: int, ctx_ready=None):
+        """fmap (BT,256,h,w) at 1/4, context features at 1/4, 1/8, 1/16 -> the dict ``cascade`` consumes.
+        ctx_ready (optional callable): called once, right before the context features are first read -- ``forward`` passes the wait for the
+        stream cnet runs on, so that the pooling and the SST block (which need fnet's output only) do not wait for cnet."""
         L.require_gpu(fmap1, fmap2, c4, c8, c16)
         lib, st = L.load(), L.stream_ptr
         N, C, h, w = fmap1.shape
@@ -481,7 +483,6 @@ class PPMStereo(PPMStereoHotPath):
             L.check(lib.ppms_ctx_mix(f.data_ptr(), c.data_ptr(), net.data_ptr(), inp.data_ptr(), N, f.shape[2] * f.shape[3], st()))
             feats["net_" + tag], feats["inp_" + tag] = net, inp
 
-        mix(fm[0], c4, "4")
         h16, w16, h8, w8 = h // 4, w // 4, h // 2, w // 2
         f16 = []
         for f in fm:                                           # :649-652 avg_pool 4x4, then the SST block
@@ -495,6 +496,9 @@ class PPMStereo(PPMStereoHotPath):
             for p in f16:
                 L.check(lib.ppms_axpby(p.data_ptr(), pe.data_ptr(), p.data_ptr(), 1.0, 1.0, pe.numel(), p.numel(), st()))
         feats["f1_16"], feats["f2_16"] = f16
+        if ctx_ready is not None:
+            ctx_ready()
+        mix(fm[0], c4, "4")
         mix(f16[0], c16, "16")
         for i, f in enumerate(fm):                             # :666-671 (avg_pool2 + interp(1/16)) / 2
             p = f32(N, C, h8, w8)
@@ -532,16 +536,24 @@ class PPMStereo(PPMStereoHotPath):
                 with torch.cuda.stream(side):
                     c4, c8, c16 = self.cnet(im1)
                 fmap1, fmap2 = self.fnet([im1, im2])
-                cur.wait_stream(side)
                 for t_ in (c4, c8, c16):
                     if torch.is_tensor(t_):
                         t_.record_stream(cur)
+                ready = {"done": False}
+
+                def ctx_ready():                               # the pooling and the SST block run before this: they need fnet's output only
+                    if not ready["done"]:
+                        cur.wait_stream(side)
+                        ready["done"] = True
             else:
                 fmap1, fmap2 = self.fnet([im1, im2])
                 c4, c8, c16 = self.cnet(im1)
+                ctx_ready = None
             if b == 1:
-                feats = self.pre_loop(fmap1, fmap2, c4, c8, c16, T)
+                feats = self.pre_loop(fmap1, fmap2, c4, c8, c16, T, ctx_ready)
             else:                                              # the glue in front of the loop is per clip (the SST block's time attention sees T frames)
+                if ctx_ready is not None:
+                    ctx_ready()
                 per = [self.pre_loop(*(x[bi * T:(bi + 1) * T] for x in (fmap1, fmap2, c4, c8, c16)), T) for bi in range(b)]
                 feats = {k: torch.cat([p_[k] for p_ in per]) for k in per[0]}
             preds, uncs = [], []
