@@ -62,6 +62,41 @@ def test_corr_build_and_lookup(lib, B, H, W, seed, gold):
     assert maxdiff(CorrBlock1D.corr(d["fmap1"].to(DEV), d["fmap2"].to(DEV)), O.corr_volume(d["fmap1"], d["fmap2"])[:, :, :, None]) < 3e-5
 
 
+@pytest.mark.parametrize("C", [16, 256])
+def test_corr_build_line_kernel_equals_the_general_kernel_bit_for_bit(lib, C):
+    """The line-resident pyramid build (W % 4 == 0, C % 16 == 0, 16-byte aligned operands) against the general kernel, which the library
+    falls back to for a 4-byte-misaligned copy of the same features: every level of the pyramid, every width class -- one / two / four
+    32-pixel tiles per block side, ragged last tiles and blocks, several x1 and x2 blocks per line, pyramid widths that are not
+    multiples of 8 / 16 (levels 3 and 4 drop their incomplete windows)."""
+    import ctypes as C_
+    L = lib
+    for W in (16, 20, 24, 28, 36, 44, 52, 60, 64, 68, 96, 100, 128, 132, 200, 256, 260, 384):
+        B, H = 2, 3
+        f1, f2 = hash_normal((B, C, H, W), 3100 + W).to(DEV), hash_normal((B, C, H, W), 3200 + W).to(DEV)
+        rows = B * H * W
+        widths = [W >> l for l in range(5)]
+
+        def build(a, b):
+            store = torch.full((rows * sum(widths),), float("nan"), device=DEV)
+            lv, off = [], 0
+            for wl in widths:
+                lv.append(store[off:off + rows * wl])
+                off += rows * wl
+            ptrs = (C_.c_void_p * 5)(*[t.data_ptr() for t in lv])
+            L.check(L.load().ppms_corr_build(a.data_ptr(), b.data_ptr(), ptrs, B, C, H, W, L.stream_ptr()))
+            torch.cuda.synchronize()
+            return store
+
+        fast = build(f1, f2)
+        p1, p2 = torch.empty(f1.numel() + 1, device=DEV), torch.empty(f2.numel() + 1, device=DEV)
+        m1, m2 = p1[1:].view_as(f1), p2[1:].view_as(f2)
+        m1.copy_(f1), m2.copy_(f2)
+        assert m1.data_ptr() % 16 == 4
+        general = build(m1, m2)
+        assert torch.isfinite(fast).all() and torch.isfinite(general).all(), W      # every pyramid element written by both
+        assert torch.equal(fast, general), f"W={W} C={C}: {int((fast != general).sum())} elements differ"
+
+
 def test_corr_rejects_narrow_maps(lib):
     from ppmstereo_amd.corr import CorrBlock1D
     with pytest.raises(RuntimeError):
