@@ -115,7 +115,7 @@ TIMING_EVERY = 20         # per-launch events in steps 0, 20, 40, ... of the tim
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (one process per GPU); default: WORLD_SIZE when a launcher set it, else 1")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--T", type=int, default=5)
@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / argument plumbing only: the ranks form the process group, run a stub step "
                     "(no GPU work), take the barrier + max-over-ranks path and rank 0 prints a line with value = null (CPU rehearsal, tests/test_bench_launch.py)")
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1")) if "RANK" in os.environ else 1
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU) and hand back their exit code.
