@@ -314,6 +314,7 @@ class PPMStereoHotPath(nn.Module):
                 if pipeline.record_done:
                     pipeline.done_events.append(pipeline.last)
                 pipeline._results += [preds[-1], uncs[-1]]         # (ClipPipeline.wait records the consuming stream on them)
+                del pipeline._results[:-16]                        # a caller that never waits (bench.py) must not accumulate references
             return preds[-1], uncs[-1]
 
 
