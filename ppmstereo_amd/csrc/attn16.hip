@@ -174,9 +174,12 @@ static inline int la_nsplit(int n) {
 template <int DH>
 __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict__ K, int ldk, const float* __restrict__ V, int ldv,
                                                          float* __restrict__ kv, float* __restrict__ ksum, int n, int heads) {
-    constexpr int CH = 64, B = DH / 16;                // pixels staged per pass; block edge per thread
+    // Round 4: a pass stages 160 pixels (the whole share of a workgroup at n = 640) with 16-byte loads, all of them in flight before the
+    // first is consumed -- the kernel used to walk 64-pixel passes of 4-byte loads, i.e. three memory round trips in a row (26 -> 13 us at
+    // n = 640).  The sums run over the pixels in the same order as before: same bits.
+    constexpr int CH = 160, B = DH / 16, Q4 = DH / 4;  // pixels staged per pass; block edge per thread; 16-byte pieces per pixel row
     const int LA_NSPLIT = gridDim.z;
-    __shared__ float ks[CH][DH + 1], vs[CH][DH + 1];
+    __shared__ __attribute__((aligned(16))) float ks[CH][DH], vs[CH][DH];
     const int hd = blockIdx.x, f = blockIdx.y, sp_id = blockIdx.z;
     const int tid = threadIdx.x;
     const int d0 = (tid >> 4) * B, v0 = (tid & 15) * B;
@@ -185,19 +188,35 @@ __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict
     for (int i = 0; i < B; ++i)
 #pragma unroll
         for (int j = 0; j < B; ++j) acc[i][j] = 0.0f;
-    float ksacc = 0.0f;                                // threads 0..47
+    float ksacc = 0.0f;                                // threads 0..DH-1
     const int per = (n + LA_NSPLIT - 1) / LA_NSPLIT;
     const int s_begin = sp_id * per, s_end = (s_begin + per < n) ? s_begin + per : n;
     for (int s0 = s_begin; s0 < s_end; s0 += CH) {
-        for (int i = tid; i < CH * DH; i += 256) {
-            const int sp = i / DH, c = i % DH;
-            const bool ok = s0 + sp < s_end;
-            const int64_t pix = (int64_t)f * n + s0 + sp;
-            ks[sp][c] = ok ? K[pix * ldk + hd * DH + c] : 0.0f;
-            vs[sp][c] = ok ? V[pix * ldv + hd * DH + c] : 0.0f;
+        const int cnt = (s_end - s0 < CH) ? s_end - s0 : CH;
+        constexpr int NIT = (CH * Q4 + 255) / 256;
+        f32x4 kr[NIT], vr[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {             // every load of the pass is requested here ...
+            const int i = tid + it * 256;
+            const int sp = i / Q4, c4 = i - sp * Q4;
+            kr[it] = vr[it] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < CH * Q4 && sp < cnt) {
+                const int64_t pix = (int64_t)f * n + s0 + sp;
+                kr[it] = gld<f32x4>(K + pix * ldk + hd * DH + c4 * 4);
+                vr[it] = gld<f32x4>(V + pix * ldv + hd * DH + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {             // ... and written to LDS here
+            const int i = tid + it * 256;
+            if (i < CH * Q4) {
+                const int sp = i / Q4, c4 = i - sp * Q4;
+                *(f32x4*)&ks[sp][c4 * 4] = kr[it];
+                *(f32x4*)&vs[sp][c4 * 4] = vr[it];
+            }
         }
         __syncthreads();
-        for (int sp = 0; sp < CH; ++sp) {
+        for (int sp = 0; sp < cnt; ++sp) {
             float kk[B], aa[B];
 #pragma unroll
             for (int i = 0; i < B; ++i) {
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict
                 for (int j = 0; j < B; ++j) acc[i][j] += kk[i] * aa[j];
         }
         if (tid < DH)
-            for (int sp = 0; sp < CH; ++sp) ksacc += ks[sp][tid];
+            for (int sp = 0; sp < cnt; ++sp) ksacc += ks[sp][tid];
         __syncthreads();
     }
     float* o = kv + (((int64_t)sp_id * gridDim.y + f) * heads + hd) * DH * DH;
@@ -225,25 +244,32 @@ __global__ __launch_bounds__(256) void linattn_kv_kernel(const float* __restrict
 template <int DH>
 __global__ __launch_bounds__(256) void linattn_apply_kernel(const float* __restrict__ Q, int ldq, const float* __restrict__ kv,
                                                             const float* __restrict__ ksum, ppms_sp out, int n, int heads, float eps, int LA_NSPLIT) {
-    constexpr int PX = 32;
-    __shared__ float kvs[DH][DH + 1], kss[DH], qs[PX][DH];
+    constexpr int PX = 32, Q4 = DH / 4;
+    __shared__ __attribute__((aligned(16))) float kvs[DH][DH], kss[DH], qs[PX][DH];
     const int hd = blockIdx.y, f = blockIdx.z, p0 = blockIdx.x * PX;
     const int tid = threadIdx.x;
     const int64_t pstride_kv = (int64_t)gridDim.z * heads * DH * DH, pstride_ks = (int64_t)gridDim.z * heads * DH;
     const float* kvp = kv + ((int64_t)f * heads + hd) * DH * DH;
-    for (int i = tid; i < DH * DH; i += 256) {
-        float a = 0.0f;
-        for (int sp = 0; sp < LA_NSPLIT; ++sp) a += kvp[sp * pstride_kv + i];
-        kvs[i / DH][i % DH] = a;
+    // the splits' partial blocks, 16 bytes per load, summed in split order (as before: same bits)
+    for (int i = tid; i < DH * Q4; i += 256) {
+        f32x4 a = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int sp = 0; sp < LA_NSPLIT; ++sp) {
+            const f32x4 t = gld<f32x4>(kvp + sp * pstride_kv + i * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] += t[j];
+        }
+        *(f32x4*)&kvs[i / Q4][(i % Q4) * 4] = a;
     }
     if (tid < DH) {
         float a = 0.0f;
         for (int sp = 0; sp < LA_NSPLIT; ++sp) a += ksum[sp * pstride_ks + ((int64_t)f * heads + hd) * DH + tid];
         kss[tid] = a;
     }
-    for (int i = tid; i < PX * DH; i += 256) {
-        const int sp = i / DH, c = i % DH;
-        qs[sp][c] = (p0 + sp < n) ? Q[((int64_t)f * n + p0 + sp) * ldq + hd * DH + c] : 0.0f;
+    for (int i = tid; i < PX * Q4; i += 256) {
+        const int sp = i / Q4, c4 = i % Q4;
+        f32x4 q = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p0 + sp < n) q = gld<f32x4>(Q + ((int64_t)f * n + p0 + sp) * ldq + hd * DH + c4 * 4);
+        *(f32x4*)&qs[sp][c4 * 4] = q;
     }
     __syncthreads();
     for (int i = tid; i < PX * DH; i += 256) {
@@ -267,6 +293,9 @@ extern "C" int ppms_linear_attention(const float* Q, int ldq, const float* K, in
                                      int T, int n, int heads, int dh, void* stream) {
     PPMS_REQUIRE(Q && K && V && kv_ws && out.hi && out.lo && heads == 8 && (dh == 48 || dh == 32),
                  "linear_attention: 8 heads x 48 (update_block16) or x 32 (SST block) channels expected");
+    // the kernels read rows in 16-byte pieces
+    PPMS_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V | (uintptr_t)kv_ws) & 15) == 0,
+                 "linear_attention: Q / K / V / workspace must be 16-byte aligned with row strides that are multiples of 4 floats");
     const int nsplit = la_nsplit(n);
     float* kv = kv_ws;
     float* ksum = kv_ws + (size_t)nsplit * T * heads * dh * dh;
