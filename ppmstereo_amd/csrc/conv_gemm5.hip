@@ -93,10 +93,20 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
     const int r = lane & 31, h = lane >> 5;
     // wave roles (the two waves of a SIMD, w and w + 4, get 4 + (NBT - 4) pixel blocks)
     const int kg = (g.kgroups == 2) ? (wave >> 2) : 0;
-    const int wm = (g.kgroups == 2) ? ((wave & 3) >> 1) : (wave & 3);
+    int wm = (g.kgroups == 2) ? ((wave & 3) >> 1) : (wave & 3);
     const int wn = (g.kgroups == 2) ? ((wave & 1) ^ kg) : (wave >> 2);
-    const int nbw = wn == 0 ? 4 : g.NBT - 4;       // 32-pixel blocks of this wave
-    const int blk0 = wn == 0 ? 0 : 4;              // its first block in the tile
+    int nbw = wn == 0 ? 4 : g.NBT - 4;             // 32-pixel blocks of this wave
+    int blk0 = wn == 0 ? 0 : 4;                    // its first block in the tile
+    if (p.M == 192) {
+        // THREE 64-cout blocks (round 4: the 190- / 192-cout convs of the motion encoder used to run padded to 256 rows, a quarter of
+        // their MFMAs on zeros).  3 x NBT (cout block, pixel block) units go to the 8 waves so that every SIMD pair (w, w + 4) carries 6
+        // (NBT = 8) or 6 / 5 / 5 / 5 (NBT = 7) of them instead of 7 or 8: cout block 2 is split 4 + (NBT - 4) over waves 0 and 1,
+        // cout blocks 0 and 1 each 3 + (NBT - 5) + 2 over waves (2, 6, 4) and (3, 7, 5).
+        const int n5 = g.NBT - 5;
+        wm = wave < 2 ? 2 : (wave & 1);                                   // waves 2, 4, 6 -> block 0; 3, 5, 7 -> block 1
+        nbw = wave == 0 ? 4 : wave == 1 ? g.NBT - 4 : wave < 4 ? 3 : wave < 6 ? 2 : n5;
+        blk0 = wave == 0 ? 0 : wave == 1 ? 4 : wave < 4 ? 0 : wave < 6 ? g.NBT - 2 : 3;
+    }
     const int GT = NT5 / g.kgroups;                // threads of a K-group (they gather the group's windows)
     const int gt = tid - kg * GT;
     const int gwave = gt >> 6;
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
 #elif CONV5_PRIO == 3
     if (nbw == 4) __builtin_amdgcn_s_setprio(1);
 #endif
-    if (nbw == 4) CONV5_LOOP(4) else CONV5_LOOP(3)
+    if (nbw == 4) CONV5_LOOP(4) else if (nbw == 3) CONV5_LOOP(3) else CONV5_LOOP(2)
 #if CONV5_PRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -541,12 +551,13 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = 
 static bool conv5_volume_fits(const ppms_conv* d) { return (int64_t)d->T * d->H * d->W < (1ll << 22) && d->H < 480; }
 
 extern "C" int ppms_conv_gemm5_applicable(const ppms_conv* d) {
-    if (d == nullptr || (d->M != 256 && d->M != 128) || d->m_split % 64 != 0 || d->nseg < 1 || d->nseg > 2) return 0;
+    if (d == nullptr || (d->M != 256 && d->M != 192 && d->M != 128) || d->m_split % 64 != 0 || d->nseg < 1 || d->nseg > 2) return 0;
     if (!conv5_volume_fits(d)) return 0;
     for (int s = 0; s < d->nseg; ++s)
         if (d->seg[s].c <= 0 || d->seg[s].c % 16 != 0) return 0;
     Geo5 g;
     if (!plan5(d, g)) return 0;                     // (kh = kw = 1: GEMM mode, segments in multiples of 64 / 32 channels)
+    if (d->M == 192 && (d->epi[0].out_vt != nullptr || (d->m_split < d->M && d->epi[1].out_vt != nullptr))) return 0;
     return (int64_t)g.tiles_x * g.tiles_y * d->T >= ppms_num_cus() * 25 / 32 ? 1 : 0;   // (200 of 256) fewer workgroups than CUs: conv_gemm2's K slicing fills the chip better
 }
 
@@ -610,7 +621,8 @@ static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, 
     PPMS_REQUIRE(nbt == 0 || nbt == 7 || nbt == 8, "conv_gemm5: nbt must be 0 (choose), 7 or 8");
     PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm5: nseg=%d", d->nseg);
     PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm5: bad volume %dx%dx%d", d->T, d->H, d->W);
-    PPMS_REQUIRE((d->M == 256 || d->M == 128) && d->m_split % 64 == 0, "conv_gemm5: M=%d must be 128 or 256", d->M);
+    PPMS_REQUIRE((d->M == 256 || d->M == 192 || d->M == 128) && d->m_split % 64 == 0, "conv_gemm5: M=%d must be 128, 192 or 256", d->M);
+    PPMS_REQUIRE(d->M != 192 || nslice == 1, "conv_gemm5: the 192-cout layout has no K-sliced form");
     PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15 && d->kh <= 15, "conv_gemm5: odd kernel extents <= 15");
     PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm5: weights/bias missing");
     PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm5: t_halo=%d", d->t_halo);

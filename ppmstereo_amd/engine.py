@@ -44,6 +44,7 @@ TUNING = dict(
     hoist=True,           # iteration-invariant inp share of the GRU gates computed once per scale
     gemm1=True,           # thin-GEMM kernel (gemm1.hip) for the 1x1 convolutions / Linear layers it serves
     convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
+    conv5_m192=True,      # conv_gemm5's three-cout-block layout for the 190 / 192-cout convs (else padded to 256 rows)
     fork_min_pixels=0,    # independent branches of an iteration run on the side stream only on maps with at least this many pixels (0: always)
     conv5_pad2x=False,    # conv_gemm5 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 78 us instead of 65 + 143 us
                           # of the K-sliced form, but on the side stream it then competes with convc2 for whole CUs: clip time unchanged, 40.8 ms)
@@ -230,7 +231,10 @@ class PackedBlock:
                 sweep = w5.transpose(3, 4).contiguous()                      # y sweep: kh / kw swapped
             rows = (max(cout_map) + 1) if cout_map is not None else w5.shape[0]
             if TUNING["conv5"] and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
-                self.w4[name] = _packing.pack_conv4(sweep, bias, segs, seg_pad, cout_map, (rows + 127) // 128 * 128)
+                # conv_gemm5 serves 128, 192 and 256 rows (192: three 64-cout blocks dealt over the eight waves, round 4 -- convc2's 192 and
+                # final_conv's 190 couts no longer run padded to 256)
+                m5 = 128 if rows <= 128 else (192 if rows <= 192 and TUNING["conv5_m192"] else 256)
+                self.w4[name] = _packing.pack_conv4(sweep, bias, segs, seg_pad, cout_map, m5)
             elif TUNING["conv5"] and TUNING["conv5_gemm"] and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith(("_y", "_p")):
                 # no spatial sweep: conv_gemm5's GEMM mode (windows of 64 channels) when the segments come in such multiples.  Only the
                 # 256-cout convs (GRU pass-T z/r 197 -> 164 us, mask_2d.2 62 -> 46 us at the 1/4 scale): with 128 couts the two K-groups

@@ -92,7 +92,7 @@ def pack_conv4(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
     nchunk = cpad // 16
     rows = list(range(cout)) if cout_map is None else list(cout_map)
     M = _pad_to(max(rows) + 1, 128) if m_pad is None else m_pad
-    assert M % 128 == 0 and max(rows) < M
+    assert M % 64 == 0 and max(rows) < M                    # (the kernel serves 128, 192 and 256 rows)
     wk = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh, kw, cin)              # [cout][trow][kx][ci]
     full = torch.zeros(M, kt * kh, kw, cpad, dtype=torch.float32, device=w.device)
     ridx = torch.tensor(rows, device=w.device)

@@ -110,7 +110,8 @@ def test_ops_refuse_cpu_tensors(lib):
 
 
 # ------------------------------------------------------------------------------------------------ conv GEMM
-def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None, nslice=None, ysweep=False):
+def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None, nslice=None, ysweep=False,
+              m_pad=None):
     """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
     from ppmstereo_amd.engine import ConvOp, epilogue
     from ppmstereo_amd.packing import pack_conv2, pack_conv4
@@ -133,7 +134,8 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     if (version in (3, 5) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
         w5 = weight if weight.dim() == 5 else weight[:, :, None]
         wpack = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, k3[1] * k3[2]).contiguous()
-    packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad)
+    packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad,
+                                **({} if m_pad is None else dict(m_pad=m_pad)))
     cout = weight.shape[0]
     out = L.SPTensor(P, meta["M"], DEV)
     outf = torch.zeros(P, meta["M"], device=DEV)
@@ -395,6 +397,31 @@ def test_conv_gemm5_vs_torch(lib, name, T, H, W, segs, cout, k3, nbt):
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
+@pytest.mark.parametrize("nbt", [5007, 5008])
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", [("3x3_m192_final", 2, 13, 45, [320], 190, (1, 3, 3)), ("3x3_m192_full_blocks", 1, 16, 56, [256], 192, (1, 3, 3)),
+                                                   ("x15_m192", 2, 9, 40, [64, 32], 160, (1, 1, 15)), ("y5_m192", 1, 24, 32, [48], 129, (1, 5, 1)),
+                                                   ("3x3x3_m192_T3", 3, 10, 40, [64], 192, (3, 3, 3))])
+def test_conv_gemm5_three_cout_blocks_vs_torch(lib, name, T, H, W, segs, cout, k3, nbt):
+    """M = 192 (round 4): three 64-cout blocks dealt over the eight waves -- cout block 2 on waves 0 / 1 with 4 + (NBT - 4) pixel blocks, cout
+    blocks 0 and 1 on three waves each with 3 + (NBT - 5) + 2 -- so that convc2's 192 and final_conv's 190 couts no longer run padded to
+    256 rows.  x / y / 2-D sweeps, temporal taps, ragged maps and couts vs torch, bit-reproducible, with the GRU epilogue class."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    seg_pad = [((c + 15) // 16) * 16 for c in segs]
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=nbt, seg_pad=seg_pad, m_pad=192)
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    assert torch.equal(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=nbt, seg_pad=seg_pad, m_pad=192))
+    assert torch.equal(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=nbt, seg_pad=seg_pad, m_pad=256)), "same bits as the 256-row layout"
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=nbt, seg_pad=seg_pad, kind=lib.EPI_GRU, aux=aux, z=z, m_pad=192)
+    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
 @pytest.mark.parametrize("cout", [128, 256, 190])
 def test_conv_gemm5_epilogue_classes(lib, cout):
     """conv_gemm5 instantiates its row loop per descriptor class (conv_epilogue.h): plain store (no load in the loop), hoisted share
@@ -427,13 +454,14 @@ def test_conv_gemm5_full_map(lib):
     (7-block tiles: 240 workgroups): the GRU (1,1,15) conv to 256 couts, a 3x3 conv to 256, and the q-gate conv to 128 couts."""
     T, H, W = 5, 80, 128
     P = T * H * W
-    for segs, cout, k3 in (([128, 256], 256, (1, 1, 15)), ([128], 256, (1, 3, 3)), ([128, 256], 128, (1, 1, 5))):
+    for segs, cout, k3, m_pad in (([128, 256], 256, (1, 1, 15), None), ([128], 256, (1, 3, 3), None), ([128, 256], 128, (1, 1, 5), None),
+                                  ([320], 190, (1, 3, 3), 192)):                       # (final_conv on the three-cout-block layout)
         xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
         cin = sum(segs)
         wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
         bs = hash_normal((cout,), 201) * 0.1
         ref = _ref_conv(xs, wt, bs, k3, T, H, W)
-        got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=5)
+        got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=5, m_pad=m_pad)
         assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), (segs, k3)
 
 

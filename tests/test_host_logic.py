@@ -56,8 +56,9 @@ def test_packing_reproduces_the_convolution(segs, cout, k3):
     assert (got - ref).abs().max() < 2e-4 * (1 + ref.abs().max())          # hi+lo weights carry ~16 mantissa bits
 
 
-@pytest.mark.parametrize("segs,cout,k3", [([128, 384], 256, (1, 1, 15)), ([48, 16], 190, (1, 3, 3)), ([128], 256, (3, 3, 3)), ([64], 128, (1, 5, 1))])
-def test_fragment_order_packing_reproduces_the_convolution(segs, cout, k3):
+@pytest.mark.parametrize("segs,cout,k3,m_pad", [([128, 384], 256, (1, 1, 15), None), ([48, 16], 190, (1, 3, 3), None), ([128], 256, (3, 3, 3), None),
+                                                ([64], 128, (1, 5, 1), None), ([48, 16], 190, (1, 3, 3), 192), ([32], 160, (1, 1, 5), 192)])
+def test_fragment_order_packing_reproduces_the_convolution(segs, cout, k3, m_pad):
     """pack_conv4 (conv_gemm5.hip: weights in MFMA-fragment order, 16-channel k-steps, taps in sweep order) unpacks to the same
     weight matrix: checked against F.conv3d, with the sweep-axis conventions the engine uses (y sweep: kh / kw swapped; 2-D
     sweep: (ky, kx) flattened into x)."""
@@ -74,8 +75,8 @@ def test_fragment_order_packing_reproduces_the_convolution(segs, cout, k3):
     elif kh > 1:
         sweep = wt.transpose(3, 4).contiguous()
     seg_pad = [((c + 15) // 16) * 16 for c in segs]
-    packed, bias, meta = pack_conv4(sweep, bs, segs, seg_pad)
-    assert packed.dtype == torch.bfloat16 and meta["M"] % 128 == 0 and packed.numel() == 2 * meta["M"] * meta["nk"] * 16
+    packed, bias, meta = pack_conv4(sweep, bs, segs, seg_pad, None, m_pad)            # (m_pad 192: conv_gemm5's three-cout-block layout)
+    assert packed.dtype == torch.bfloat16 and meta["M"] == (m_pad or (cout + 127) // 128 * 128) and packed.numel() == 2 * meta["M"] * meta["nk"] * 16
     Wm_ = unpack_conv4_reference(packed, meta["M"], meta["nk"], meta["taps"], meta["cpad"] // 16)      # [M][taps of the packed view * cpad]
     # bring the packed view's tap order back to (kz, ky, kx) of the true kernel
     cp = meta["cpad"]
