@@ -150,6 +150,17 @@ int ppms_conv_gemm5_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int
 int ppms_gemm1_applicable(const ppms_conv* desc);
 /* cb_hint: 32-cout blocks per workgroup (1, 2, 4), 0 = let the library choose from the grid size */
 int ppms_gemm1(const ppms_conv* desc, const ppms_conv* dev_desc, int cb_hint, void* stream);
+/* Register-streamed convolution for small maps (conv_stream.hip; the 1/8 and 1/16 scales, where ppms_conv_gemm2 needs K slices and a reduce
+ * launch to fill the chip): any odd (kt, kh, kw), input channels a multiple of 64 in one or two 16-channel-aligned segments, M % 64 == 0,
+ * weights in the pack_stream layout ([M/32][tap][K/16][hi, lo][lane][8], taps in natural order).  One workgroup = four waves that share the
+ * 16-channel chunks of every tap of ONE 32- or 64-pixel x 64-cout tile; both operands go straight to registers through a ring of requests
+ * (no LDS, no barrier in the K loop); partial tiles summed through LDS in wave order; the shared row epilogue (every kind but ADDF32, no
+ * out_vt).  No workspace, no second launch, bit-reproducible.  Replaces, for the same ppms_conv descriptor, what the reference runs as one
+ * cuDNN convolution (ppmtereo_update.py:254-312, 445-482, 670-678, 889-893, 910-914).
+ * applicable: 0 = not served; 1 = served on a map of <= 16 384 pixels (what it is for); 2 = served, but the map is large. */
+int ppms_conv_stream_applicable(const ppms_conv* desc);
+/* hint: 32-pixel blocks per tile (1, 2), 0 = let the library choose from the grid size */
+int ppms_conv_stream(const ppms_conv* desc, const ppms_conv* dev_desc, int hint, void* stream);
 /* sizeof(ppms_sp), sizeof(ppms_epilogue), sizeof(ppms_conv) as compiled: lets a foreign-language binding check its
  * struct layout at load time */
 int ppms_struct_sizes(int* sp, int* epilogue, int* conv);

@@ -61,6 +61,8 @@ _SIGS = {
     "ppms_conv_gemm3": (c_int, [C.POINTER(Conv), c_void_p, c_void_p]),
     "ppms_gemm1_applicable": (c_int, [C.POINTER(Conv)]),
     "ppms_gemm1": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
+    "ppms_conv_stream_applicable": (c_int, [C.POINTER(Conv)]),
+    "ppms_conv_stream": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
     "ppms_conv_gemm5_applicable": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm5": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
     "ppms_conv_gemm5_slices": (c_int, [C.POINTER(Conv)]),

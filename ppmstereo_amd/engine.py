@@ -43,6 +43,9 @@ TUNING = dict(
     slices=True,          # grid-level K slicing of the convs of small maps (1/16, 1/8 scales)
     hoist=True,           # iteration-invariant inp share of the GRU gates computed once per scale
     gemm1=True,           # thin-GEMM kernel (gemm1.hip) for the 1x1 convolutions / Linear layers it serves
+    stream=True,          # register-streamed kernel (conv_stream.hip) where the library rates it faster (small maps: no K slices, no reduce launch);
+                          # "all": wherever it serves a conv of a map of <= 16 384 pixels (A/B runs)
+    stream_hint=0,        # its tile: 0 = the library chooses, 1 / 2 = 32- / 64-pixel tiles
     convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
     conv5_m192=True,      # conv_gemm5's three-cout-block layout for the 190 / 192-cout convs (else padded to 256 rows)
     fork_min_pixels=0,    # independent branches of an iteration run on the side stream only on maps with at least this many pixels (0: always)
@@ -127,6 +130,8 @@ class ConvOp:
             L.check(L.load().ppms_conv_gemm5(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         elif self.version == 6:
             L.check(L.load().ppms_gemm1(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
+        elif self.version == 7:
+            L.check(L.load().ppms_conv_stream(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         elif self.ysweep:
             L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
         elif self.nslice > 1:
@@ -214,6 +219,7 @@ class PackedBlock:
 
         self.w4: Dict[str, tuple] = {}             # conv_gemm5 packs (MFMA-fragment order, sweep-ordered taps, M padded to 128)
         self.w1: Dict[str, tuple] = {}             # gemm1 packs of the 1x1 convolutions (MFMA A-operand images per 32 couts x 16 channels)
+        self.w7: Dict[str, tuple] = {}             # conv_stream packs (the same images per tap, natural tap order) for the small maps
 
         def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
             self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
@@ -222,6 +228,8 @@ class PackedBlock:
                 meta2 = self.w[name][2]
                 if sum(meta2["seg_padded"]) % 64 == 0:
                     self.w1[name] = _packing.pack_gemm1(weight, bias, segs, meta2["seg_padded"], cout_map, meta2["M"])
+            if TUNING["stream"] and not name.endswith(("_y", "_p")) and sum(self.w[name][2]["seg_padded"]) % 64 == 0:
+                self.w7[name] = _packing.pack_stream(weight, bias, segs, self.w[name][2]["seg_padded"], cout_map, self.w[name][2]["M"])
             sweep = w5                                                     # x sweep: natural order
             if w5.shape[3] > 1 and w5.shape[4] > 1:
                 # k-step order of the 2-D window sweep: (ky, kx) flattened into the x axis
@@ -457,6 +465,14 @@ class ScaleEngine:
             d1.w, d1.bias = packed1.data_ptr(), bias1.data_ptr()
             if self.lib.ppms_gemm1_applicable(C.byref(d1)) == 1:          # (2: served, but the implicit GEMM is as fast on a map this large)
                 return ConvOp(d1, [packed1, bias1, *keep], 6, device=self.dev)
+        if TUNING["stream"] and isinstance(wname, str) and wname in self.pk.w7:
+            # small maps (1/8, 1/16 scales): the register-streamed kernel -- no K slices, no reduce launch
+            packed7, bias7, _ = self.pk.w7[wname]
+            d7 = L.Conv.from_buffer_copy(bytes(d))
+            d7.w, d7.bias = packed7.data_ptr(), bias7.data_ptr()
+            rate = self.lib.ppms_conv_stream_applicable(C.byref(d7))
+            if rate == 1 or (rate == 2 and TUNING["stream"] == "all" and self.P <= 16384):      # ("all": A/B runs only)
+                return ConvOp(d7, [packed7, bias7, *keep], 7, wm_hint=TUNING["stream_hint"], device=self.dev)
         if isinstance(wname, str):
             op = self._try_fragment_kernels(wname, d, m_split, keep)
             if op is not None:

@@ -152,6 +152,53 @@ def pack_gemm1(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
     return packed.reshape(-1), b, meta
 
 
+def pack_stream(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
+                seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
+                m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+    """Layout of the register-streamed small-map kernel (ppmstereo_amd/csrc/conv_stream.hip): pack_gemm1's A-operand images with taps,
+        bf16 [M/32][tap][K/16][plane (hi, lo)][lane = 32*h + r][8] = W[cout = 32*blk + r][tap][k = 16*chunk + 8*h + j],
+    tap = (kz*kh + ky)*kw + kx in the natural order (no sweep), the input segments concatenated along K, each zero-padded to a multiple of
+    16 channels; the padded K must be a multiple of 64 (every tap's chunks are dealt to the four waves of a workgroup in equal shares)."""
+    w = weight.detach().float()
+    if w.dim() == 4:
+        w = w[:, :, None]
+    cout, cin, kt, kh, kw = w.shape
+    assert sum(seg_channels) == cin, (seg_channels, cin)
+    seg_padded = [_pad_to(c, 16) for c in seg_channels] if seg_padded is None else list(seg_padded)
+    assert all(p % 16 == 0 and p >= c for p, c in zip(seg_padded, seg_channels))
+    cpad = sum(seg_padded)
+    assert cpad % 64 == 0, f"pack_stream: padded input channels {cpad} must be a multiple of 64"
+    rows = list(range(cout)) if cout_map is None else list(cout_map)
+    M = _pad_to(max(rows) + 1, 64) if m_pad is None else m_pad
+    assert M % 64 == 0 and max(rows) < M
+    taps = kt * kh * kw
+    wk = w.permute(0, 2, 3, 4, 1).reshape(cout, taps, cin)                     # [cout][tap][ci]
+    full = torch.zeros(M, taps, cpad, dtype=torch.float32, device=w.device)
+    ridx = torch.tensor(rows, device=w.device)
+    src = dst = 0
+    for c, p in zip(seg_channels, seg_padded):
+        full[ridx, :, dst:dst + c] = wk[:, :, src:src + c]
+        src += c
+        dst += p
+    nk16 = cpad // 16
+    t = full.reshape(M // 32, 32, taps, nk16, 2, 8).permute(0, 2, 3, 4, 1, 5).contiguous()          # [blk][tap][chunk][h][r][j]
+    t = t.reshape(M // 32, taps * nk16, 64, 8)
+    hi, lo = split_bf16(t)
+    packed = torch.stack([hi, lo], dim=2).contiguous()                                               # [blk][step][plane][lane][8]
+    b = torch.zeros(M, dtype=torch.float32, device=w.device)
+    if bias is not None:
+        b[ridx] = bias.detach().float()
+    meta = dict(M=M, nk=taps * nk16, taps=(kt, kh, kw), cpad=cpad, seg_padded=seg_padded, version=7)
+    return packed.reshape(-1), b, meta
+
+
+def unpack_stream_reference(packed: torch.Tensor, M: int, taps: int, nk16: int) -> torch.Tensor:
+    """Inverse of pack_stream -> fp32 [M][K] in the plain K order (k = tap*Cpad + ci), for the host-logic tests."""
+    t = packed.reshape(M // 32, taps, nk16, 2, 2, 32, 8).float()                                     # [blk][tap][chunk][plane][h][r][j]
+    t = t[:, :, :, 0] + t[:, :, :, 1]                                                                 # [blk][tap][chunk][h][r][j]
+    return t.permute(0, 4, 1, 2, 3, 5).reshape(M, taps * nk16 * 16)
+
+
 def unpack_gemm1_reference(packed: torch.Tensor, M: int, nk: int) -> torch.Tensor:
     """Inverse of pack_gemm1 -> fp32 [M][K], for the host-logic tests."""
     t = packed.reshape(M // 32, nk, 2, 2, 32, 8).float()                                 # [blk][step][plane][h][r][j]

@@ -118,8 +118,8 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     tile_px = 0
     if version in (5, 5007, 5008):                                         # conv_gemm5; 5007 / 5008 force the blocks per tile
         tile_px, version = (0 if version == 5 else version - 5000), 5
-    from ppmstereo_amd.packing import pack_gemm1
-    pack_conv = pack_conv4 if version == 5 else pack_gemm1 if version == 6 else pack_conv2
+    from ppmstereo_amd.packing import pack_gemm1, pack_stream
+    pack_conv = pack_conv4 if version == 5 else pack_gemm1 if version == 6 else pack_stream if version == 7 else pack_conv2
     P = T * H * W
     segs, keep = [], []
     seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
@@ -298,6 +298,96 @@ def test_gemm1_vs_torch(lib, name, T, H, W, segs, cout):
     assert maxdiff(_run_conv(L, xs, wt, bs, (1, 1, 1), T, H, W, version=6, kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + ref)) < 5e-5 * max(1.0, ref.abs().max().item())
     assert maxdiff(_run_conv(L, xs, wt, bs, (1, 1, 1), T, H, W, version=6, act=L.ACT_ELU1), F.elu(ref) + 1) < 5e-5 * max(1.0, ref.abs().max().item())
     assert maxdiff(_run_conv(L, xs, wt, None, (1, 1, 1), T, H, W, version=6, scale=0.25), 0.25 * (ref - bs)) < 5e-5 * max(1.0, ref.abs().max().item())
+
+
+STREAM_CASES = [
+    # name, T,H,W, segs, cout, k3
+    ("gru_1x15_block16", 5, 20, 32, [128, 384], 256, (1, 1, 15)),
+    ("gru_1x15_hoisted", 2, 10, 18, [128, 256], 256, (1, 1, 15)),
+    ("q_1x5", 2, 10, 18, [128, 256], 128, (1, 1, 5)),
+    ("z_tail_1x5", 3, 7, 9, [128], 128, (1, 1, 5)),
+    ("y_1x5x1", 2, 11, 9, [128, 64], 128, (1, 5, 1)),
+    ("t_5x1x1", 5, 6, 10, [128, 64], 128, (5, 1, 1)),
+    ("t_5x1x1_T2", 2, 5, 7, [64], 64, (5, 1, 1)),
+    ("flow_head_3x3x3", 4, 7, 9, [128], 256, (3, 3, 3)),
+    ("final_3x3_320_190", 2, 9, 13, [320], 190, (1, 3, 3)),
+    ("unc_3x3_two_segs", 3, 9, 13, [128, 128], 128, (1, 3, 3)),
+    ("linear_768", 2, 6, 10, [384, 384], 768, (1, 1, 1)),
+    ("one_pixel", 1, 1, 1, [64], 64, (3, 3, 3)),
+    ("frames_inside_a_tile", 5, 3, 5, [64], 64, (3, 3, 3)),
+    ("w80_3x3", 2, 46, 80, [64], 64, (1, 3, 3)),
+]
+
+
+@pytest.mark.parametrize("hint", [1, 2])
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", STREAM_CASES)
+def test_conv_stream_vs_torch(lib, name, T, H, W, segs, cout, k3, hint):
+    """The register-streamed small-map kernel (conv_stream.hip: four waves share the chunks of every tap of one tile, operands straight to
+    registers through a ring, LDS reduction in wave order) against torch conv3d: every tap shape of the update block, one and two segments,
+    ragged pixel counts and couts, tiles that span several frames (temporal-tap skipping), both tile sizes, bit-identical from run to run,
+    and against the LDS-staged kernel it replaces."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=7, wm=hint)
+    tol = 3e-5 * max(1.0, ref.abs().max().item())
+    assert maxdiff(got, ref) < tol, name
+    assert torch.equal(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=7, wm=hint))
+    assert maxdiff(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=2)) < 2e-5 * max(1.0, ref.abs().max().item())
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=7, wm=hint, kind=lib.EPI_GRU, aux=aux, z=z)
+    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
+def test_conv_stream_epilogues_and_hoisted_share(lib):
+    """Every epilogue class of the shared row epilogue through conv_stream, and the hoisted input share (pre_f32) of the GRU gates."""
+    import functools
+    L = lib
+    T, H, W, k3 = 2, 6, 10, (1, 3, 3)
+    P = T * H * W
+    x = hash_normal((P, 64), 300)
+    wt = hash_normal((64, 64, *k3), 301) / math.sqrt(64 * 9)
+    bs = hash_normal((64,), 302) * 0.1
+    aux = hash_normal((P, 64), 303)
+    z = torch.sigmoid(hash_normal((P, 64), 304))
+    lin = _ref_conv([x], wt, bs, k3, T, H, W)
+    run = functools.partial(_run_conv, L, [x], wt, bs, k3, T, H, W, version=7)
+    assert maxdiff(run(act=L.ACT_RELU), F.relu(lin)) < 5e-5
+    assert maxdiff(run(act=L.ACT_GELU), F.gelu(lin)) < 5e-5
+    assert maxdiff(run(act=L.ACT_SIGMOID), torch.sigmoid(lin)) < 5e-5
+    assert maxdiff(run(act=L.ACT_TANH), torch.tanh(lin)) < 5e-5
+    assert maxdiff(run(scale=0.25), 0.25 * lin) < 5e-5
+    assert maxdiff(run(kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + lin)) < 5e-5
+    assert maxdiff(run(kind=L.EPI_RH, aux=aux), torch.sigmoid(lin) * aux) < 5e-5
+    assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < 5e-5
+    # hoisted share: conv([h | inp | rest]) == conv_h_rest([h | rest]) + pre
+    T, H, W, k3 = 2, 6, 24, (1, 1, 5)
+    P = T * H * W
+    h, inp, rest = hash_normal((P, 128), 400), hash_normal((P, 128), 401), hash_normal((P, 64), 402)
+    wt = hash_normal((128, 320, *k3), 403) / math.sqrt(320 * 5)
+    bs = hash_normal((128,), 404) * 0.1
+    full = _ref_conv([h, inp, rest], wt, bs, k3, T, H, W)
+    pre = _run_conv(L, [inp], wt[:, 128:256].contiguous(), bs, k3, T, H, W, version=7)
+    w_h = torch.cat([wt[:, :128], wt[:, 256:]], 1).contiguous()
+    aux = hash_normal((P, 128), 405)
+    z = torch.sigmoid(hash_normal((P, 128), 406))
+    run = lambda **k: _run_conv(L, [h, rest], w_h, None, k3, T, H, W, version=7, pre=pre, **k)
+    assert maxdiff(run(), full) < 5e-5
+    assert maxdiff(run(act=L.ACT_GELU), F.gelu(full)) < 5e-5
+    assert maxdiff(run(kind=L.EPI_RH, aux=aux), torch.sigmoid(full) * aux) < 5e-5
+    assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(full)) < 5e-5
+
+
+def test_conv_stream_refuses_what_it_does_not_serve(lib):
+    L = lib
+    d = L.Conv()
+    assert L.load().ppms_conv_stream_applicable(C.byref(d)) == 0
+    with pytest.raises(RuntimeError):
+        L.check(L.load().ppms_conv_stream(C.byref(d), None, 0, None))
 
 
 @pytest.mark.parametrize("T,H,W", [(2, 8, 32), (3, 23, 40), (1, 5, 7)])

@@ -317,6 +317,29 @@ def test_pack_gemm1_round_trip():
     assert meta["M"] == 64 and (full[1::2][:20] == 0).all() and full[0::2][:20].abs().max() > 0
 
 
+def test_pack_stream_round_trip():
+    """pack_stream (conv_stream.hip: [M/32][tap][K/16][hi, lo][lane][8], taps in the natural (kz, ky, kx) order) unpacks to the [M][tap][K]
+    matrix of the weights it was given: two segments with padding, a cout map with padded rows, 3-D taps."""
+    from ppmstereo_amd.packing import pack_stream, unpack_stream_reference
+    from ppmstereo_amd.weights import hash_normal
+    w = hash_normal((54, 36 + 10, 3, 1, 5), 77)
+    packed, b, meta = pack_stream(w, hash_normal((54,), 78), [36, 10], [48, 16], None, 64)
+    assert meta["M"] == 64 and meta["nk"] == 15 * 4 and meta["taps"] == (3, 1, 5) and packed.numel() == 2 * 64 * 15 * 64
+    full = unpack_stream_reference(packed, 64, 15, 4).reshape(64, 15, 64)
+    want = torch.zeros(64, 15, 64)
+    wk = w.permute(0, 2, 3, 4, 1).reshape(54, 15, 46)
+    want[:54, :, :36] = wk[:, :, :36]
+    want[:54, :, 48:58] = wk[:, :, 36:]
+    assert (full - want).abs().max() < 2e-5 * want.abs().max()          # hi + lo of a bf16 split: 16 mantissa bits
+    assert b.shape == (64,) and (b[54:] == 0).all()
+    rows = list(range(126)) + list(range(128, 192))                      # final_conv's cout map
+    packed, b, meta = pack_stream(hash_normal((190, 64, 3, 3), 79), None, [64], None, rows, 192)
+    full = unpack_stream_reference(packed, 192, 9, 4)
+    assert meta["M"] == 192 and (full[126:128] == 0).all() and full[128:].abs().max() > 0
+    with pytest.raises(AssertionError):
+        pack_stream(hash_normal((8, 32, 1, 1), 80), None, [32])          # K = 32: not a multiple of 64
+
+
 @pytest.mark.parametrize("tool,header", [("gen_conv5_asm", "conv5_asm.h"), ("gen_attn_asm", "attn64_asm.h")])
 def test_committed_asm_headers_are_the_generators_default_output(tool, header):
     """The hand-scheduled loops are generated files and the ablation scripts (tools/abl_*_phase.sh) rewrite them in place with wrong-results

@@ -4,6 +4,7 @@ no environment variable itself).  Import this module before the first engine is 
     PPMS_CONV5=0 PPMS_SLICE=0 python -c "import tools.ab_switches; ..."      or      import ab_switches  (from tools/)
 
     PPMS_CONV5, PPMS_CONV5_SLICED, PPMS_CONV5_GEMM, PPMS_CONV3, PPMS_PWCHAIN, PPMS_SLICE, PPMS_HOIST, PPMS_CONV5_PAD2X: 0 / 1
+    PPMS_STREAM: 0 / 1 / all (conv_stream.hip: off / where the library rates it faster / wherever it serves a small map); PPMS_STREAM_HINT: 0 / 1 / 2
     PPMS_YSWEEP: 0 = off, 1 = y-swept (1, kh, 1) convs, 2d = also the 2-D window for kh, kw > 1
 """
 import os
@@ -17,6 +18,10 @@ _MAP = dict(PPMS_CONV5="conv5", PPMS_CONV5_SLICED="conv5_sliced", PPMS_CONV5_GEM
 for _env, _key in _MAP.items():
     if _env in os.environ:
         _engine.TUNING[_key] = os.environ[_env] != "0"
+if "PPMS_STREAM" in os.environ:
+    _engine.TUNING["stream"] = {"0": False, "1": True}.get(os.environ["PPMS_STREAM"], os.environ["PPMS_STREAM"])
+if "PPMS_STREAM_HINT" in os.environ:
+    _engine.TUNING["stream_hint"] = int(os.environ["PPMS_STREAM_HINT"])
 if "PPMS_FORK_MIN" in os.environ:
     _engine.TUNING["fork_min_pixels"] = int(os.environ["PPMS_FORK_MIN"])
 if "PPMS_YSWEEP" in os.environ:
