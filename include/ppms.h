@@ -94,7 +94,11 @@ typedef struct ppms_conv {
                                    * every input segment: 0 = zero padding at both ends (one GPU holds the whole window); > 0 when
                                    * the window's frames are sharded over GPUs and the neighbours' boundary frames sit in halo
                                    * slabs around this rank's T frames (ppmstereo_amd/dist.py).  Outputs cover [0, T) only. */
-    int32_t reserved;
+    int32_t lo_zero_from;         /* > 0: the input channels from this index on (counted over the concatenated segments; a multiple of
+                                   * 64) are known to hold bf16-exact values, i.e. their lo plane is all zero (the memory read-out `hid` of
+                                   * the attention, ppmstereo.py:550-552, is a bf16 tensor): the kernels skip the products with that plane
+                                   * -- the same bits, a third of those channels' MFMAs saved.  A PROMISE by the caller: with a non-zero
+                                   * lo plane there the result silently loses that plane's contribution.  0: no such channels. */
     ppms_epilogue epi[2];
 } ppms_conv;
 
@@ -268,7 +272,9 @@ int ppms_attn_prep_k(const float* key, int ld, const float* pe, const int32_t* s
 /* flash_attn_func call of ppmstereo.py:550 for all T clips + the aggregation of :552:
  * hid = bf16(softmax(Q K'^T * scale) V); mfg = mf + beta * hid.
  * qb: bf16 [T][n][128]; kb: bf16 [T][ksel][n][128]; vt: bf16 [T][128][n] (per-frame transposed values, picked through
- * sel); mf / mfg: SP views (128 channels).  out_bf16 (optional): bf16 [T][n][128] raw attention output. */
+ * sel); mf / mfg: SP views (128 channels).  out_bf16 (optional): bf16 [T][n][128] raw attention output.
+ * mf.hi == NULL: no aggregation -- the `mfg` view receives hid itself (hi plane = hid, lo plane = 0: bf16-exact channels, see
+ * ppms_conv.lo_zero_from; the caller then feeds the convolutions [mf | hid] with weights (W_mf + W_mfg | beta W_mfg), the same sum). */
 int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
                   ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, void* stream);
 /* split_ws (optional, caller-owned, ppms_mem_attn_workspace_bytes(T, ksel, n) bytes, contents need not be

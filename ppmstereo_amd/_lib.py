@@ -32,7 +32,7 @@ class Conv(C.Structure):
     _fields_ = [("seg", SP * 2), ("nseg", C.c_int32), ("w", c_void_p), ("bias", c_void_p),
                 ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("kt", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
-                ("M", C.c_int32), ("m_split", C.c_int32), ("t_halo", C.c_int32), ("reserved", C.c_int32), ("epi", Epilogue * 2)]
+                ("M", C.c_int32), ("m_split", C.c_int32), ("t_halo", C.c_int32), ("lo_zero_from", C.c_int32), ("epi", Epilogue * 2)]
 
 
 class ChainLayer(C.Structure):

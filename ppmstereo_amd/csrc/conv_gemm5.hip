@@ -35,6 +35,8 @@ struct Geo5 {
     int nsweep;              // taps swept inside one window (kw, kh or kh*kw)
     int rdy;                 // 1: the row-step index carries a dy (x sweep), 0: only dt
     int nchunk, n0;          // 16-channel chunks per tap (all segments), chunks of segment 0
+    int lz0;                 // windows whose chunk index is >= lz0 hold bf16-exact activations (all-zero lo plane, ppms_conv.lo_zero_from): their
+                             // a_hi x b_lo products are skipped; nchunk: none
     int kgroups;             // 1: M = 256 (4 cout blocks x 2 pixel halves), 2: M = 128 (2 x 2 x two K-groups)
     int npieces;             // DMA pieces per thread of a K-group and window
     int RW, logRW;           // 16-channel chunks per window row: 1 (a window = 16 channels, swept by the spatial taps) or, for convs
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
     {                                                                                                                          \
         const int jj = (JJ);                                                                                                   \
         const int ahead = nsteps - 1 - jj;                                                                                     \
+        const int lz = (int)((unsigned)(g.lz0 - 1 - wchunk) >> 31); /* 1: this step's window (chunk >= lz0) has an all-zero lo plane; shift, not ?: -- a select lands in a VGPR */\
         vm_wait5((sw == 0 && w > 0 && w + 1 < nwin) ? g.npieces : ((jj == 0 && nwin > 1) ? g.npieces : 0));                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                                     \
@@ -261,6 +264,8 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
         }                                                                                                                      \
         if (++sw == g.nsweep) {                                                                                                \
             sw = swx = trow = 0;                                                                                               \
+            wchunk += wstride;                                                                                                 \
+            if (wchunk >= g.nchunk) wchunk -= g.nchunk;                                                                        \
             if (ahead > 0) {                                                                                                   \
                 if (CONV5_NOSYNC != 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                        \
                 if (CONV5_NOSYNC != 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
@@ -276,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
             }                                                                                                                  \
         }                                                                                                                      \
         if (ahead > 0) { CONV5_ADDR(adr_hi, NBW, w & 1, trow, sw) }                                                              \
-        mfma_group3<NBW, MORE>(acc, areg[U][0], areg[U][2], bh, areg[U][1], areg[U][3], bx, adr_hi);                                                 \
+        mfma_group3<NBW, MORE>(acc, areg[U][0], areg[U][2], bh, areg[U][1], areg[U][3], bx, adr_hi, lz);                                                      \
     }
     // the whole K loop for a static block count
 #define CONV5_LOOP(NBW)                                                                                                        \
@@ -293,6 +298,7 @@ __global__ __launch_bounds__(512, 2) void conv5_kernel(const ppms_conv pv, const
         __builtin_amdgcn_s_barrier();                                                                                          \
         if (nwin > 1) dma_b(win0 + wstride, 1);                                                                                \
         int sw = 0, swx = 0, trow = 0, w = 0;                                                                                  \
+        int wchunk = win0 % g.nchunk; /* chunk index of the current window (it advances by wstride, modulo nchunk) */           \
         int la_s = 1, la_ks = win0 * g.nsweep + 1; /* tap / packed k16-step of the next A load (nsweep >= 2); stops at the last step */ \
         bf16x8 bh[4], bx[2];                                                                                                  \
         unsigned adr_hi[4];                                                                                                    \
@@ -535,6 +541,7 @@ static bool plan5(const ppms_conv* d, Geo5& g, int force_nbt = 0, bool sliced = 
     }
     g.nchunk = nchunk;
     g.n0 = d->seg[0].c / (16 * RW);
+    g.lz0 = (d->lo_zero_from > 0 && d->lo_zero_from % (16 * RW) == 0) ? d->lo_zero_from / (16 * RW) : nchunk;
     g.kgroups = kgroups;
     g.npieces = (g.Wr * 4 * RW + GT - 1) / GT;
     g.nslice = 1;

@@ -284,15 +284,17 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
 #pragma unroll
             for (int j = 0; j < 4; ++j) hid[j] = (bf16_t)(o[dblk][4 * g + j] * inv_l);
             if (out_bf16) *(bf16x4*)(out_bf16 + pix * D + d) = hid;
-            const bf16x4 a = *(const bf16x4*)(mh + d), b = *(const bf16x4*)(ml + d);
-            bf16x4 oh, ol;
+            bf16x4 oh = hid, ol = {(bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f, (bf16_t)0.0f};      // mf.hi == NULL: the view receives hid itself
+            if (mf.hi != nullptr) {
+                const bf16x4 a = *(const bf16x4*)(mh + d), b = *(const bf16x4*)(ml + d);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y = join_bf16(a[j], b[j]) + beta * (float)hid[j];
-                bf16_t hh, ll;
-                split_bf16(y, hh, ll);
-                oh[j] = hh;
-                ol[j] = ll;
+                for (int j = 0; j < 4; ++j) {
+                    const float y = join_bf16(a[j], b[j]) + beta * (float)hid[j];
+                    bf16_t hh, ll;
+                    split_bf16(y, hh, ll);
+                    oh[j] = hh;
+                    ol[j] = ll;
+                }
             }
             *(bf16x4*)(gh + d) = oh;
             *(bf16x4*)(gl + d) = ol;
@@ -574,16 +576,25 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     }
     const float inv_l = 1.0f / l, beta = beta_p[0];
     const int d = g8 * 8;
-    const bf16x8 mh = *(const bf16x8*)((const bf16_t*)mf.hi + pix * mf.ld + d), ml = *(const bf16x8*)((const bf16_t*)mf.lo + pix * mf.ld + d);
     bf16x8 hid, oh, ol;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        hid[j] = (bf16_t)(acc[j] * inv_l);
-        const float y = join_bf16(mh[j], ml[j]) + beta * (float)hid[j];
-        bf16_t hh, ll;
-        split_bf16(y, hh, ll);
-        oh[j] = hh;
-        ol[j] = ll;
+    for (int j = 0; j < 8; ++j) hid[j] = (bf16_t)(acc[j] * inv_l);
+    if (mf.hi != nullptr) {                             // (uniform) mfg = mf + beta * hid
+        const bf16x8 mh = *(const bf16x8*)((const bf16_t*)mf.hi + pix * mf.ld + d), ml = *(const bf16x8*)((const bf16_t*)mf.lo + pix * mf.ld + d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = join_bf16(mh[j], ml[j]) + beta * (float)hid[j];
+            bf16_t hh, ll;
+            split_bf16(y, hh, ll);
+            oh[j] = hh;
+            ol[j] = ll;
+        }
+    } else {                                            // the view receives hid itself: bf16-exact values, an all-zero lo plane
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            oh[j] = hid[j];
+            ol[j] = (bf16_t)0.0f;
+        }
     }
     if (out_bf16) *(bf16x8*)(out_bf16 + pix * D + d) = hid;
     *(bf16x8*)((bf16_t*)mfg.hi + pix * mfg.ld + d) = oh;
@@ -600,7 +611,8 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
     PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
     PPMS_REQUIRE(ksel >= 1 && ksel <= 5 && T >= 1 && n >= 1, "mem_attn: bad sizes ksel=%d T=%d n=%d", ksel, T, n);
     PPMS_REQUIRE(frames_per_workgroup >= 0 && frames_per_workgroup <= 2, "mem_attn: frames_per_workgroup must be 0 (automatic), 1 or 2, got %d", frames_per_workgroup);
-    PPMS_REQUIRE(mf.hi && mf.lo && mfg.hi && mfg.lo && mf.ld % 8 == 0 && mfg.ld % 8 == 0, "mem_attn: mf / mfg must be 16-B aligned SP views");
+    PPMS_REQUIRE(((mf.hi && mf.lo && mf.ld % 8 == 0) || (!mf.hi && !mf.lo)) && mfg.hi && mfg.lo && mfg.ld % 8 == 0,
+                 "mem_attn: mf (or a NULL view: the output is hid itself) / mfg must be 16-B aligned SP views");
     static ppms_device_once once;
     once.run([] {
         (void)hipFuncSetAttribute((const void*)mem_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);

@@ -46,6 +46,8 @@ TUNING = dict(
     stream=True,          # register-streamed kernel (conv_stream.hip) where the library rates it faster (small maps: no K slices, no reduce launch);
                           # "all": wherever it serves a conv of a map of <= 16 384 pixels (A/B runs)
     stream_hint=0,        # its tile: 0 = the library chooses, 1 / 2 = 32- / 64-pixel tiles
+    hid_exact=True,       # hoisted blocks: the GRU convs read [h | mf, hid] with weights (W_mf + W_mfg | beta W_mfg) instead of [h | mf, mfg]; hid is a
+                          # bf16 tensor (all-zero lo plane), so the products with that plane are skipped (ppms_conv.lo_zero_from)
     convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
     conv5_m192=True,      # conv_gemm5's three-cout-block layout for the 190 / 192-cout convs (else padded to 256 rows)
     fork_min_pixels=0,    # independent branches of an iteration run on the side stream only on maps with at least this many pixels (0: always)
@@ -310,6 +312,15 @@ class PackedBlock:
                 put(name + "_h", w_h, None, [128, 256])
                 if name in ("zr2", "q2"):
                     put(name + "_h_y", w_h.transpose(3, 4).contiguous(), None, [128, 256])
+                if TUNING["hid_exact"]:
+                    # W_mf mf + W_mfg (mf + beta hid) = (W_mf + W_mfg) mf + (beta W_mfg) hid  (ppmstereo.py:552, ppmtereo_update.py:985-988):
+                    # the third input block becomes the attention's bf16 read-out itself (sums formed in fp64, rounded once)
+                    beta = float(sd["aggregator.beta"].detach().double().reshape(-1)[0])
+                    wd = wt.double()
+                    w_x = torch.cat([wd[:, :128], wd[:, 256:384] + wd[:, 384:], beta * wd[:, 384:]], 1).float().contiguous()
+                    put(name + "_x", w_x, None, [128, 256])
+                    if name in ("zr2", "q2"):
+                        put(name + "_x_y", w_x.transpose(3, 4).contiguous(), None, [128, 256])
         put("fh1", g("flow_head.conv1.weight"), g("flow_head.conv1.bias"), [128])
         # flow_head.conv2 (256 -> 2, 3x3x3) as a 1x1 GEMM to 27*2 = 54 channels + shifted sum (ppms_tap_gather_sum)
         w2 = g("flow_head.conv2.weight")                                     # (2, 256, 3, 3, 3)
@@ -416,6 +427,7 @@ class ScaleEngine:
         self.lib = L.load()
         self._ev, self._ev_i = None, 0
         self._xa_halo = None        # handle of x's +-2-frame halo while it is in flight (sharded window)
+        self._x_hid = False         # True: X[256:384] holds the attention read-out hid (attend()), not mfg = mf + beta hid (set_mfg())
         # independent branches of an iteration (flow encoder || correlation encoder, r-gate || z-gate, mask head || flow
         # head) run on a second HIP stream, fork/joined with events: they fill each other's launch tails
         # the HBM-bound launches of an iteration, bracketable by bench.py like the convolutions (roofline_hbm)
@@ -442,7 +454,7 @@ class ScaleEngine:
 
     # ------------------------------------------------------------------ descriptors
     def _conv(self, wname, segs: List[L.SP], k3, epi0: L.Epilogue, epi1: Optional[L.Epilogue] = None, m_split: Optional[int] = None,
-              keep=(), nslice: Optional[int] = None) -> ConvOp:
+              keep=(), nslice: Optional[int] = None, lo_zero_from: int = 0) -> ConvOp:
         packed, bias, meta = self.pk.w[wname] if isinstance(wname, str) else wname
         d = L.Conv()
         for i, s in enumerate(segs):
@@ -452,6 +464,7 @@ class ScaleEngine:
         d.w, d.bias = packed.data_ptr(), bias.data_ptr()
         d.T, d.H, d.W = self.T, self.h, self.w
         d.t_halo = self.halo if k3[0] > 1 else 0        # temporal taps read the neighbour ranks' boundary frames from the halo slabs
+        d.lo_zero_from = lo_zero_from                    # input channels from here on are bf16-exact (all-zero lo plane): a promise, see ppms.h
         d.kt, d.kh, d.kw = k3
         d.M = meta["M"]
         d.m_split = meta["M"] if m_split is None else m_split
@@ -578,22 +591,26 @@ class ScaleEngine:
             for k, kk in (("zr1_0", (1, 1, 15)), ("q1", (1, 1, 5)), ("zr2", (1, 5, 1)), ("q2", (1, 5, 1)), ("zr3", (5, 1, 1)), ("q3", (5, 1, 1))):
                 m = self.PRE[k].shape[1]
                 o["pre_" + k] = self._conv(k + "_i", [inp], kk, E(n_valid=m, out_f32=self.PRE[k], out_f32_ld=m))
-        sfx = "_h" if hoist else ""
         pre = lambda k, off=0: dict(pre_f32=self.PRE[k], pre_off=off) if hoist else {}
         # GRU pass along W (two-layer z / r), then H, then T: h cycles through Hb[0] -> Hb[1] -> Hb[2] -> Hb[0]
-        o["zr1_0"] = self._conv("zr1_0" + sfx, [H[0].view(), x_all], (1, 1, 15), E(act=L.ACT_GELU, n_valid=128, out_sp=self.ZT.view(), **pre("zr1_0")),
-                                E(act=L.ACT_GELU, n_valid=128, out_sp=self.RT.view(), **pre("zr1_0", 128)), m_split=128)
         o["z1_2"] = self._conv("z1_2", [self.ZT.view()], (1, 1, 5), E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128))
         o["r1_2"] = self._conv("r1_2", [self.RT.view()], (1, 1, 5), E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[0].view()))
-        o["q1"] = self._conv("q1" + sfx, [self.RH.view(), x_all], (1, 1, 5),
-                             E(L.EPI_GRU, n_valid=128, out_sp=H[1].view(), aux_sp=H[0].view(), aux_f32=self.Z, aux_f32_ld=128, **pre("q1")))
-        for n, kk, src, dst in (("2", (1, 5, 1), 1, 2), ("3", (5, 1, 1), 2, 0)):
-            o["zr" + n] = self._conv("zr" + n + sfx, [H[src].view(), x_all], kk,
-                                     E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128, **pre("zr" + n)),
-                                     E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[src].view(), **pre("zr" + n, 128)), m_split=128)
-            o["q" + n] = self._conv("q" + n + sfx, [self.RH.view(), x_all], kk,
-                                    E(L.EPI_GRU, n_valid=128, out_sp=H[dst].view(), aux_sp=H[src].view(), aux_f32=self.Z, aux_f32_ld=128,
-                                      **pre("q" + n)))
+        # the convs over x exist twice on hoisted blocks: "" reads [h | mf, mfg] (the reference's operands: update() driven with a caller's mfg),
+        # "_x" reads [h | mf, hid] with the folded weights and skips the products with hid's all-zero lo plane (the loop: attend() leaves hid)
+        self.hid_mode = bool(hoist and TUNING["hid_exact"])
+        for tag, sfx, lz in ((("", "_h" if hoist else "", 0), ("_x", "_x", 256)) if self.hid_mode else (("", "_h" if hoist else "", 0),)):
+            o["zr1_0" + tag] = self._conv("zr1_0" + sfx, [H[0].view(), x_all], (1, 1, 15), E(act=L.ACT_GELU, n_valid=128, out_sp=self.ZT.view(), **pre("zr1_0")),
+                                          E(act=L.ACT_GELU, n_valid=128, out_sp=self.RT.view(), **pre("zr1_0", 128)), m_split=128, lo_zero_from=lz)
+            o["q1" + tag] = self._conv("q1" + sfx, [self.RH.view(), x_all], (1, 1, 5),
+                                       E(L.EPI_GRU, n_valid=128, out_sp=H[1].view(), aux_sp=H[0].view(), aux_f32=self.Z, aux_f32_ld=128, **pre("q1")), lo_zero_from=lz)
+            for n, kk, src, dst in (("2", (1, 5, 1), 1, 2), ("3", (5, 1, 1), 2, 0)):
+                o["zr" + n + tag] = self._conv("zr" + n + sfx, [H[src].view(), x_all], kk,
+                                               E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128, **pre("zr" + n)),
+                                               E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[src].view(), **pre("zr" + n, 128)), m_split=128,
+                                               lo_zero_from=lz)
+                o["q" + n + tag] = self._conv("q" + n + sfx, [self.RH.view(), x_all], kk,
+                                              E(L.EPI_GRU, n_valid=128, out_sp=H[dst].view(), aux_sp=H[src].view(), aux_f32=self.Z, aux_f32_ld=128,
+                                                **pre("q" + n)), lo_zero_from=lz)
         o["fh1"] = self._conv("fh1", [H[0].view()], (3, 3, 3), E(act=L.ACT_RELU, n_valid=256, out_sp=self.FH1.view()))
         o["fh2"] = self._conv("fh2", [self.FH1.view()], k1, E(n_valid=54, out_f32=self.FH2Y, out_f32_ld=64))
         o["m1"] = self._conv("m1", [H[0].view()], (3, 3, 3) if self.pk.convex_3d else k3, E(act=L.ACT_RELU, n_valid=256, out_sp=self.M1.view()))
@@ -642,6 +659,7 @@ class ScaleEngine:
 
     def set_mfg(self, mfg: torch.Tensor):
         self.load_nchw(mfg, self.X.view(256, 128))
+        self._x_hid = False
 
     def set_flow(self, flow: torch.Tensor):
         f = flow.contiguous().float()
@@ -674,6 +692,9 @@ class ScaleEngine:
         return self.store_nchw(self.X.view(128, 128), 128)
 
     def get_mfg(self):
+        if self._x_hid:             # the buffer holds hid: mfg = mf + beta * hid (ppmstereo.py:552), formed on demand (tests, API parity)
+            mfg = self.X.to_f32(128, 128) + self.pk.beta * self.X.to_f32(256, 128)
+            return mfg.reshape(self.T, self.h, self.w, 128).permute(0, 3, 1, 2).contiguous()
         return self.store_nchw(self.X.view(256, 128), 128)
 
     def get_value(self):
@@ -811,9 +832,12 @@ class ScaleEngine:
             ev = self._ev[self._ev_i]
             self._ev_i += 1
             ev[0].record()
+        # hoisted blocks: X[256:384] receives hid itself (bf16-exact), the GRU convs use the folded weights ("_x" ops)
+        mf_in = L.SP(None, None, 0, 0) if self.hid_mode else self.X.view(128, 128)
         L.check(self.lib.ppms_mem_attn(self.QB.data_ptr(), self.KB.data_ptr(), self.VTG.data_ptr(), sel, self.ksel, self.scale,
-                                       self.pk.beta.data_ptr(), self.X.view(128, 128), self.X.view(256, 128), L.ptr(out_bf16), self.T, self.n,
+                                       self.pk.beta.data_ptr(), mf_in, self.X.view(256, 128), L.ptr(out_bf16), self.T, self.n,
                                        self.ATT_WS.data_ptr(), 0, s))
+        self._x_hid = self.hid_mode
         if ev is not None:
             ev[1].record()
         if self.shard is not None and self.pk.attn is None:
@@ -874,13 +898,14 @@ class ScaleEngine:
         if self.pk.hoist and self._pre_pending:
             torch.cuda.current_stream().wait_event(self._ev_pre)
             self._pre_pending = False
-        o["zr1_0"]()
+        tag = "_x" if self._x_hid else ""         # which operands X[256:384] holds: hid (the loop) or mfg (a caller's)
+        o["zr1_0" + tag]()
         with self._fork():
             o["r1_2"]()
         o["z1_2"]()
         self._join()
         for k in ("q1", "zr2", "q2"):
-            o[k]()
+            o[k + tag]()
         # GRU pass along T, (5,1,1) convs (ppmtereo_update.py:305-310): +-2 frames of [h | mf, mfg], then of r*h
         if self.shard is not None:
             self._halo_sp(self.Hb[2], 2)            # h after the H pass: needed at once
@@ -889,9 +914,9 @@ class ScaleEngine:
                 self._xa_halo = None
             else:                                   # (update() driven without attend(): the module-level forward())
                 self._halo_sp(self.XA, 2)
-        o["zr3"]()
+        o["zr3" + tag]()
         self._halo_sp(self.RH, 2)
-        o["q3"]()
+        o["q3" + tag]()
         self._halo_sp(self.Hb[0], 1)                # FlowHead3D / mask_3d: 3x3x3 convs of the new hidden state
         if need_mask:
             with self._fork():                    # mask head || flow head

@@ -65,6 +65,31 @@ def test_update_block_methods(model, tag):
         gd.check("net", net, 1e-4), gd.check("mask", mask, 2e-4), gd.check("dflow", dflow, 1e-4)
 
 
+@pytest.mark.parametrize("tag,T,h,w", [("update_block04", 5, 80, 128), ("update_block08", 5, 16, 64), ("update_block04", 2, 8, 32)])
+def test_gru_convs_on_the_read_out_equal_the_mfg_form(model, tag, T, h, w):
+    """Inside the loop the hoisted blocks feed the GRU convs [h | mf, hid] with weights (W_mf + W_mfg | beta W_mfg) instead of
+    [h | mf, mfg = mf + beta hid] (ppmstereo.py:552, ppmtereo_update.py:985-988): hid is the attention's bf16 read-out, its lo plane is all
+    zero and the products with it are skipped (ppms_conv.lo_zero_from).  The same sum in another order: SequenceUpdateBlock3D.forward on a
+    caller's mfg (the reference's operands) and the engine's update() on hid agree to fp32 rounding, at the 1/4 scale's full size (conv_gemm5)
+    and on small maps."""
+    blk = getattr(model, tag)
+    d = synth_scale_inputs(T, h, w, seed=51, with_mhs=False)
+    mf = hash_normal((T, 128, h, w), 52)
+    hid = hash_normal((T, 128, h, w), 53).to(torch.bfloat16).float()
+    beta = float(W[tag]["aggregator.beta"].reshape(-1)[0])
+    net_a, mask_a, dflow_a = blk(g(d["net"]), g(d["inp"]), g(mf), g(mf + beta * hid), t=T)
+    e = blk.engine(T, h, w, torch.device(DEV))
+    assert e.hid_mode
+    e.set_net(g(d["net"])), e.set_inp(g(d["inp"])), e.set_mf(g(mf))
+    e.load_nchw(g(hid), e.X.view(256, 128))
+    assert (e.X.own()[1, :, 256:] == 0).all()
+    e._x_hid = True
+    e.update()
+    assert maxdiff(e.get_mfg(), mf + beta * hid) < 1e-4          # (mf is stored split, hi + lo: 2^-16 relative)
+    for a, b, name in ((net_a, e.get_net(), "net"), (mask_a, e.get_mask(), "mask"), (dflow_a, e.get_dflow(), "dflow")):
+        assert maxdiff(a, b) < 2e-5 * max(1.0, a.abs().max().item()), name
+
+
 FUB = [("fub16", "update_block16", 0, 5, 8, 32, 2, 4, False), ("fub08", "update_block08", 1, 8, 8, 32, 3, 2, True),
        ("fub04", "update_block04", 2, 5, 16, 64, 2, 1, True), ("fub04_T2", "update_block04", 2, 2, 8, 32, 2, 1, True),
        # BASELINE configs 4-5 have T = 40 >> top-k: QAM pick / usage counter over several iterations, temporal_pe(40) inside the

@@ -111,7 +111,7 @@ def test_ops_refuse_cpu_tensors(lib):
 
 # ------------------------------------------------------------------------------------------------ conv GEMM
 def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=None, scale=1.0, seg_pad=None, version=2, wm=0, pre=None, nslice=None, ysweep=False,
-              m_pad=None):
+              m_pad=None, lo_zero_from=0):
     """x_list: list of (P, C_i) fp32 CPU tensors (channel-last).  Returns (P, Cout) fp32 from the SP output."""
     from ppmstereo_amd.engine import ConvOp, epilogue
     from ppmstereo_amd.packing import pack_conv2, pack_conv4
@@ -162,6 +162,7 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     d.T, d.H, d.W = T, H, W
     d.kt, d.kh, d.kw = k3
     d.M = d.m_split = meta["M"]
+    d.lo_zero_from = lo_zero_from
     d.epi[0] = e
     if version == 5 and nslice is not None and nslice < 0:                 # -1: let the library plan the slices (must find some)
         nslice = int(L.load().ppms_conv_gemm5_slices(C.byref(d)))
@@ -512,6 +513,29 @@ def test_conv_gemm5_three_cout_blocks_vs_torch(lib, name, T, H, W, segs, cout, k
     assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3,lz", [
+    ("gru_1x15", 2, 12, 128, [128, 256], 256, (1, 1, 15), 256), ("q_1x5_m128", 2, 12, 128, [128, 256], 128, (1, 1, 5), 256),
+    ("y_1x5x1", 2, 40, 32, [128, 256], 256, (1, 5, 1), 256), ("t_5x1x1_gemm_mode", 5, 16, 64, [128, 256], 256, (5, 1, 1), 256),
+    ("3x3_m192_one_segment", 2, 13, 45, [320], 190, (1, 3, 3), 192)])
+def test_conv_gemm5_skips_products_with_a_zero_lo_plane(lib, name, T, H, W, segs, cout, k3, lz):
+    """ppms_conv.lo_zero_from: input channels that hold bf16-exact values (the attention's read-out hid) have an all-zero lo plane, and
+    conv_gemm5 leaves their a_hi x b_lo MFMAs out (a scalar branch inside each such asm statement).  Same bits as the full product --
+    every sweep mode, both K-group layouts, the GEMM mode's 64-channel windows; and against torch."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    xcat = torch.cat(xs, 1)
+    xcat[:, lz:] = xcat[:, lz:].to(torch.bfloat16).float()                  # bf16-exact from channel lz on
+    xs = list(torch.split(xcat, segs, 1))
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    full = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=5)
+    skip = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=5, lo_zero_from=lz)
+    assert torch.equal(full, skip), name
+    assert maxdiff(skip, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+
+
 @pytest.mark.parametrize("cout", [128, 256, 190])
 def test_conv_gemm5_epilogue_classes(lib, cout):
     """conv_gemm5 instantiates its row loop per descriptor class (conv_epilogue.h): plain store (no load in the loop), hoisted share
@@ -786,6 +810,14 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
     mfg = X.to_f32(128, 128).cpu()
     # mfg is stored split (hi + lo): ~2^-16 relative
     assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 1e-4
+    # mf.hi == NULL: no aggregation, the view receives hid itself -- hi plane = the bf16 read-out, lo plane all zero (ppms_conv.lo_zero_from)
+    X.own()[1, :, 128:] = 1.0
+    raw2 = torch.zeros_like(raw)
+    L.check(lib_.ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), seld.data_ptr(), ksel_frames, scale, beta.data_ptr(), L.SP(None, None, 0, 0), X.view(128, 128),
+                               raw2.data_ptr(), T, n, L.ptr(ws), attn_frames, s))
+    torch.cuda.synchronize()
+    assert torch.equal(raw2, raw)
+    assert torch.equal(X.own()[0, :, 128:].reshape(T, n, 128), raw) and (X.own()[1, :, 128:] == 0).all()
 
 
 @pytest.mark.parametrize("attn_frames", [0, 2])

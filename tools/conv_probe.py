@@ -21,8 +21,13 @@ for t in (eng.X, eng.Hb[0], eng.Hb[1], eng.Hb[2], eng.RH, eng.ZT, eng.RT, eng.FH
 flops = {"zr1_0": 2 * 256 * 512 * 15, "q1": 2 * 128 * 512 * 5, "zr2": 2 * 256 * 512 * 5, "q2": 2 * 128 * 512 * 5, "zr3": 2 * 256 * 512 * 5, "q3": 2 * 128 * 512 * 5,
          "fh1": 2 * 256 * 128 * 27, "fh2": 2 * 2 * 256 * 27, "m1": 2 * 256 * 128 * 9, "m2": 2 * 144 * 256, "unc0": 2 * 128 * 256 * 9, "final_0": 2 * 190 * 320 * 9,
          "convc2_0": 2 * 192 * 256 * 9, "z1_2": 2 * 128 * 128 * 5, "r1_2": 2 * 128 * 128 * 5, "to_v": 2 * 128 * 128, "convf2_0": 2 * 64 * 128 * 9}
+lz = int(os.environ.get("PROBE_LOZERO", "0"))       # e.g. 256: the mfg third of x = [mf, mfg] holds bf16-exact values (ppms_conv.lo_zero_from)
+if lz:
+    eng.X.own()[1, :, 256:] = 0
 for name in ops:
     op = eng.op[name]
+    if lz and name in ("zr1_0", "q1", "zr2", "q2", "zr3", "q3"):
+        op.desc.lo_zero_from = lz
     for _ in range(3):
         op()
     torch.cuda.synchronize()
