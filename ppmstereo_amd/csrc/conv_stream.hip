@@ -324,7 +324,7 @@ extern "C" int ppms_conv_stream_applicable(const ppms_conv* d) {
     if (!plan7(d, pl, 0)) return 0;
     const int64_t K = (int64_t)pl.g.nsteps * 16;
     const bool spatial = d->kh > 1 || d->kw > 1;
-    if (pl.g.P <= 4096) return K * d->M <= 1200000 ? 1 : 2;
+    if (pl.g.P <= 4096) return (double)pl.g.P * (double)K * d->M <= 4.0e9 ? 1 : 2;       // (3 200 pixels: K x M <= 1.25 M)
     if (!spatial && pl.g.P <= 32768 && (d->kt > 1 || K >= 768)) return 1;
     if (d->M <= 64 && pl.g.P <= 16384) return 1;
     return 2;
