@@ -8,7 +8,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1 &&
 cd /tmp &&
-timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $out/conv -o pmc -- /usr/bin/python3 $OLDPWD/tools/conv_pmc_probe.py zr1_0 4 > $out/conv.log 2>&1 &&
+timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $out/conv -o pmc -- /usr/bin/python3 $OLDPWD/tools/conv_pmc_probe.py zr1_0_x 4 > $out/conv.log 2>&1 &&
 timeout -k 10 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $out/attn -o pmc -- /usr/bin/python3 $OLDPWD/tools/attn_probe.py 4 1 > $out/attn.log 2>&1
 cd $OLDPWD
 python tools/pmc_summary.py $(find $out/conv -name "*counter_collection.csv" | head -1) conv5_kernel > $out/conv_pmc.txt

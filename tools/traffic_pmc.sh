@@ -11,7 +11,7 @@ python -c "import __graft_entry__ as g; g.build()" > $out/build.log 2>&1 &&
 cd /tmp &&
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $out/attn_$c -o pmc -- /usr/bin/python3 $OLDPWD/tools/attn_probe.py 4 1 > $out/attn_$c.log 2>&1 &&
-  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $out/conv_$c -o pmc -- /usr/bin/python3 $OLDPWD/tools/conv_pmc_probe.py zr1_0 4 > $out/conv_$c.log 2>&1 &&
+  timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $out/conv_$c -o pmc -- /usr/bin/python3 $OLDPWD/tools/conv_pmc_probe.py zr1_0_x 4 > $out/conv_$c.log 2>&1 &&
   timeout -k 10 200 rocprofv3 --pmc $c --output-format csv -d $out/corr_$c -o pmc -- /usr/bin/python3 $OLDPWD/tools/corr_probe.py 5 80 128 > $out/corr_$c.log 2>&1 || exit 1
 done
 cd $OLDPWD &&
