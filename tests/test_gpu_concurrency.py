@@ -97,6 +97,15 @@ def test_small_kernels_are_unaffected_by_a_concurrent_conv(eng):
     cases = {"bilinear(ones)": lambda: bilinear(ones, (4 * h, 4 * w), False), "bilinear(random)": lambda: bilinear(rnd, (4 * h, 4 * w), False),
              "bilinear(align_corners)": lambda: bilinear(rnd, (4 * h, 4 * w), True), "convex_upsample": cvx, "nhwc_to_nchw": to_nchw,
              "dwconv_gelu": dw, "layernorm": ln, "conv q1 (other conv concurrent)": lambda: (eng.op["q1"](), eng.Hb[1].to_f32())[1]}
+    # the register-streamed small-map conv (conv_stream.hip: four K-groups summed through LDS in wave order) on a 1/16-scale engine, under the
+    # 1/4 scale's convs on the other stream
+    from ppmstereo_amd.ppmstereo import PPMStereoHotPath
+    e16 = PPMStereoHotPath().load_hot_path_weights(Wm.hot_path_weights()).to(DEV).eval().update_block16.engine(5, 20, 32, torch.device(DEV))
+    for t in (e16.X, e16.XA, e16.Hb[0], e16.RH):
+        t.set_f32(0.3 * hash_normal((t.pixels, t.channels), 2).to(DEV))
+    assert e16.op["q1"].version == 7 and e16.op["fh1"].version == 7
+    cases["conv_stream q1 (1/16 scale)"] = lambda: (e16.op["q1"](), e16.Hb[1].to_f32())[1]
+    cases["conv_stream fh1 (1/16 scale, 64-pixel tiles)"] = lambda: (e16.op["fh1"](), e16.FH1.to_f32())[1]
     bad = {name: _mismatches(eng, fn) for name, fn in cases.items()}
     bad["mem_attn 64-query + combine"] = _mismatches(eng, attn(True), heavy=("zr1_0", "m1", "zr2"), n=30)
     bad["mem_attn 32-query fused"] = _mismatches(eng, attn(False), heavy=("zr1_0", "m1", "zr2"), n=12)
