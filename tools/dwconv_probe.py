@@ -7,7 +7,8 @@ from ppmstereo_amd.ppmstereo import PPMStereoHotPath
 from ppmstereo_amd.weights import hash_normal
 dev = torch.device("cuda:0")
 m = PPMStereoHotPath().load_hot_path_weights(Wm.hot_path_weights()).to(dev).eval()
-eng = m.update_block04.engine(5, 80, 128, dev)
+T_, h_, w_ = (int(v) for v in os.environ.get("PROBE_SHAPE", "5,80,128").split(","))
+eng = m.update_block04.engine(T_, h_, w_, dev)
 for t in (eng.C1, eng.C2):
     t.set_f32(0.3 * hash_normal((t.pixels, t.channels), 1).to(dev))
 w7 = hash_normal((40, 49), 3).to(dev).contiguous(); b7 = hash_normal((40,), 4).to(dev)
