@@ -383,6 +383,43 @@ def test_conv_stream_epilogues_and_hoisted_share(lib):
     assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(full)) < 5e-5
 
 
+@pytest.mark.parametrize("version", [7, 2])
+@pytest.mark.parametrize("T,H,W,halo,k3", [(3, 4, 8, 2, (5, 1, 1)), (2, 5, 7, 1, (3, 3, 3)), (1, 3, 5, 2, (5, 1, 1))])
+def test_conv_temporal_halo_slabs(lib, version, T, H, W, halo, k3):
+    """ppms_conv.t_halo (frame-sharded windows, ppmstereo_amd/dist.py): the T frames of a rank sit between `halo` readable frames of its
+    neighbours, and temporal taps read those instead of zero padding.  A conv over the middle T frames of a (T + 2 halo)-frame volume with
+    t_halo = halo must equal the middle of the conv over the whole volume wherever the taps stay inside it (every output frame: the halo is as
+    deep as the taps reach) -- conv_stream (tiles that span frames, per-tile temporal-tap skipping) and conv_gemm2."""
+    from ppmstereo_amd.engine import ConvOp, epilogue
+    from ppmstereo_amd.packing import pack_conv2, pack_stream
+    L = lib
+    assert halo >= k3[0] // 2
+    Tf, HW = T + 2 * halo, H * W
+    cin, cout = 64, 64
+    xf = hash_normal((Tf * HW, cin), 600)
+    wt = hash_normal((cout, cin, *k3), 601) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 602) * 0.1
+    ref = _ref_conv([xf], wt, bs, k3, Tf, H, W)[halo * HW:(halo + T) * HW]
+    xt = L.SPTensor(T * HW, cin, DEV, before=halo * HW, after=halo * HW)
+    hi = xf.to(torch.bfloat16)
+    xt.data[0].copy_(hi.to(DEV))
+    xt.data[1].copy_((xf - hi.float()).to(torch.bfloat16).to(DEV))
+    packed, b, meta = (pack_stream if version == 7 else pack_conv2)(wt.to(DEV), bs.to(DEV), [cin], [cin])
+    out = L.SPTensor(T * HW, meta["M"], DEV)
+    d = L.Conv()
+    d.seg[0] = xt.view()
+    d.nseg, d.w, d.bias = 1, packed.data_ptr(), b.data_ptr()
+    d.T, d.H, d.W = T, H, W
+    d.kt, d.kh, d.kw = k3
+    d.t_halo = halo
+    d.M = d.m_split = meta["M"]
+    d.epi[0] = epilogue(n_valid=cout, out_sp=out.view())
+    ConvOp(d, [packed, b], version, nslice=1)()
+    torch.cuda.synchronize()
+    got = out.to_f32()[:, :cout].cpu()
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item())
+
+
 def test_conv_stream_refuses_what_it_does_not_serve(lib):
     L = lib
     d = L.Conv()
