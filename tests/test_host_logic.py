@@ -208,6 +208,38 @@ def test_k_slicing_plan_for_small_maps():
     assert lib.ppms_conv_gemm2_slice_workspace_bytes(C.byref(d), 1) == 0
 
 
+def test_conv_stream_rating():
+    """ppms_conv_stream_applicable: 1 = served and rated faster than the K-sliced LDS-staged kernel + reduce launch (maps of <= 4 096 pixels while
+    pixels x K x M <= 4e9; larger maps only for convolutions without spatial taps and for 64-cout convs), 2 = served but the staged kernels win,
+    0 = not served (input channels not a multiple of 64, M not a multiple of 64, out_vt)."""
+    import ctypes as C
+    from ppmstereo_amd import _lib as L
+    lib = L.load()
+    r = lambda *a, **k: lib.ppms_conv_stream_applicable(C.byref(_desc(*a, **k)))
+    # the 1/16 scale of config 2 (3 200 pixels): everything but update_block16's 15-tap z/r conv
+    assert r(5, 20, 32, 128, (1, 1, 5), [128, 384]) == 1           # q1
+    assert r(5, 20, 32, 256, (1, 5, 1), [128, 384]) == 1           # zr2
+    assert r(5, 20, 32, 256, (3, 3, 3), [128]) == 1                # flow head
+    assert r(5, 20, 32, 192, (1, 3, 3), [320]) == 1                # final_conv
+    assert r(5, 20, 32, 768, (1, 1, 1), [384, 384]) == 1           # the K = 768 Linear layer of the space attention
+    assert r(5, 20, 32, 256, (1, 1, 15), [128, 384]) == 2          # 3 200 x 7 680 x 256 = 6.3e9: the staged kernel re-uses its window over 15 taps
+    # the 1/8 scale (12 800 pixels): only what the staged kernel has no window re-use or too few tiles for
+    assert r(5, 40, 64, 256, (5, 1, 1), [128, 256]) == 1           # temporal GRU pass
+    assert r(5, 40, 64, 64, (1, 3, 3), [128]) == 1                 # convf2: 64 couts
+    assert r(5, 40, 64, 128, (1, 1, 5), [128, 256]) == 2
+    assert r(5, 40, 64, 256, (3, 3, 3), [128]) == 2
+    # the 1/4 scale: never
+    assert r(5, 80, 128, 128, (5, 1, 1), [128, 256]) == 2
+    assert r(5, 80, 128, 64, (1, 3, 3), [128]) == 2
+    # config 3's 1/16 scale (18 400 pixels): the tap-less ones
+    assert r(5, 46, 80, 384, (1, 1, 1), [768]) == 1 and r(5, 46, 80, 128, (1, 1, 5), [128, 384]) == 2
+    # not served
+    assert r(5, 20, 32, 128, (1, 1, 1), [96]) == 0                 # K = 96
+    assert r(5, 20, 32, 128, (1, 1, 1), [128], out_vt=True) == 0   # to_v writes V^T (gemm1 serves it)
+    d = _desc(5, 20, 32, 128, (1, 2, 1), [128])
+    assert lib.ppms_conv_stream_applicable(C.byref(d)) == 0        # even kernel extent
+
+
 def test_large_map_kernel_applicability():
     """ppms_conv_gemm3_applicable: M % 128 == 0, a spatial sweep axis, >= 384 workgroups, and (2-D sweeps) a halo'd window
     that fits the LDS budget."""
