@@ -222,9 +222,13 @@ def main():
         step_ms = [pipe.done_events[i - 1].elapsed_time(pipe.done_events[i]) for i in range(1, args.steps)]
         pipe.serial, pipe.record_done = False, False
     attn_ms = [e.attn_times_ms() for e, _ in engs] if not args.no_kernel_timing else []
+    # the large-map convolution launches of the timed region: read their events NOW and detach the lists, so that the extra steps below (which
+    # switch KERNEL_TIMING on again) cannot append a second step's launches to them (round 4 counted `total_ms_per_step` twice that way)
+    conv3_ms = {k: [a.elapsed_time(b) for a, b in op.events] for k, op in conv3.items()}
+    for op in conv3.values():
+        op.events = None
     fam_events = {}
     if family:                                        # one extra step (outside `value`) with events around EVERY convolution-family launch
-        saved = {k: op.events for k, op in family.items()}
         for op in family.values():
             op.events = []
         for e, _ in engs:
@@ -235,7 +239,7 @@ def main():
         torch.cuda.synchronize()
         for k, op in family.items():
             fam_events[k] = [a.elapsed_time(b) for a, b in op.events]
-            op.events = saved[k]
+            op.events = None
 
     hbm_roof = None
     if not args.no_kernel_timing:                     # another extra step: the HBM-bound kernels of the path (SURVEY 8d "report both")
@@ -302,32 +306,47 @@ def main():
         # ---- large-map conv kernels: algorithmic FLOPs of a launch = 2 * pixels * couts * cin * taps from its descriptor
         if conv3:
             torch.cuda.synchronize()
-            c_flop = c_ms = 0.0
+            c_flop = c_ms = c_bound_ms = 0.0
             c_n, per_op = 0, {}
             for (sc, name), op in sorted(conv3.items()):
-                ms = [a.elapsed_time(b) for a, b in op.events]
+                ms = conv3_ms[(sc, name)]
                 if not ms:
                     continue
                 c_flop += op.flops() * len(ms)
                 c_ms += sum(ms)
                 c_n += len(ms)
+                # MFMAs per algorithmic product of THIS launch: 3 (hi*hi, lo*hi, hi*lo), less the hi*lo products the kernel leaves out for input
+                # channels whose lo plane is known to be zero (ppms_conv.lo_zero_from): its bound is dense bf16 / mfma_per_product, not / 3
+                mpp = op.mfma_per_product()
+                c_bound_ms += len(ms) * op.flops() * mpp / (BF16_DENSE_PEAK_TFLOPS * 1e12) * 1e3
                 per_op[f"1/{sc}:{name}"] = dict(kernel=f"conv{op.version}_kernel", launches=len(ms), avg_ms=round(sum(ms) / len(ms), 4), gflop=round(op.flops() / 1e9, 2),
-                                                tflops=round(op.flops() / (sum(ms) / len(ms) * 1e-3) / 1e12, 1))
+                                                tflops=round(op.flops() / (sum(ms) / len(ms) * 1e-3) / 1e12, 1), mfma_per_product=round(mpp, 4))
             if c_n:
                 cach = c_flop / (c_ms * 1e-3) / 1e12
+                cpeak = c_flop / (c_bound_ms * 1e-3) / 1e12           # the launch mix's own bound: dense bf16 / (flop-weighted MFMAs per product), >= 833.3
+                assert c_n == len(conv3_ms) * n_sampled or pipe is not None, (c_n, len(conv3_ms), n_sampled)       # one launch per op and sampled step
                 ctraffic = None
                 tfile = _latest_profile("conv_traffic.json")
                 if tfile and (T, H, W) == (5, 320, 512):
                     ctraffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
                 roofs.append(dict(bound="mfma", kernel="conv5_kernel / conv3_kernel (large-map implicit-GEMM convolutions, bf16x3 split MFMA; per_op names the kernel), "
                                                        "every launch in every 20th step of the timed region (step 0, 20, ...); "
-                                                       "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / 3 (three MFMAs per product)",
-                                  achieved=round(cach, 2), peak=round(CONV_BOUND_TFLOPS, 1), unit="TFLOP/s", frac=round(cach / CONV_BOUND_TFLOPS, 4),
+                                                       "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / (MFMAs per product): 3 "
+                                                       "(hi*hi + lo*hi + hi*lo), less the hi*lo products skipped for input channels with an all-zero lo plane "
+                                                       "(per_op[].mfma_per_product; flop-weighted over the launches: mfma_per_product)",
+                                  achieved=round(cach, 2), peak=round(cpeak, 1), unit="TFLOP/s", frac=round(cach / cpeak, 4),
+                                  mfma_per_product=round(BF16_DENSE_PEAK_TFLOPS / cpeak, 4), frac_of_three_mfma_bound=round(cach / CONV_BOUND_TFLOPS, 4),
+                                  mfma_issued_tflops=round(cach * BF16_DENSE_PEAK_TFLOPS / cpeak, 1),
                                   frac_of_bf16_dense=round(cach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=ctraffic,
                                   traffic_note="HBM bytes of ONE zr1_0 launch at the 1/4 scale, profiles/rNN_conv_traffic.json",
                                   launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / n_sampled, 3),
                                   flop_per_launch=c_flop / c_n, per_op=per_op))
         roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first
+        if pipe is None and not sharded:
+            # consistency: the two families run one after the other inside a step (the convs' own two streams overlap each other, which can only
+            # shorten the step), so their event sums cannot exceed the step by more than the event overhead of the sampled step
+            tot = sum(r["total_ms_per_step"] for r in roofs)
+            assert tot <= max(step_ms[0], 1e3 * elapsed / args.steps) * 1.05, (tot, step_ms[0], 1e3 * elapsed / args.steps)
         # ---- the whole convolution family of a step, all three scales: every implicit-GEMM launch (large-map and small-map kernels, the
         # slice-reduce halves, the once-per-scale hoisted shares and q/k projections), the fused per-pixel chains, the depthwise 7x7 -- against
         # the reference's algorithmic conv FLOPs (14.128 MFLOP per pixel and iteration at 1/4 and 1/8, 17.75 at 1/16)

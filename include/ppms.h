@@ -161,9 +161,12 @@ int ppms_gemm1(const ppms_conv* desc, const ppms_conv* dev_desc, int cb_hint, vo
  * (no LDS, no barrier in the K loop); partial tiles summed through LDS in wave order; the shared row epilogue (every kind but ADDF32, no
  * out_vt).  No workspace, no second launch, bit-reproducible.  Replaces, for the same ppms_conv descriptor, what the reference runs as one
  * cuDNN convolution (ppmtereo_update.py:254-312, 445-482, 670-678, 889-893, 910-914).
- * applicable: 0 = not served; 1 = served on a map of <= 16 384 pixels (what it is for); 2 = served, but the map is large. */
+ * applicable: 0 = not served; 1 = served AND measured faster than the LDS-staged kernels with their K slices + reduce launch; 2 = served,
+ * but the LDS-staged kernels (ppms_conv_gemm2 / _sliced) win -- a binding sends a convolution here only on 1.  The rating
+ * (conv_stream.hip, profiles/r04_conv_stream_probe.txt): maps of <= 4 096 pixels while pixels x K x M <= 4e9 (K = taps x input channels);
+ * larger maps only without spatial taps (kt > 1 or K >= 768) up to 32 768 pixels, and 64-cout convolutions up to 16 384 pixels. */
 int ppms_conv_stream_applicable(const ppms_conv* desc);
-/* hint: 32-pixel blocks per tile (1, 2), 0 = let the library choose from the grid size */
+/* hint: 0 = the library chooses the tile from the grid size; 1 / 2 = 32- / 64-pixel tiles.  Any other value is refused (PPMS_EINVAL). */
 int ppms_conv_stream(const ppms_conv* desc, const ppms_conv* dev_desc, int hint, void* stream);
 /* sizeof(ppms_sp), sizeof(ppms_epilogue), sizeof(ppms_conv) as compiled: lets a foreign-language binding check its
  * struct layout at load time */

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import packing as _packing
-from .engine import ConvOp, epilogue
+from .engine import ConvOp, TUNING, epilogue
 from .weights import CNET_DEPTHS, CNET_DIMS
 
 
@@ -109,7 +109,7 @@ class Feature(nn.Module):
             pk[name] = (packed, bias, meta, tuple(w4.shape[2:]))
             if tuple(w4.shape[2:]) == (1, 1) and sum(meta["seg_padded"]) % 64 == 0:          # 1x1 layers the thin-GEMM kernel may serve (gemm1.hip)
                 pk[name + "@1"] = _packing.pack_gemm1(w4, b.detach().to(device), segs, meta["seg_padded"], None, meta["M"])
-            if sum(meta["seg_padded"]) % 64 == 0:            # layers the register-streamed small-map kernel may serve (conv_stream.hip)
+            if TUNING["stream"] and sum(meta["seg_padded"]) % 64 == 0:      # layers the register-streamed small-map kernel may serve (conv_stream.hip; same switch as the loop's engine)
                 pk[name + "@7"] = _packing.pack_stream(w4, b.detach().to(device), segs, meta["seg_padded"], None, meta["M"])
 
         def v(name, t):
@@ -211,12 +211,12 @@ class _CnetEngine:
                 if lib.ppms_gemm1_applicable(C.byref(d1)) == 1:
                     self.steps.append(ConvOp(d1, [p1, b1], 6, device=device))
                     return
-            if name + "@7" in pk:                                             # small maps: no K slices, no reduce launch (the library rates it)
+            if TUNING["stream"] and name + "@7" in pk:                        # small maps: no K slices, no reduce launch (the library rates it)
                 p7, b7, _ = pk[name + "@7"]
                 d7 = L.Conv.from_buffer_copy(bytes(dd))
                 d7.w, d7.bias = p7.data_ptr(), b7.data_ptr()
                 if lib.ppms_conv_stream_applicable(C.byref(d7)) == 1:
-                    self.steps.append(ConvOp(d7, [p7, b7], 7, device=device))
+                    self.steps.append(ConvOp(d7, [p7, b7], 7, wm_hint=TUNING["stream_hint"], device=device))
                     return
             self.steps.append(ConvOp(dd, [packed_w, bias], 2, device=device))
 

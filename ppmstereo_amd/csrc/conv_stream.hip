@@ -334,7 +334,11 @@ extern "C" int ppms_conv_stream_applicable(const ppms_conv* d) {
 extern "C" int ppms_conv_stream(const ppms_conv* d, const ppms_conv* dev_desc, int hint, void* stream) {
     (void)dev_desc;
     Plan7 pl;
-    PPMS_REQUIRE(hint >= 0, "conv_stream: hint must be 0 (choose), 1 or 2 (32-pixel blocks per tile)");
+#ifdef PPMS_STREAM_PROBE
+    PPMS_REQUIRE(hint >= 0, "conv_stream: hint must be 0 (choose), 1 or 2 (32-pixel blocks per tile), or a probe encoding (KG << 8) | (PB << 4) | D");
+#else
+    PPMS_REQUIRE(hint >= 0 && hint <= 2, "conv_stream: hint must be 0 (choose), 1 or 2 (32-pixel blocks per tile)");
+#endif
     PPMS_REQUIRE(plan7(d, pl, hint), "conv_stream: not a convolution this kernel serves (odd taps, input channels a multiple of 64 in 16-channel-aligned "
                                      "segments, M %% 64 == 0, pack_stream weights, aligned SP operands, no out_vt / ADDF32 epilogue; ppms_conv_stream_applicable tells)");
     hipStream_t st = (hipStream_t)stream;

@@ -114,6 +114,17 @@ class ConvOp:
         cin = sum(d.seg[i].c for i in range(d.nseg))
         return 2.0 * d.T * d.H * d.W * cout * cin * d.kt * d.kh * d.kw
 
+    def mfma_per_product(self) -> float:
+        """MFMAs the kernel issues per algorithmic bf16x3 product: 3 (hi*hi, lo*hi, hi*lo), less the hi*lo products conv_gemm5 leaves out for the
+        input channels from `lo_zero_from` on (bf16-exact activations: their lo plane is all zero).  bench.py prices a launch against
+        dense bf16 / this."""
+        d = self.desc
+        cin = sum(d.seg[i].c for i in range(d.nseg))
+        lz = int(d.lo_zero_from)
+        if self.version != 5 or lz <= 0 or lz >= cin or lz % 16:
+            return 3.0
+        return 3.0 - (cin - lz) / cin
+
     def __call__(self):
         ev = self.events if KERNEL_TIMING["on"] else None
         if ev is not None:                  # bench.py: HIP events on the launch stream around this launch
@@ -756,11 +767,11 @@ class ScaleEngine:
     def hbm_bytes(self) -> Dict[str, float]:
         """Algorithmic HBM bytes of one launch of the HBM-bound kernels of this scale, every tensor touched once:
         lookup T n (4 levels x 10 taps x 4 B in + 36 x 4 B out + 8 B flow); key modulation K' = bf16(K s + PE): the fp32 keys of the
-        window's frames once (Tg n 128 x 4 B) + T k n 128 x 2 B of bf16 K' out; convex upsampling T n (144 + 2) 4 B in + T 16 n 2 x 4 B out; pyramid build 2 x 256 T n 4 B in + 1.875 T n w 4 B out."""
+        window's frames once (Tg n 128 x 4 B) + T k n 128 x 2 B of bf16 K' out; convex upsampling T n (144 + 2) 4 B in + T 16 n 2 x 4 B out; pyramid build 2 x 256 T n 4 B in + 1.9375 T n w 4 B out (five levels: 1 + 1/2 + 1/4 + 1/8 + 1/16)."""
         T, n, w = self.T, self.n, self.w
         return dict(corr_lookup=T * n * (4 * 10 * 4 + 36 * 4 + 8.0), attn_prep_k=self.Tg * n * 128 * 4.0 + T * self.ksel * n * 128 * 2.0,
                     convex_upsample=T * n * (self.pk.mask_ch + 2) * 4.0 + T * 16 * n * 2 * 4.0,
-                    corr_build=2 * 256 * T * n * 4.0 + 1.875 * T * n * w * 4.0)
+                    corr_build=2 * 256 * T * n * 4.0 + 1.9375 * T * n * w * 4.0)
 
     def _fork(self):
         if self.P < TUNING["fork_min_pixels"]:

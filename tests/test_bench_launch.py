@@ -44,8 +44,12 @@ def test_bench_propagates_a_rank_failure():
 def test_driver_command_shape_under_torchrun():
     """The driver's own command line: python -m torch.distributed.run ... bench.py --gpus N (RANK is set: no second launch)."""
     e = dict(os.environ, PPMS_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    import socket
+    with socket.socket() as sk:                                      # a free port, as bench.launch_ranks takes one (a fixed one collides under pytest -n)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"],
                        capture_output=True, text=True, cwd="/tmp", env=e, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _line(r.stdout)["n_gpus"] == 2

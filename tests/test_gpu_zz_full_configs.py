@@ -83,6 +83,49 @@ def test_forward_update_block_ten_iterations_vs_reference(model):
     gd.check("flow_out", fo, 5e-3), gd.check("net", net, 5e-3), gd.check("mhs", mhs, 2e-3), gd.check("uncs", torch.stack(uncs), 5e-4)
 
 
+def test_cascade_and_block_iters20_vs_reference(model):
+    """iters = 20 (10 / 10 / 20 iterations: the count of BASELINE configs 3-5, ppmstereo.py:482,708,744,777) against the REFERENCE's own
+    PPMStereo.forward(test_mode=False), all 40 predictions (tests/golden/cascade_it20.npz, same inputs as cascade_it10), and twenty
+    iterations of forward_update_block (fub04_it20).  The per-prediction table goes to profiles/rNN_parity.log (pytest -s).  The
+    oracle itself -- fp32 everywhere but the bf16 attention operands -- is 3.5e-4 px from the reference at prediction 39
+    (tests/test_oracle_golden.py): the recurrence amplifies bf16 rounding flips, and the distance grows with the iteration count."""
+    from ppmstereo_amd.corr import CorrBlock1D
+    gd = Golden("cascade_it20")
+    T, feats = it10_cascade_inputs()
+    preds, uncs = [], []
+    disp, unc = model.cascade({k: v.to(DEV) for k, v in feats.items()}, 20, T, preds, uncs)
+    assert len(preds) == 40
+    P = torch.stack(preds).float().cpu().numpy()
+    k, step = gd.keys["predictions"]
+    got, ref = P.reshape(-1)[::step], gd.raw("predictions")
+    which = np.arange(0, P.size, step) // P[0].size
+    worst = 0.0
+    for i in range(40):
+        e = np.abs(got - ref)[which == i]
+        worst = max(worst, float(e.mean()))
+        print(f"iters=20 prediction {i:2d} ({'1/16' if i < 10 else '1/8' if i < 20 else '1/4'}): EPE vs reference {e.mean():.3e} px, max {e.max():.3e} px")
+    k, step = gd.keys["disparity"]
+    e = np.abs(disp[None].float().cpu().numpy().reshape(-1)[::step] - gd.raw("disparity"))
+    print(f"iters=20 final disparity: EPE vs reference {e.mean():.3e} px, max {e.max():.3e} px; worst prediction EPE {worst:.3e} px")
+    assert e.mean() < 1e-3 and worst < 1e-3, (e.mean(), worst)       # north-star budget at the iteration count of configs 3-5
+    gd.check("uncertainty", unc[None], 4e-3)
+    gd = Golden("fub04_it20")
+    T, h, w, iters = 5, 16, 64, 20
+    d = synth_scale_inputs(T, h, w, seed=1052, with_mhs=True)
+    preds, uncs = [], []
+    fo, net, mhs = model.forward_update_block(None, model.update_block04, CorrBlock1D(g(d["fmap1"]), g(d["fmap2"])), g(d["flow"]), g(d["net"]),
+                                              g(d["inp"]), g(d["mhs"]), model.att[2], preds, uncs, iters, 1, T)
+    P = torch.stack(preds).float().cpu().numpy()
+    k, step = gd.keys["preds"]
+    got, ref = P.reshape(-1)[::step], gd.raw("preds")
+    which = np.arange(0, P.size, step) // P[0].size
+    for i in range(iters):
+        e = np.abs(got - ref)[which == i]
+        print(f"fub04 iters=20 iteration {i:2d}: EPE vs reference {e.mean():.3e} px, max {e.max():.3e} px")
+        assert e.mean() < 1e-3
+    gd.check("uncs", torch.stack(uncs), 1e-3)
+
+
 def test_config2_full_iteration_counts_vs_oracle(model):
     """BASELINE config 2 exactly as the metric is quoted: T=5, 320x512, iters=10 (5 / 5 / 10 iterations), the whole cascade against the CPU
     oracle (~90 s of host time), EPE printed after every iteration so that the amplification over the recurrence is on record.

@@ -22,7 +22,7 @@ for wl in widths:
     lv.append(store[off:off + rows * wl])
     off += rows * wl
 ptrs = (C.c_void_p * 5)(*[t.data_ptr() for t in lv])
-by = 2 * 256 * rows * 4 + 1.875 * rows * W * 4
+by = 2 * 256 * rows * 4 + 1.9375 * rows * W * 4
 
 
 def run(a, b, reps=30):

@@ -6,7 +6,7 @@ The reference lives read-only at /root/reference and never travels: this script 
 OUTPUT vectors (inputs and weights are regenerated from their seeds by the tests).
 
     python tools/gen_golden.py                     # rewrites tests/golden/
-    python tools/gen_golden.py it10 --out /tmp/g   # only the iters=10 fixtures, into another directory
+    python tools/gen_golden.py it10 --out /tmp/g   # only the iters=10 / iters=20 fixtures, into another directory
 
 Nothing in tests/, bench.py or smoke() reads /root/reference at run time.
 """
@@ -108,15 +108,15 @@ os.makedirs(OUT, exist_ok=True)
 MAX_ELEMS = 16384
 
 
-def save(name, **arrs):
-    """Tensors above MAX_ELEMS are stored as a strided subsample x.flatten()[::step] under "key__s<step>"
+def save(name, max_elems=MAX_ELEMS, **arrs):
+    """Tensors above max_elems are stored as a strided subsample x.flatten()[::step] under "key__s<step>"
     (tests/golden_util.py applies the same rule), keeping every fixture small."""
     path = os.path.join(OUT, name + ".npz")
     out = {}
     for k, v in arrs.items():
         a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
-        if a.size > MAX_ELEMS:
-            step = -(-a.size // MAX_ELEMS) | 1          # odd stride: does not alias with power-of-two dims
+        if a.size > max_elems:
+            step = -(-a.size // max_elems) | 1          # odd stride: does not alias with power-of-two dims
             out[f"{k}__s{step}"] = a.reshape(-1)[::step].copy()
             out[f"{k}__shape"] = np.asarray(a.shape)
         else:
@@ -146,7 +146,8 @@ def bare_model(attention_type=None, use_convex_3d=False):
 
 
 def it10_fixtures(m):
-    """North-star iteration counts (ppmstereo.py:482: 5 / 5 / 10 iterations at iters=10): the reference's own PPMStereo.forward with stub
+    """North-star iteration counts (ppmstereo.py:482: 5 / 5 / 10 iterations at iters=10; 10 / 10 / 20 at iters=20, the count of BASELINE
+    configs 3-5): the reference's own PPMStereo.forward with stub
     encoders on a T=5, 64x256 clip, EVERY prediction of the cascade kept (test_mode=False returns the stacked list, :795-810), and ten
     iterations of forward_update_block at one scale.  The right features are the left ones shifted along the epipolar line + noise, so
     the correlation volume has real peaks (as ppmstereo_amd.synth)."""
@@ -165,16 +166,21 @@ def it10_fixtures(m):
 
     m.fnet, m.cnet = FNet(), CNet()
     img = torch.zeros(1, T, 3, H, W)
-    ATTN_LOG.clear()
-    preds, uncs = m.forward(img, img, iters=10, test_mode=False)          # (20, 1, T, 1, H, W)
-    assert preds.shape[0] == 20 and len(ATTN_LOG) == T * 20
-    save("cascade_it10", predictions=preds[:, 0], uncertainties=uncs[:, 0], disparity=preds[-1], uncertainty=uncs[-1], n_attn_calls=len(ATTN_LOG))
-    T, h, w, iters = 5, 16, 64, 10
-    d = synth_scale_inputs(T, h, w, seed=1052, with_mhs=True)
-    cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
-    preds, uncs = [], []
-    fo, net, mhs = m.forward_update_block(None, m.update_block04, cb, d["flow"], d["net"], d["inp"], d["mhs"], m.att[2], preds, uncs, iters, 1, T)
-    save("fub04_it10", flow_out=fo, net=net, mhs=mhs, preds=torch.stack(preds), uncs=torch.stack(uncs))
+    # iters = 10 (config 2) and iters = 20 (configs 3-5: 10 / 10 / 20 iterations, 40 predictions) on the SAME inputs; the iters=20 fixtures
+    # keep four times the samples (40 predictions share them)
+    for iters, cap in ((10, MAX_ELEMS), (20, 4 * MAX_ELEMS)):
+        npred = 2 * (iters // 2) + iters
+        ATTN_LOG.clear()
+        preds, uncs = m.forward(img, img, iters=iters, test_mode=False)          # (npred, 1, T, 1, H, W)
+        assert preds.shape[0] == npred and len(ATTN_LOG) == T * npred
+        save(f"cascade_it{iters}", max_elems=cap, predictions=preds[:, 0], uncertainties=uncs[:, 0], disparity=preds[-1], uncertainty=uncs[-1],
+             n_attn_calls=len(ATTN_LOG))
+        T_, h, w = 5, 16, 64
+        d = synth_scale_inputs(T_, h, w, seed=1052, with_mhs=True)
+        cb = rcorr.CorrBlock1D(d["fmap1"], d["fmap2"])
+        preds, uncs = [], []
+        fo, net, mhs = m.forward_update_block(None, m.update_block04, cb, d["flow"], d["net"], d["inp"], d["mhs"], m.att[2], preds, uncs, iters, 1, T_)
+        save(f"fub04_it{iters}", max_elems=min(cap, 2 * MAX_ELEMS), flow_out=fo, net=net, mhs=mhs, preds=torch.stack(preds), uncs=torch.stack(uncs))
 
 
 @torch.no_grad()
