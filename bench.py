@@ -195,7 +195,7 @@ def main():
             e.enable_attn_timing(args.steps * n_it)
             for name, op in e.conv_family_ops().items():          # every convolution-family launch of every scale (roofline_3, timed in
                 family[(sc, name)] = op                            # ONE extra step behind the timed region: ~900 event pairs cost ~5 ms)
-                if getattr(op, "version", 0) in (3, 5):            # the large-map kernels (roofline / roofline_2): inside the timed region
+                if getattr(op, "version", 0) in (3, 5, 8):            # the large-map kernels (roofline / roofline_2): inside the timed region
                     op.events = []
                     conv3[(sc, name)] = op
 
@@ -319,12 +319,15 @@ def main():
                 # channels whose lo plane is known to be zero (ppms_conv.lo_zero_from): its bound is dense bf16 / mfma_per_product, not / 3
                 mpp = op.mfma_per_product()
                 c_bound_ms += len(ms) * op.flops() * mpp / (BF16_DENSE_PEAK_TFLOPS * 1e12) * 1e3
-                per_op[f"1/{sc}:{name}"] = dict(kernel=f"conv{op.version}_kernel", launches=len(ms), avg_ms=round(sum(ms) / len(ms), 4), gflop=round(op.flops() / 1e9, 2),
+                per_op[f"1/{sc}:{name}"] = dict(kernel=f"conv{6 if op.version == 8 else op.version}_kernel", launches=len(ms), avg_ms=round(sum(ms) / len(ms), 4), gflop=round(op.flops() / 1e9, 2),
                                                 tflops=round(op.flops() / (sum(ms) / len(ms) * 1e-3) / 1e12, 1), mfma_per_product=round(mpp, 4))
             if c_n:
                 cach = c_flop / (c_ms * 1e-3) / 1e12
                 cpeak = c_flop / (c_bound_ms * 1e-3) / 1e12           # the launch mix's own bound: dense bf16 / (flop-weighted MFMAs per product), >= 833.3
-                assert c_n == len(conv3_ms) * n_sampled or pipe is not None, (c_n, len(conv3_ms), n_sampled)       # one launch per op and sampled step
+                # every sampled step launches the same list (round 4's line held two steps' launches for one sampled step: 234 = 2 x 117)
+                assert all(len(ms) % n_sampled == 0 for ms in conv3_ms.values()), {k: len(ms) for k, ms in conv3_ms.items()}
+                if (T, H, W, iters) == (5, 320, 512, 10) and not sharded:
+                    assert c_n == 117 * n_sampled, (c_n, n_sampled)       # config 2: 117 large-map conv launches per clip (8 mask-head launches in test_mode)
                 ctraffic = None
                 tfile = _latest_profile("conv_traffic.json")
                 if tfile and (T, H, W) == (5, 320, 512):

@@ -146,6 +146,16 @@ int ppms_conv_gemm5(const ppms_conv* desc, const ppms_conv* dev_desc, int nbt, v
  * epilogue (bit-reproducible).  ppms_conv_gemm5_slices: the slice count that fills the chip in one round, 0 = not applicable. */
 int ppms_conv_gemm5_slices(const ppms_conv* desc);
 int ppms_conv_gemm5_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int nbt, int nslice, void* workspace, void* stream);
+/* Large-map kernel on v_mfma_f32_16x16x32_bf16 (conv_gemm6.hip, round 5): ONE wave per SIMD -- a 4-wave workgroup per CU owns all couts
+ * (M == 256 / 192: 64 / 48 couts x 13 pixel blocks per wave; M == 128: 64 couts x 7 or 6 blocks) of a tile of 16 rows x 13 columns = 13
+ * blocks of 16 pixels: 51 200 pixels = 250 tiles on 256 CUs.  Weights in MFMA-fragment order for 16-cout x 32-channel blocks
+ * (ppmstereo_amd/packing.py pack_conv6, sweep-ordered like pack_conv4), straight from L2 to registers one k32-step ahead; 32-channel
+ * activation windows (64 without spatial taps), column-major, double buffered by LDS-DMA, swept by the taps along x, along y (kh <= 5) or
+ * over all kh x kw taps.  Same descriptor and epilogues as ppms_conv_gemm5 except out_vt; input segments in multiples of 32 channels (64
+ * when kh = kw = 1).  applicable: 0 = not served, 1 = served and the 208-pixel tiles fill >= 85 % of the CU-slots of the launch's rounds,
+ * 2 = served with a poor fill (a caller keeps ppms_conv_gemm5 there). */
+int ppms_conv_gemm6_applicable(const ppms_conv* desc);
+int ppms_conv_gemm6(const ppms_conv* desc, const ppms_conv* dev_desc, void* stream);
 /* Thin GEMM for 1x1 convolutions / Linear layers (gemm1.hip): kt = kh = kw = 1, K = 128 / 192 / 256 / 384 / 512 input channels in one or two
  * 16-channel-aligned segments, M % 32 == 0, weights in the pack_gemm1 layout ([M/32][K/16][hi, lo][lane][8]: the MFMA A-operand image).
  * One workgroup = four waves that split K between them, both operands straight to registers, partial tiles summed through LDS in wave

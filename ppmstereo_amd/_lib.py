@@ -65,6 +65,8 @@ _SIGS = {
     "ppms_conv_stream": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
     "ppms_conv_gemm5_applicable": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm5": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
+    "ppms_conv_gemm6_applicable": (c_int, [C.POINTER(Conv)]),
+    "ppms_conv_gemm6": (c_int, [C.POINTER(Conv), c_void_p, c_void_p]),
     "ppms_conv_gemm5_slices": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm5_sliced": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ppms_struct_sizes": (c_int, [C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),

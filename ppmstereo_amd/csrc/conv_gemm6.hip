@@ -1,0 +1,478 @@
+// Implicit-GEMM convolution for large maps on v_mfma_f32_16x16x32_bf16: ONE wave per SIMD, 16-pixel block granularity (gfx950).
+//
+// Same math, descriptor and epilogues as conv_gemm2/3/5 (bf16x3 split: hi*hi + lo*hi + hi*lo, fp32 accumulate).  What changes against
+// conv_gemm5 (8 waves, 32x32x16 MFMA, 64 x 128 wave tiles, 7 x 32-pixel tiles):
+//   * the MFMA shape: under dense MFMA load on real operands the part holds a ~12 % higher clock on 16x16x32 than on 32x32x16 at equal
+//     cycles per FLOP (tools/probe/mfma_shape_probe.hip, MI355X_MICROARCH.md "DVFS give-back" item 7);
+//   * the tile: 16 rows x 13 columns = 208 pixels (13 blocks of 16: one block = one column of the patch) -> 51 200 pixels = 250 tiles on
+//     256 CUs, 4 % of tile quantisation instead of 10.7 % (240 tiles of 224);
+//   * the wave tile: a 4-wave workgroup, one wave per SIMD, each wave 64 (48) couts x all 13 pixel blocks of the tile (M = 256 / 192), or
+//     64 couts x 7 / 6 blocks (M = 128): 12 MFMAs per pair of LDS fragment reads, 156 per 8 weight-fragment loads -- a third of conv_gemm5's
+//     operand traffic per MFMA -- with the accumulators (208 registers) in the AGPR half of the 512-register file;
+//   * 32-channel activation windows (one k32-step per tap): LDS rows of 128 B [hi k0-31 | lo k0-31], 16-B chunk c stored at position
+//     c ^ (wy & 6) (wy = row inside the window column): the fragment reads are conflict-free for every tap offset.
+// Window = halo'd patch stored COLUMN-major (row = wx * WH + wy), gathered by LDS-DMA with per-lane source addresses (zero page for padding),
+// double buffered, one barrier per window; the taps sweep the window from LDS.  Without a spatial sweep (kh = kw = 1: the temporal GRU pass,
+// 1x1 heads) a window holds TWO 32-channel chunks of the tile, one behind the other, and the "sweep" steps through them.
+// Weights: pack_conv6 (ppmstereo_amd/packing.py): [k32-step][M/16][hi, lo][lane = 16 kg + r][8] = the MFMA A-operand images.
+#include "common.h"
+#include "conv_epilogue.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int NT6 = 256;
+constexpr int MAXP6 = 14;                     // LDS-DMA pieces (16 B) per thread and window
+constexpr int NBT6 = 13;                      // 16-pixel blocks (columns) per tile
+constexpr int STG6_ROWS = 7 * 16;             // pixels a wave stages per epilogue pass
+
+__device__ __attribute__((aligned(256))) unsigned int g_zero_page6[64];     // zero-initialised: source of padded rows
+
+struct Geo6 {
+    int tiles_x, tiles_y;
+    int WH, WC;              // window column height (16 + y halo; even) and columns (13 + x halo); GEMM mode: 16 x 26 (two 13-column chunks)
+    int hxl, hyl;            // halo on the left / above
+    int mode;                // 0: x sweep, 1: y sweep, 2: 2-D sweep, 3: GEMM (no spatial taps)
+    int nsweep;              // k32-steps per window
+    int swx_n, inc, jump;    // the LDS row offset of the tap advances by inc per step and by jump more after every swx_n steps
+    int yinc, ywrap;         // the tap's y offset (the swizzle phase of the fragment reads): += yinc per step, += 1 and back to ... see kernel
+    int nchunk, n0;          // windows per temporal tap (all segments), windows of segment 0
+    int cpw;                 // input channels per window: 32, GEMM mode 64
+    int lz0;                 // windows whose index inside the tap is >= lz0 hold bf16-exact activations (all-zero lo plane): hi x lo products skipped
+    int npieces;             // DMA pieces per thread and window
+    int wbytes;              // bytes of one window buffer (npieces * 4 KiB)
+    int64_t P;
+#ifdef PPMS_CONV6_TIMING
+    long long* dbg;
+#endif
+};
+
+#ifdef PPMS_CONV6_TIMING
+static long long* g_conv6_dbg = nullptr;
+#define CONV6_STAMP(K)                                                                    \
+    if (g.dbg != nullptr && (__builtin_amdgcn_readfirstlane(threadIdx.x) & 255) == 0)     \
+        g.dbg[(int64_t)blockIdx.x * 8 + (K)] = wall_clock64();
+#else
+#define CONV6_STAMP(K)
+#endif
+
+__device__ __forceinline__ void dma16_6(const void* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const PPMS_GLOBAL void*)(uintptr_t)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void vm_wait6(int n) {
+#define PPMS_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n) {
+        PPMS_VMW(1) PPMS_VMW(2) PPMS_VMW(3) PPMS_VMW(4) PPMS_VMW(5) PPMS_VMW(6) PPMS_VMW(7) PPMS_VMW(8) PPMS_VMW(9) PPMS_VMW(10) PPMS_VMW(11)
+        PPMS_VMW(12) PPMS_VMW(13) PPMS_VMW(14)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef PPMS_VMW
+}
+
+#include "conv6_asm.h"
+
+// MB: 16-cout blocks per wave -- 4 (M = 256, 128) or 3 (M = 192)
+template <int MB>
+__global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const Geo6 g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ppms_conv& p = pv;                       // by value in the kernel arguments (see conv_gemm2.hip)
+    CONV6_STAMP(0)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, lkg = lane >> 4;                    // fragment roles: pixel (cout) of the block, k-group of 8 channels
+    // wave roles: M = 256 / 192: wave w owns cout blocks [w MB, w MB + MB) and all 13 pixel blocks; M = 128: (wm, wn) = (w & 1, w >> 1), 64 couts x
+    // pixel blocks [0, 7) or [7, 13)
+    const bool split = p.M == 128;
+    const int wm = split ? (wave & 1) : wave;
+    const int wn = split ? (wave >> 1) : 0;
+    const int nbw = split ? (wn ? 6 : 7) : NBT6;
+    const int blk0 = wn ? 7 : 0;
+    int tile = blockIdx.x;
+    const int tx = tile % g.tiles_x;
+    tile /= g.tiles_x;
+    const int ty = tile % g.tiles_y;
+    const int tf = tile / g.tiles_y;
+    const int x0 = tx * NBT6, y0 = ty * 16;
+    const int H = p.H, W = p.W, T = p.T;
+    const int HW = H * W;
+    const int ht = p.kt >> 1;
+
+    // prefetch for window w + 1 goes out in the first step of window w (the other buffer was released by the barrier that ended window w - 1)
+    // ---- window slots: LDS piece q = tid + i * 256 (lane-linear destination); row = q >> 3, position q & 7 --------------------------------
+    // one register per slot: pixel index (< 2^22) | 16-B unit inside the pixel's 32 (64) channels << 22 | plane << 25; ~0: padding (zero page)
+    unsigned sl[MAXP6];
+    {
+        const int rows = g.WH * g.WC;
+#pragma unroll
+        for (int i = 0; i < MAXP6; ++i) {
+            const int q = tid + i * NT6;
+            const int row = q >> 3, pos = q & 7;
+            sl[i] = ~0u;
+            if (i < g.npieces && row < rows) {
+                int sub = 0, wx, wy;
+                if (g.mode == 3) {
+                    sub = row >= NBT6 * 16 ? 1 : 0;
+                    const int rr = row - sub * NBT6 * 16;
+                    wx = rr >> 4, wy = rr & 15;
+                } else {
+                    wx = row / g.WH, wy = row - wx * g.WH;
+                }
+                const int x = x0 + wx - g.hxl, y = y0 + wy - g.hyl;
+                const int c = pos ^ (wy & 6);                    // the 16-B chunk of the row this position holds: plane * 4 + k-group
+                if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H)
+                    sl[i] = (unsigned)((tf * H + y) * W + x) | ((unsigned)((c & 3) + 4 * sub) << 22) | ((unsigned)(c >> 2) << 25);
+            }
+        }
+    }
+    // every descriptor field the loop needs, fetched once
+    const char* const sp0h = (const char*)p.seg[0].hi;
+    const char* const sp0l = (const char*)p.seg[0].lo;
+    const char* const sp1h = (const char*)p.seg[p.nseg - 1].hi;
+    const char* const sp1l = (const char*)p.seg[p.nseg - 1].lo;
+    const int ld0 = p.seg[0].ld * 2, ld1 = p.seg[p.nseg - 1].ld * 2;          // bytes between pixels
+    const char* zpage = (const char*)g_zero_page6;
+    asm volatile("" : "+s"(zpage));
+    char* const wave_dst = smem + wave * 1024;
+    // one DMA piece of window `win` (= temporal tap * nchunk + chunk) into buffer `buf`
+    int d_win = 0, d_buf = 0;
+    const char *d_hi = nullptr, *d_lo = nullptr;
+    int d_ld = 0;
+    auto dma_setup = [&](int win, int buf) {
+        const int kz = win / g.nchunk, chunk = win - kz * g.nchunk;
+        const int dt = kz - ht;
+        const int sg = (chunk >= g.n0) ? 1 : 0;
+        const int c0 = (chunk - (sg ? g.n0 : 0)) * g.cpw * 2;                  // byte offset of the window's first channel
+        const int64_t shift = (int64_t)dt * HW * (sg ? ld1 : ld0) + c0;
+        d_hi = (sg ? sp1h : sp0h) + shift;
+        d_lo = (sg ? sp1l : sp0l) + shift;
+        d_ld = sg ? ld1 : ld0;
+        d_win = win, d_buf = buf;
+    };
+    auto dma_piece = [&](int i) {
+        const unsigned s = sl[i];
+        const unsigned pix = s & 0x3fffffu, unit = (s >> 22) & 7u;
+        const char* b = (s & (1u << 25)) ? d_lo : d_hi;
+        const char* src = (s != ~0u) ? b + (uint64_t)pix * (unsigned)d_ld + unit * 16 : zpage;
+        dma16_6(src, wave_dst + d_buf * g.wbytes + i * (NT6 * 16));
+    };
+
+    // ---- weights: [k32-step][M/16][plane][64 lanes][16 B]; this wave's 2 MB fragments are contiguous ----------------------------------------
+    const char* abase = (const char*)p.w;
+    const unsigned avoff0 = (unsigned)(wm * MB * 2048 + lane * 16), avoff1 = avoff0 + 4096;
+    const int64_t astep = (int64_t)(p.M >> 4) * 2048;
+    u32x4 areg[2][8];
+    auto load_a = [&](u32x4 (&st)[8], int ks) {
+        const char* sb = abase + (int64_t)ks * astep;
+#define CONV6_LA(K, OFFV, IMM) if ((K) < 2 * MB) asm volatile("global_load_dwordx4 %0, %1, %2 offset:" #IMM : "+v"(st[K]) : "v"(OFFV), "s"(sb) : "memory");
+        CONV6_LA(0, avoff0, 0) CONV6_LA(1, avoff0, 1024) CONV6_LA(2, avoff0, 2048) CONV6_LA(3, avoff0, 3072)
+        CONV6_LA(4, avoff1, 0) CONV6_LA(5, avoff1, 1024) CONV6_LA(6, avoff1, 2048) CONV6_LA(7, avoff1, 3072)
+#undef CONV6_LA
+    };
+
+    // ---- B-operand addressing: row = (blk0 + n) * WH' + tap offset + li; chunk position (plane * 4 + lkg) ^ ((li + tap y) & 6) ---------------
+    const int colrows = g.mode == 3 ? 16 : g.WH;
+    unsigned coff[13];
+#pragma unroll
+    for (int n = 0; n < 13; ++n) coff[n] = (unsigned)((blk0 + n) * colrows * 128);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    auto lane_addr = [&](int tyo) { return lds0 + (unsigned)(li * 128) + (unsigned)(((lkg ^ ((li + tyo) & 6)) & 7) << 4); };
+
+    // temporal taps outside the readable frames contribute zeros: skip them (contiguous kz range)
+    const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
+    const int kz1 = (ht + T + p.t_halo - 1 - tf) < (p.kt - 1) ? (ht + T + p.t_halo - 1 - tf) : (p.kt - 1);
+    const int win0 = kz0 * g.nchunk;
+    const int nwin = (kz1 + 1 - kz0) * g.nchunk;
+    const int nsteps = nwin * g.nsweep;
+
+    f32x4 acc[4][13];
+    u32x4 ring[4][2];
+
+#define CONV6_STEP(U, NBW, JJ)                                                                                                     \
+    {                                                                                                                              \
+        const int jj = (JJ);                                                                                                       \
+        const bool last = jj + 1 >= nsteps;                                                                                        \
+        /* tap state of the NEXT step */                                                                                           \
+        int n_sw = sw + 1, n_swx = swx + 1, n_off = off + g.inc, n_ty = tyo + g.yinc, n_w = w;                                      \
+        if (n_swx == g.swx_n) n_swx = 0, n_off += g.jump, n_ty += g.ywrap;                                                          \
+        const bool wend = n_sw == g.nsweep;                                                                                        \
+        if (wend) n_sw = 0, n_swx = 0, n_off = 0, n_ty = 0, n_w = w + 1;                                                            \
+        if (last) n_off = off, n_ty = tyo, n_w = w;                                                                                \
+        const unsigned cur_off = (unsigned)((w & 1) * g.wbytes + off * 128), nxt_off = (unsigned)((n_w & 1) * g.wbytes + n_off * 128); \
+        const unsigned lh = lane_addr(tyo), lhn = lane_addr(n_ty);                                                                  \
+        /* 1: this window's lo plane is all zero (shift, not ?: -- a select lands in a VGPR, and the asm wants a scalar register) */  \
+        const int lz = __builtin_amdgcn_readfirstlane((int)((unsigned)(g.lz0 - 1 - wchunk) >> 31));                                 \
+        const bool issue = sw == 0 && w + 1 < nwin; /* this step carries the DMA of the next window (into the other buffer) */     \
+        if (issue) dma_setup(win0 + w + 1, (w + 1) & 1);                                                                           \
+        const char* sbn = abase + (int64_t)(win0 * g.nsweep + (last ? jj : jj + 1)) * astep;                                        \
+        conv6_step<MB, NBW>(acc, areg[U], areg[(U) ^ 1], ring, lh, lhn, cur_off, nxt_off, coff, avoff0, avoff1, sbn, lz, [&](int h) { \
+            if (issue) {                                                                                                           \
+                _Pragma("unroll") for (int i = 0; i < MAXP6; ++i)                                                                   \
+                    if (i % conv6_shape<MB, NBW>::HOOKS == h && i < g.npieces) dma_piece(i);                                        \
+            }                                                                                                                      \
+        });                                                                                                                        \
+        sw = n_sw, swx = n_swx, off = n_off, tyo = n_ty;                                                                            \
+        if (wend && !last) {                                                                                                       \
+            /* window switch: everything this wave issued has landed (the next window's pieces are older than this step's weight  */ \
+            /* loads), every wave is done reading the old window                                                                  */ \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
+            __builtin_amdgcn_s_barrier();                                                                                          \
+            w = n_w;                                                                                                               \
+            if (++wchunk == g.nchunk) wchunk = 0;                                                                                  \
+            conv6_prime<NBW>(ring, lhn, nxt_off, coff);                                                                             \
+        } else {                                                                                                                   \
+            vm_wait6(issue ? g.npieces : 0);                                                                                       \
+        }                                                                                                                          \
+    }
+#define CONV6_LOOP(NBW)                                                                                                            \
+    {                                                                                                                              \
+        _Pragma("unroll") for (int a = 0; a < MB; ++a) _Pragma("unroll") for (int b = 0; b < (NBW); ++b) {                          \
+            acc[a][b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                                                            \
+            asm volatile("" : "+a"(acc[a][b]));                                                                                     \
+        }                                                                                                                          \
+        dma_setup(win0, 0);                                                                                                        \
+        _Pragma("unroll") for (int i = 0; i < MAXP6; ++i) if (i < g.npieces) dma_piece(i);                                          \
+        load_a(areg[0], win0 * g.nsweep);                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                              \
+        int sw = 0, swx = 0, off = 0, tyo = 0, w = 0;                                                                               \
+        int wchunk = 0; /* index of the current window inside its temporal tap (win0 is a multiple of nchunk) */                   \
+        conv6_prime<NBW>(ring, lane_addr(0), 0u, coff);                                                                             \
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); /* the zeroed accumulators are AGPR writes: wait states in front of the first MFMA */ \
+        int j = 0;                                                                                                                 \
+        for (; j + 1 < nsteps; j += 2) {                                                                                           \
+            CONV6_STEP(0, NBW, j)                                                                                                  \
+            CONV6_STEP(1, NBW, j + 1)                                                                                              \
+        }                                                                                                                          \
+        if (j < nsteps) CONV6_STEP(0, NBW, j)                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");                                        \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(areg[0][k]), "v"(areg[1][k]));                          \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(ring[k][0]), "v"(ring[k][1]));                          \
+    }
+    CONV6_STAMP(1)
+    if (nbw == NBT6) CONV6_LOOP(13)
+    else if constexpr (MB == 4) {                  // (M = 128: the two pixel halves of the tile)
+        if (nbw == 7) CONV6_LOOP(7) else CONV6_LOOP(6)
+    }
+    CONV6_STAMP(2)
+#undef CONV6_LOOP
+#undef CONV6_STEP
+    __syncthreads();                               // the window buffers become the epilogue's staging areas
+
+    // ---- epilogue: accumulators (lane: pixel li, couts 16 m + 4 lkg ..) -> wave-private LDS patch [pixel][16 MB couts] -> 8 couts of one
+    // pixel per lane, the shared row epilogue (conv_epilogue.h).  Two passes of <= 7 pixel blocks.
+    constexpr int LD6 = 16 * MB + 4;
+    float* stg = (float*)smem + wave * (STG6_ROWS * LD6);
+    const int c_lo = wm * 16 * MB;                                     // first cout of this wave
+    const int q = lane & 7;                                            // cout group of 8 inside the wave's couts (MB = 3: groups 0..5)
+    const bool qok = q < 2 * MB;
+    const int cout = c_lo + q * 8;
+    const int lane_half = (cout >= p.m_split) ? 1 : 0;
+    float b8[8];
+    {
+        const float* bp = p.bias + (qok ? cout : c_lo);
+        const f32x4 b0 = gld<f32x4>(bp), b1 = gld<f32x4>(bp + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            b8[j] = b0[j];
+            b8[4 + j] = b1[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(b8[j]));       // landed before the row loops (vmcnt counts loads and stores in one order)
+    }
+    auto do_pass = [&](auto pass_tag) {
+        constexpr int pass = decltype(pass_tag)::value;
+        constexpr int pb0 = pass * 7;                                   // first block (wave-local) of the pass
+        const int npb = (nbw - pb0) < 7 ? (nbw - pb0) : 7;              // blocks in this pass (<= 0: none)
+        if (npb > 0) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int nl = 0; nl < 7; ++nl) {
+            if (pb0 + nl < 13 && nl < npb) {
+#pragma unroll
+                for (int m = 0; m < MB; ++m) *(f32x4*)(stg + (nl * 16 + li) * LD6 + m * 16 + 4 * lkg) = acc[m][pb0 + nl < 13 ? pb0 + nl : 0];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nit = npb * 2;                                        // 8 pixels per iteration
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            // the wave's couts that fall into this half of the descriptor (M = 192: wave 2 straddles m_split = 128)
+            const int h_lo = hlf ? p.m_split : 0, h_hi = hlf ? p.M : p.m_split;
+            if (c_lo + 16 * MB <= h_lo || c_lo >= h_hi) continue;
+            const ppms_epilogue e = p.epi[hlf];                         // BY VALUE (SGPRs)
+            const int cl = cout - h_lo;
+            const bool mine = qok && lane_half == hlf;
+            auto rows = [&](auto cls_tag, auto grp_tag) {
+                constexpr int CLS = decltype(cls_tag)::value, G = decltype(grp_tag)::value;
+#pragma unroll 1
+                for (int it0 = 0; it0 < nit; it0 += G) {
+                    row8_aux aux[G];
+                    int64_t pixg[G];
+                    bool okg[G];
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi) {
+                        const int prow = (it0 + gi) * 8 + (lane >> 3);
+                        const int px = x0 + blk0 + pb0 + (prow >> 4), py = y0 + (prow & 15);
+                        okg[gi] = mine && it0 + gi < nit && px < W && py < H;
+                        pixg[gi] = (int64_t)(tf * H + py) * W + px;
+                        if (okg[gi]) row8_fetch<CLS>(e, pixg[gi], cl, aux[gi]);
+                    }
+#pragma unroll
+                    for (int gi = 0; gi < G; ++gi) {
+                        float v[8];
+                        const int prow = (it0 + gi) * 8 + (lane >> 3);
+                        const float* sp = stg + (prow < STG6_ROWS ? prow : 0) * LD6 + (qok ? q : 0) * 8;
+                        const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v[j] = a[j] + b8[j];
+                            v[4 + j] = b[j] + b8[4 + j];
+                        }
+                        if (okg[gi]) row8_finish<CLS>(e, v, pixg[gi], cl, HW, aux[gi]);
+                    }
+                }
+            };
+            using I0 = std::integral_constant<int, EPI_CLS_PLAIN>;
+            using I1 = std::integral_constant<int, EPI_CLS_PRE>;
+            using I2 = std::integral_constant<int, EPI_CLS_AUX>;
+            using I3 = std::integral_constant<int, EPI_CLS_GRU>;
+            using I4 = std::integral_constant<int, EPI_CLS_ANY>;
+            using I5 = std::integral_constant<int, EPI_CLS_AUXPRE>;
+            using G1 = std::integral_constant<int, 1>;
+            using G2 = std::integral_constant<int, 2>;
+            const int cls = epilogue_class(e);
+            if (cls == EPI_CLS_PLAIN) rows(I0{}, G2{});
+            else if (cls == EPI_CLS_PRE) rows(I1{}, G2{});
+            else if (cls == EPI_CLS_AUX) rows(I2{}, G2{});
+            else if (cls == EPI_CLS_GRU) rows(I3{}, G2{});
+            else if (cls == EPI_CLS_AUXPRE) rows(I5{}, G2{});
+            else rows(I4{}, G1{});
+        }
+        }
+    };
+    do_pass(std::integral_constant<int, 0>{});
+    do_pass(std::integral_constant<int, 1>{});
+    CONV6_STAMP(3)
+}
+
+// window geometry for a descriptor; false when this kernel does not serve it
+static bool plan6(const ppms_conv* d, Geo6& g) {
+    const bool gemm = d->kw == 1 && d->kh == 1;
+    g.mode = gemm ? 3 : (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);
+    const int hx = (g.mode == 0 || g.mode == 2) ? d->kw - 1 : 0, hy = (g.mode == 1 || g.mode == 2) ? d->kh - 1 : 0;
+    g.cpw = gemm ? 64 : 32;
+    int nchunk = 0;
+    for (int s = 0; s < d->nseg; ++s) {
+        if (d->seg[s].c <= 0 || d->seg[s].c % g.cpw) return false;
+        nchunk += d->seg[s].c / g.cpw;
+    }
+    g.nchunk = nchunk;
+    g.n0 = d->seg[0].c / g.cpw;
+    g.lz0 = (d->lo_zero_from > 0 && d->lo_zero_from % g.cpw == 0) ? d->lo_zero_from / g.cpw : nchunk;
+    g.tiles_x = (d->W + NBT6 - 1) / NBT6;
+    g.tiles_y = (d->H + 15) / 16;
+    g.WH = 16 + hy;
+    g.WC = gemm ? 2 * NBT6 : NBT6 + hx;
+    g.hxl = hx >> 1;
+    g.hyl = hy >> 1;
+    g.yinc = 0, g.ywrap = 0;
+    if (g.mode == 3) {
+        g.nsweep = 2, g.swx_n = 1 << 30, g.inc = NBT6 * 16, g.jump = 0;
+    } else if (g.mode == 0) {
+        g.nsweep = d->kw, g.swx_n = 1 << 30, g.inc = g.WH, g.jump = 0;
+    } else if (g.mode == 1) {
+        g.nsweep = d->kh, g.swx_n = 1 << 30, g.inc = 1, g.jump = 0, g.yinc = 1;
+    } else {
+        g.nsweep = d->kh * d->kw, g.swx_n = d->kw, g.inc = g.WH, g.jump = 1 - d->kw * g.WH, g.ywrap = 1;
+    }
+    const int rows = g.WH * g.WC;
+    g.npieces = (rows * 8 + NT6 - 1) / NT6;
+    g.wbytes = g.npieces * NT6 * 16;
+    g.P = (int64_t)d->T * d->H * d->W;
+    return g.npieces <= MAXP6 && g.nsweep >= 2;
+}
+
+static bool conv6_volume_fits(const ppms_conv* d) { return (int64_t)d->T * d->H * d->W < (1ll << 22); }
+
+static size_t conv6_lds(const ppms_conv* d, const Geo6& g) {
+    size_t lds = (size_t)2 * g.wbytes;
+    const size_t stg = (size_t)4 * STG6_ROWS * ((d->M == 192 ? 48 : 64) + 4) * 4;
+    return lds < stg ? stg : lds;
+}
+
+}  // namespace
+
+// 0: not served.  1: served, and the 208-pixel tiles fill the chip at least as well as conv_gemm5's 224- / 256-pixel tiles would (>= 85 % of the
+// CU-slots of the launch's rounds carry pixels).  2: served, but the fill is poor (the caller keeps conv_gemm5 there).
+extern "C" int ppms_conv_gemm6_applicable(const ppms_conv* d) {
+    if (d == nullptr || (d->M != 256 && d->M != 192 && d->M != 128) || d->nseg < 1 || d->nseg > 2) return 0;
+    if (d->m_split % 8 != 0 || !conv6_volume_fits(d)) return 0;
+    if (!(d->kt & 1) || !(d->kh & 1) || !(d->kw & 1)) return 0;
+    if (d->kw > 1 && d->kh > 1 && d->kh > 5) return 0;
+    if (d->kw > 15 || d->kh > 5) return 0;
+    for (int h = 0; h < 2; ++h) {
+        if (h == 1 && d->m_split >= d->M) break;
+        if (d->epi[h].out_vt != nullptr) return 0;                       // V^T is written from the accumulator layout: conv_gemm5 / gemm1
+    }
+    Geo6 g;
+    if (!plan6(d, g)) return 0;
+    if (conv6_lds(d, g) > 160 * 1024) return 0;
+    const int64_t tiles = (int64_t)g.tiles_x * g.tiles_y * d->T;
+    const int64_t cus = ppms_num_cus();
+    if (tiles < cus * 25 / 32) return 0;                                 // fewer workgroups than CUs: the K-sliced small-map kernels fill the chip better
+    const double fill = (double)g.P / ((double)((tiles + cus - 1) / cus) * cus * 16 * NBT6);
+    return fill >= 0.85 ? 1 : 2;
+}
+
+#ifdef PPMS_CONV6_TIMING
+extern "C" void ppms_debug_conv6_timing(long long* p) { g_conv6_dbg = p; }
+#endif
+
+extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, void* stream) {
+    PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm6: null descriptor");
+    PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm6: nseg=%d", d->nseg);
+    PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm6: bad volume %dx%dx%d", d->T, d->H, d->W);
+    PPMS_REQUIRE((d->M == 256 || d->M == 192 || d->M == 128) && d->m_split % 8 == 0, "conv_gemm6: M=%d must be 128, 192 or 256 (m_split a multiple of 8)", d->M);
+    PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15 && d->kh <= 5, "conv_gemm6: odd kernel extents, kw <= 15, kh <= 5");
+    PPMS_REQUIRE(d->w != nullptr && d->bias != nullptr, "conv_gemm6: weights/bias missing");
+    PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm6: t_halo=%d", d->t_halo);
+    PPMS_REQUIRE(conv6_volume_fits(d), "conv_gemm6: volume too large for the packed window slots (< 2^22 pixels)");
+    for (int s = 0; s < d->nseg; ++s) {
+        PPMS_REQUIRE(d->seg[s].hi && d->seg[s].lo && d->seg[s].c > 0 && d->seg[s].ld % 8 == 0 && d->seg[s].ld <= 1024,
+                     "conv_gemm6: segment %d needs hi/lo planes, ld %% 8 == 0 and ld <= 1024", s);
+        PPMS_REQUIRE(((uintptr_t)d->seg[s].hi & 15) == 0 && ((uintptr_t)d->seg[s].lo & 15) == 0, "conv_gemm6: segment %d not 16-B aligned", s);
+    }
+    for (int hlf = 0; hlf < 2; ++hlf) {
+        const ppms_epilogue& e = d->epi[hlf];
+        if (hlf == 1 && d->m_split >= d->M) break;
+        PPMS_REQUIRE(e.n_valid > 0, "conv_gemm6: epilogue %d has n_valid=%d", hlf, e.n_valid);
+        PPMS_REQUIRE(e.out_vt == nullptr, "conv_gemm6: no out_vt epilogue (use ppms_conv_gemm5 / ppms_gemm1)");
+        PPMS_REQUIRE(e.pre_f32 == nullptr || (e.n_valid % 4 == 0 && e.pre_f32_ld % 4 == 0), "conv_gemm6: pre_f32 needs n_valid and pre_f32_ld to be multiples of 4");
+        {
+            const char* why = epilogue_row8_check(e);
+            PPMS_REQUIRE(why == nullptr, "conv_gemm6: epilogue %d: %s", hlf, why ? why : "");
+        }
+        if (e.out_sp.hi) PPMS_REQUIRE(e.out_sp.lo && e.out_sp.ld % 4 == 0, "conv_gemm6: epilogue %d SP output misaligned", hlf);
+        if (e.kind == PPMS_EPI_RESID || e.kind == PPMS_EPI_RH || e.kind == PPMS_EPI_GRU)
+            PPMS_REQUIRE(e.aux_sp.hi && e.aux_sp.lo && e.aux_sp.ld % 4 == 0, "conv_gemm6: epilogue %d needs aux_sp", hlf);
+        if (e.kind == PPMS_EPI_GRU) PPMS_REQUIRE(e.aux_f32 != nullptr, "conv_gemm6: GRU epilogue needs z");
+    }
+    Geo6 g;
+    PPMS_REQUIRE(plan6(d, g), "conv_gemm6: not a convolution this kernel serves (segments in multiples of 32 channels -- 64 without spatial taps --, "
+                              "a halo'd 16 x 13 window of <= 14 DMA pieces per thread)");
+    const size_t lds = conv6_lds(d, g);
+    PPMS_REQUIRE(lds <= 160 * 1024, "conv_gemm6: LDS budget exceeded (%zu B)", lds);
+    const int ntiles = g.tiles_x * g.tiles_y * d->T;
+    static ppms_device_once once;
+    once.run([] {
+        (void)hipFuncSetAttribute((const void*)conv6_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+#ifdef PPMS_CONV6_TIMING
+    g.dbg = g_conv6_dbg;
+#endif
+    if (d->M == 192) hipLaunchKernelGGL(conv6_kernel<3>, dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+    else hipLaunchKernelGGL(conv6_kernel<4>, dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+    return ppms_check_launch("conv_gemm6");
+}

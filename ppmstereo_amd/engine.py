@@ -34,6 +34,7 @@ TOP_K = 5
 # reads no environment variable.  Every setting runs HIP kernels only.
 TUNING = dict(
     conv5=True,           # one 8-wave workgroup per CU, 7- / 8-block tiles (conv_gemm5.hip) where it applies
+    conv6=True,           # one wave per SIMD on the 16x16x32 MFMA, 16 x 13-pixel tiles (conv_gemm6.hip, round 5) where the library rates its fill >= 85 %
     conv5_sliced=False,   # its K-sliced form on the 1/8, 1/16 maps: correct (tests) but slower than conv_gemm2's slicing there
     conv5_gemm=True,      # its GEMM mode for the 256-cout convs without a spatial sweep ((5,1,1) GRU pass, 1x1 heads)
     conv3=True,           # large-map kernel of round 1 (conv_gemm3.hip) where conv_gemm5 does not apply
@@ -115,13 +116,13 @@ class ConvOp:
         return 2.0 * d.T * d.H * d.W * cout * cin * d.kt * d.kh * d.kw
 
     def mfma_per_product(self) -> float:
-        """MFMAs the kernel issues per algorithmic bf16x3 product: 3 (hi*hi, lo*hi, hi*lo), less the hi*lo products conv_gemm5 leaves out for the
+        """MFMAs the kernel issues per algorithmic bf16x3 product: 3 (hi*hi, lo*hi, hi*lo), less the hi*lo products conv_gemm5 / conv_gemm6 leave out for the
         input channels from `lo_zero_from` on (bf16-exact activations: their lo plane is all zero).  bench.py prices a launch against
         dense bf16 / this."""
         d = self.desc
         cin = sum(d.seg[i].c for i in range(d.nseg))
         lz = int(d.lo_zero_from)
-        if self.version != 5 or lz <= 0 or lz >= cin or lz % 16:
+        if self.version not in (5, 8) or lz <= 0 or lz >= cin or lz % (16 if self.version == 5 else 32):
             return 3.0
         return 3.0 - (cin - lz) / cin
 
@@ -141,6 +142,8 @@ class ConvOp:
             L.check(L.load().ppms_conv_gemm5_sliced(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, self.nslice, self.ws.data_ptr(), L.stream_ptr()))
         elif self.version == 5:
             L.check(L.load().ppms_conv_gemm5(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
+        elif self.version == 8:
+            L.check(L.load().ppms_conv_gemm6(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
         elif self.version == 6:
             L.check(L.load().ppms_gemm1(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
         elif self.version == 7:
@@ -231,6 +234,7 @@ class PackedBlock:
         self.w: Dict[str, tuple] = {}
 
         self.w4: Dict[str, tuple] = {}             # conv_gemm5 packs (MFMA-fragment order, sweep-ordered taps, M padded to 128)
+        self.w6: Dict[str, tuple] = {}             # conv_gemm6 packs (16-cout x 32-channel MFMA A-operand images, sweep-ordered taps)
         self.w1: Dict[str, tuple] = {}             # gemm1 packs of the 1x1 convolutions (MFMA A-operand images per 32 couts x 16 channels)
         self.w7: Dict[str, tuple] = {}             # conv_stream packs (the same images per tap, natural tap order) for the small maps
 
@@ -256,6 +260,9 @@ class PackedBlock:
                 # final_conv's 190 couts no longer run padded to 256)
                 m5 = 128 if rows <= 128 else (192 if rows <= 192 and TUNING["conv5_m192"] else 256)
                 self.w4[name] = _packing.pack_conv4(sweep, bias, segs, seg_pad, cout_map, m5)
+                pads6 = list(seg_pad) if seg_pad is not None else [((c + 31) // 32) * 32 for c in segs]
+                if TUNING["conv6"] and all(p % 32 == 0 for p in pads6):
+                    self.w6[name] = _packing.pack_conv6(sweep, bias, segs, pads6, cout_map, 128 if rows <= 128 else (192 if rows <= 192 else 256))
             elif TUNING["conv5"] and TUNING["conv5_gemm"] and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith(("_y", "_p")):
                 # no spatial sweep: conv_gemm5's GEMM mode (windows of 64 channels) when the segments come in such multiples.  Only the
                 # 256-cout convs (GRU pass-T z/r 197 -> 164 us, mask_2d.2 62 -> 46 us at the 1/4 scale): with 128 couts the two K-groups
@@ -263,6 +270,12 @@ class PackedBlock:
                 pads = list(seg_pad) if seg_pad is not None else [((c + 31) // 32) * 32 for c in segs]
                 if all(p % 32 == 0 for p in pads):
                     self.w4[name] = _packing.pack_conv4(w5, bias, segs, pads, cout_map, (rows + 127) // 128 * 128)
+
+            if TUNING["conv6"] and w5.shape[3] == 1 and w5.shape[4] == 1 and 64 < rows <= 256 and not name.endswith(("_y", "_p")):
+                # conv_gemm6 without a spatial sweep: windows of 64 channels (two k32-steps), segments in multiples of 64
+                pads6 = list(seg_pad) if seg_pad is not None else [((c + 31) // 32) * 32 for c in segs]
+                if all(p % 64 == 0 for p in pads6):
+                    self.w6[name] = _packing.pack_conv6(w5, bias, segs, pads6, cout_map, 128 if rows <= 128 else (192 if rows <= 192 else 256))
 
         e = "encoder."
         put("init0", g(e + "init_conv.0.weight"), g(e + "init_conv.0.bias"), [128])
@@ -520,7 +533,17 @@ class ScaleEngine:
         return ConvOp(d, [packed, bias, *keep], version, nslice=nslice, device=self.dev)
 
     def _try_fragment_kernels(self, wname: str, d: L.Conv, m_split, keep) -> Optional[ConvOp]:
-        """conv_gemm5 (weights in MFMA-fragment order, pack_conv4, couts padded to 128) when it serves the conv."""
+        """conv_gemm6 (one wave per SIMD, 16x16x32 MFMA, pack_conv6) where the library rates its tile fill, else conv_gemm5 (weights in
+        MFMA-fragment order, pack_conv4, couts padded to 128) when it serves the conv."""
+        if TUNING["conv6"] and wname in self.pk.w6:
+            packed6, bias6, meta6 = self.pk.w6[wname]
+            d6 = L.Conv.from_buffer_copy(bytes(d))
+            d6.w, d6.bias, d6.M = packed6.data_ptr(), bias6.data_ptr(), meta6["M"]
+            if m_split is None:
+                d6.m_split = meta6["M"]
+            real6 = d6.epi[0].n_valid + (d6.epi[1].n_valid if d6.m_split < d6.M else 0)
+            if 2 * real6 > meta6["M"] and self.lib.ppms_conv_gemm6_applicable(C.byref(d6)) == 1:
+                return ConvOp(d6, [packed6, bias6, *keep], 8, device=self.dev)
         if not TUNING["conv5"] or wname not in self.pk.w4:
             return None
         packed4, bias4, meta4 = self.pk.w4[wname]
@@ -541,7 +564,7 @@ class ScaleEngine:
         """wname + "_p" (couts padded to a multiple of 128) when the large-map kernel takes it, else the tight pack."""
         if TUNING["conv5"] and wname in self.pk.w4:
             op = self._conv(wname, *a, **k)
-            if op.version == 5:
+            if op.version in (5, 8):
                 return op
         if TUNING["conv3"] and wname + "_p" in self.pk.w:
             op = self._conv(wname + "_p", *a, **k)

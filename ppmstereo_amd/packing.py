@@ -114,6 +114,58 @@ def pack_conv4(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
     return packed.reshape(-1), b, meta
 
 
+def pack_conv6(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
+               seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
+               m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+    """Layout of the one-wave-per-SIMD large-map kernel (ppmstereo_amd/csrc/conv_gemm6.hip, v_mfma_f32_16x16x32_bf16): the A-operand images
+    of 16 couts x 32 input channels, so that a wave loads its weight fragments straight from L2 into registers with 1 KiB loads:
+        bf16 [k32-step][M/16][plane (hi, lo)][lane = 16*kg + r][8] = W[cout = 16*blk + r][cin = 32*chunk + 8*kg + j] of tap (row-step, s),
+        k32-step = ((kz*kh + ky) * nchunk32 + chunk) * kw + kx.
+    As for pack_conv4 the LAST kernel axis is the swept one: y-swept convs are passed with kh / kw swapped, 2-D swept ones with (ky, kx)
+    flattened into x; the input segments are concatenated along K, each zero-padded to a multiple of 32 channels."""
+    w = weight.detach().float()
+    if w.dim() == 4:
+        w = w[:, :, None]
+    cout, cin, kt, kh, kw = w.shape
+    assert sum(seg_channels) == cin, (seg_channels, cin)
+    seg_padded = [_pad_to(c, 32) for c in seg_channels] if seg_padded is None else list(seg_padded)
+    assert all(p % 32 == 0 and p >= c for p, c in zip(seg_padded, seg_channels))
+    cpad = sum(seg_padded)
+    nchunk = cpad // 32
+    rows = list(range(cout)) if cout_map is None else list(cout_map)
+    M = _pad_to(max(rows) + 1, 64) if m_pad is None else m_pad
+    assert M % 16 == 0 and max(rows) < M
+    wk = w.permute(0, 2, 3, 4, 1).reshape(cout, kt * kh, kw, cin)              # [cout][trow][kx][ci]
+    full = torch.zeros(M, kt * kh, kw, cpad, dtype=torch.float32, device=w.device)
+    ridx = torch.tensor(rows, device=w.device)
+    src = dst = 0
+    for c, p in zip(seg_channels, seg_padded):
+        full[ridx, :, :, dst:dst + c] = wk[:, :, :, src:src + c]
+        src += c
+        dst += p
+    nk = kt * kh * nchunk * kw
+    # [blk][r][trow][kx][chunk][kg][j] -> [trow][chunk][kx][blk][kg][r][j]
+    t = full.reshape(M // 16, 16, kt * kh, kw, nchunk, 4, 8).permute(2, 4, 3, 0, 5, 1, 6).contiguous()
+    t = t.reshape(nk, M // 16, 64, 8)
+    hi, lo = split_bf16(t)
+    packed = torch.stack([hi, lo], dim=2).contiguous()                    # [ks][blk][plane][lane][8]
+    b = torch.zeros(M, dtype=torch.float32, device=w.device)
+    if bias is not None:
+        b[ridx] = bias.detach().float()
+    meta = dict(M=M, nk=nk, taps=(kt, kh, kw), cpad=cpad, seg_padded=seg_padded, version=8)
+    return packed.reshape(-1), b, meta
+
+
+def unpack_conv6_reference(packed: torch.Tensor, M: int, nk: int, taps, nchunk: int) -> torch.Tensor:
+    """Inverse of pack_conv6 -> fp32 [M][K] in the plain K order (k = tap*Cpad + ci), for the host-logic tests."""
+    kt, kh, kw = taps
+    t = packed.reshape(nk, M // 16, 2, 64, 8).float()                      # [ks][blk][plane][lane][8]
+    t = t[:, :, 0] + t[:, :, 1]                                            # [ks][blk][lane][8]
+    t = t.reshape(kt * kh, nchunk, kw, M // 16, 4, 16, 8)                  # [trow][chunk][kx][blk][kg][r][j]
+    t = t.permute(3, 5, 0, 2, 1, 4, 6)                                     # [blk][r][trow][kx][chunk][kg][j]
+    return t.reshape(M, kt * kh * kw * nchunk * 32)
+
+
 def pack_gemm1(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels: Sequence[int],
                seg_padded: Optional[Sequence[int]] = None, cout_map: Optional[Sequence[int]] = None,
                m_pad: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor, dict]:

@@ -118,8 +118,8 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
     tile_px = 0
     if version in (5, 5007, 5008):                                         # conv_gemm5; 5007 / 5008 force the blocks per tile
         tile_px, version = (0 if version == 5 else version - 5000), 5
-    from ppmstereo_amd.packing import pack_gemm1, pack_stream
-    pack_conv = pack_conv4 if version == 5 else pack_gemm1 if version == 6 else pack_stream if version == 7 else pack_conv2
+    from ppmstereo_amd.packing import pack_conv6, pack_gemm1, pack_stream
+    pack_conv = pack_conv4 if version == 5 else pack_gemm1 if version == 6 else pack_stream if version == 7 else pack_conv6 if version == 8 else pack_conv2
     P = T * H * W
     segs, keep = [], []
     seg_pad = seg_pad or [((x.shape[1] + 31) // 32) * 32 for x in x_list]
@@ -129,9 +129,9 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
         segs.append(t.view())
         keep.append(t)
     wpack = weight
-    if (version in (3, 5) or ysweep) and k3[2] == 1 and k3[1] > 1:       # y-swept kernels: pack with kh / kw swapped
+    if (version in (3, 5, 8) or ysweep) and k3[2] == 1 and k3[1] > 1:       # y-swept kernels: pack with kh / kw swapped
         wpack = (weight if weight.dim() == 5 else weight[:, :, None]).transpose(3, 4).contiguous()
-    if (version in (3, 5) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
+    if (version in (3, 5, 8) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
         w5 = weight if weight.dim() == 5 else weight[:, :, None]
         wpack = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, k3[1] * k3[2]).contiguous()
     packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad,
@@ -614,6 +614,166 @@ def test_conv_gemm5_full_map(lib):
         ref = _ref_conv(xs, wt, bs, k3, T, H, W)
         got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=5, m_pad=m_pad)
         assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), (segs, k3)
+
+
+CONV6_CASES = [
+    # name, T,H,W, segs, cout, k3 -- x / y / 2-D sweeps, temporal taps, GEMM mode (64-channel windows), two segments, ragged maps and couts, M = 256 and 128
+    ("x15_gru_m256", 2, 20, 40, [128, 256], 256, (1, 1, 15)), ("x5_m128", 2, 12, 128, [128, 256], 128, (1, 1, 5)), ("x5_one_seg_m128", 1, 33, 27, [128], 128, (1, 1, 5)),
+    ("y5_m256", 2, 40, 32, [128, 256], 256, (1, 5, 1)), ("y5_m128_ragged", 1, 37, 29, [64, 32], 100, (1, 5, 1)),
+    ("3x3_m256", 2, 13, 45, [128], 256, (1, 3, 3)), ("3x3_two_segs_m128", 3, 9, 13, [128, 128], 128, (1, 3, 3)), ("3x3x3_m256_T4", 4, 17, 19, [128], 200, (3, 3, 3)),
+    ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3)), ("t5_gemm_m256", 5, 20, 64, [128, 256], 256, (5, 1, 1)), ("t5_gemm_m128", 5, 10, 40, [128, 256], 128, (5, 1, 1)),
+    ("1x1_m256_pad", 2, 13, 45, [256], 144, (1, 1, 1)), ("t3_gemm_m128_T2", 2, 16, 32, [64, 64], 100, (3, 1, 1)), ("x15_w24", 1, 9, 24, [32], 128, (1, 1, 15)),
+    ("T1_tiny", 1, 1, 3, [32], 130, (3, 3, 3)),
+]
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV6_CASES)
+def test_conv_gemm6_vs_torch(lib, name, T, H, W, segs, cout, k3):
+    """conv_gemm6 (round 5): one wave per SIMD on v_mfma_f32_16x16x32_bf16, tiles of 16 rows x 13 columns, 32-channel windows stored column-major
+    (64-channel windows without spatial taps) -- M = 256 (4 waves x 64 couts x 13 pixel blocks) and M = 128 (2 x 64 couts x 7 / 6 blocks) -- vs torch
+    conv3d, bit-reproducible, with the GRU epilogue class."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    gemm = k3[1] == 1 and k3[2] == 1
+    seg_pad = [((c + (63 if gemm else 31)) // (64 if gemm else 32)) * (64 if gemm else 32) for c in segs]
+    m_pad = 128 if cout <= 128 else 256
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=m_pad)
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    assert torch.equal(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=m_pad))
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=m_pad, kind=lib.EPI_GRU, aux=aux, z=z)
+    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", [("3x3_m192_final", 2, 13, 45, [320], 190, (1, 3, 3)), ("3x3_m192_full_blocks", 1, 16, 56, [256], 192, (1, 3, 3)),
+                                                   ("x15_m192", 2, 9, 40, [64, 32], 160, (1, 1, 15)), ("y5_m192", 1, 24, 32, [64], 129, (1, 5, 1)),
+                                                   ("3x3x3_m192_T3", 3, 10, 40, [64], 192, (3, 3, 3)), ("1x1_m192", 2, 13, 45, [256], 144, (1, 1, 1))])
+def test_conv_gemm6_three_cout_blocks_vs_torch(lib, name, T, H, W, segs, cout, k3):
+    """M = 192: four waves x 48 couts (three 16-cout MFMA blocks each) x 13 pixel blocks -- convc2's 192 and final_conv's 190 couts."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    gemm = k3[1] == 1 and k3[2] == 1
+    seg_pad = [((c + (63 if gemm else 31)) // (64 if gemm else 32)) * (64 if gemm else 32) for c in segs]
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=192)
+    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+    assert torch.equal(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=192))
+    assert torch.equal(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=256)), "same bits as the 256-row layout"
+    aux = hash_normal((P, cout), 303)
+    z = torch.sigmoid(hash_normal((P, cout), 304))
+    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, kind=lib.EPI_GRU, aux=aux, z=z, m_pad=192)
+    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
+
+
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3,lz", [
+    ("gru_1x15", 2, 12, 128, [128, 256], 256, (1, 1, 15), 256), ("q_1x5_m128", 2, 12, 128, [128, 256], 128, (1, 1, 5), 256),
+    ("y_1x5x1", 2, 40, 32, [128, 256], 256, (1, 5, 1), 256), ("t_5x1x1_gemm_mode", 5, 16, 64, [128, 256], 256, (5, 1, 1), 256),
+    ("3x3_m192_one_segment", 2, 13, 45, [320], 190, (1, 3, 3), 192)])
+def test_conv_gemm6_skips_products_with_a_zero_lo_plane(lib, name, T, H, W, segs, cout, k3, lz):
+    """ppms_conv.lo_zero_from on conv_gemm6: the hi x lo MFMAs of a block sit behind one scalar branch per block.  Same bits as the full product."""
+    P = T * H * W
+    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    xcat = torch.cat(xs, 1)
+    xcat[:, lz:] = xcat[:, lz:].to(torch.bfloat16).float()                  # bf16-exact from channel lz on
+    xs = list(torch.split(xcat, segs, 1))
+    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+    bs = hash_normal((cout,), 201) * 0.1
+    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+    m_pad = 128 if cout <= 128 else 192 if cout <= 192 else 256
+    full = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, m_pad=m_pad)
+    skip = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, m_pad=m_pad, lo_zero_from=lz)
+    assert torch.equal(full, skip), name
+    assert maxdiff(skip, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
+
+
+@pytest.mark.parametrize("cout", [128, 256, 190])
+def test_conv_gemm6_epilogue_classes(lib, cout):
+    """Every epilogue class of conv_epilogue.h through conv_gemm6's two-pass staging (accumulators of <= 7 pixel blocks -> wave-private LDS patch ->
+    8 couts of a pixel per lane), at 128 / 256 / ragged 190 (M = 192) couts."""
+    L = lib
+    T, H, W, k3 = 2, 12, 64, (1, 3, 3)
+    P = T * H * W
+    xs = [hash_normal((P, 64), 700), hash_normal((P, 32), 701)]
+    wt = hash_normal((cout, 96, *k3), 702) / math.sqrt(96 * 9)
+    bs = hash_normal((cout,), 703) * 0.1
+    lin = _ref_conv(xs, wt, bs, k3, T, H, W)
+    aux, z, pre = hash_normal((P, cout), 704), torch.sigmoid(hash_normal((P, cout), 705)), hash_normal((P, cout), 706)
+    m_pad = 128 if cout <= 128 else 192 if cout <= 192 else 256
+    run = lambda **k: _run_conv(L, xs, wt, bs, k3, T, H, W, version=8, m_pad=m_pad, **k)
+    tol = lambda ref: 5e-5 * max(1.0, ref.abs().max().item())
+    for act, f in ((L.ACT_NONE, lambda t: t), (L.ACT_RELU, F.relu), (L.ACT_GELU, F.gelu), (L.ACT_SIGMOID, torch.sigmoid), (L.ACT_TANH, torch.tanh)):
+        assert maxdiff(run(act=act), f(lin)) < tol(f(lin)), ("plain", act)
+    if cout % 4 == 0:
+        assert maxdiff(run(act=L.ACT_GELU, pre=pre), F.gelu(lin + pre)) < tol(lin), "pre"
+        assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z, pre=pre), (1 - z) * aux + z * torch.tanh(lin + pre)) < tol(lin), "gru + pre"
+        assert maxdiff(run(kind=L.EPI_RH, aux=aux, pre=pre), torch.sigmoid(lin + pre) * aux) < tol(lin), "rh + pre"
+    assert maxdiff(run(kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + lin)) < tol(lin), "resid"
+    assert maxdiff(run(kind=L.EPI_RH, aux=aux), torch.sigmoid(lin) * aux) < tol(lin), "rh"
+    assert maxdiff(run(kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < tol(lin), "gru"
+    assert torch.equal(run(kind=L.EPI_GRU, aux=aux, z=z), run(kind=L.EPI_GRU, aux=aux, z=z))
+
+
+def test_conv_gemm6_full_map_and_rating(lib):
+    """The shapes the 1/4 scale of BASELINE config 2 really runs (5 x 80 x 128 pixels = 250 tiles of 16 x 13): the GRU (1,1,15) conv to 256 couts, a 3x3
+    conv to 256, the q-gate conv to 128 couts, final_conv on the 192-row layout, the temporal pass; the library rates all of them 1 there and 0 on
+    a 1/8-scale map (too few tiles)."""
+    T, H, W = 5, 80, 128
+    P = T * H * W
+    for segs, cout, k3, m_pad in (([128, 256], 256, (1, 1, 15), 256), ([128], 256, (1, 3, 3), 256), ([128, 256], 128, (1, 1, 5), 128),
+                                  ([320], 190, (1, 3, 3), 192), ([128, 256], 256, (5, 1, 1), 256)):
+        xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
+        cin = sum(segs)
+        wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
+        bs = hash_normal((cout,), 201) * 0.1
+        ref = _ref_conv(xs, wt, bs, k3, T, H, W)
+        got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, m_pad=m_pad)
+        assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), (segs, k3)
+    d = lib.Conv()
+    sp = lib.SPTensor(16, 128, DEV)
+    d.seg[0], d.nseg, d.kt, d.kh, d.kw, d.M, d.m_split = sp.view(), 1, 1, 3, 3, 256, 256
+    d.T, d.H, d.W = 5, 80, 128
+    assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 1
+    d.T, d.H, d.W = 5, 40, 64
+    assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 0
+
+
+def test_conv_gemm6_two_epilogue_halves(lib):
+    """m_split: the z | r convs (M = 256, m_split = 128: waves 0-1 / 2-3) and final_conv (M = 192, m_split = 128: wave 2's 48 couts straddle the
+    split, its cout groups take their half's epilogue in two passes)."""
+    from ppmstereo_amd.engine import ConvOp, epilogue
+    from ppmstereo_amd.packing import pack_conv6
+    T, H, W, k3 = 2, 20, 30, (1, 3, 3)
+    P = T * H * W
+    for M, n0, n1 in ((256, 128, 128), (192, 126, 64)):
+        cmap = list(range(n0)) + list(range(128, 128 + n1))
+        x = hash_normal((P, 64), 810)
+        wt = hash_normal((n0 + n1, 64, *k3), 811) / math.sqrt(64 * 9)
+        bs = hash_normal((n0 + n1,), 812) * 0.1
+        ref = _ref_conv([x], wt, bs, k3, T, H, W)
+        xin = lib.SPTensor(P, 64, DEV)
+        xin.set_f32(x.to(DEV))
+        w5 = wt[:, :, None]
+        packed, b, meta = pack_conv6(w5.reshape(n0 + n1, 64, 1, 1, 9).to(DEV), bs.to(DEV), [64], [64], cmap, M)
+        o0, o1 = lib.SPTensor(P, 128, DEV), torch.zeros(P, 64, device=DEV)
+        d = lib.Conv()
+        d.seg[0], d.nseg, d.w, d.bias = xin.view(), 1, packed.data_ptr(), b.data_ptr()
+        d.T, d.H, d.W, d.kt, d.kh, d.kw, d.M, d.m_split = T, H, W, 1, 3, 3, M, 128
+        d.epi[0] = epilogue(act=lib.ACT_RELU, n_valid=n0, out_sp=o0.view())
+        d.epi[1] = epilogue(act=lib.ACT_TANH, n_valid=min(n1, 64), out_f32=o1, out_f32_ld=64)
+        ConvOp(d, [xin, packed, b, o0, o1], 8)()
+        torch.cuda.synchronize()
+        assert maxdiff(o0.to_f32()[:, :n0].cpu(), torch.relu(ref[:, :n0])) < 3e-5 * max(1.0, ref.abs().max().item()), M
+        assert maxdiff(o1[:, :min(n1, 64)].cpu(), torch.tanh(ref[:, n0:n0 + min(n1, 64)])) < 3e-5, M
+        assert (o0.to_f32()[:, n0:] == 0).all()
 
 
 @pytest.mark.parametrize("version", [5, 3, 2])

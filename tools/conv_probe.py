@@ -6,6 +6,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import ab_switches  # noqa: F401,E402  (PPMS_CONV6=0 etc.: A/B of the kernel generations)
 from ppmstereo_amd import weights as Wm
 from ppmstereo_amd.ppmstereo import PPMStereoHotPath
 from ppmstereo_amd.weights import hash_normal
@@ -40,4 +42,4 @@ for name in ops:
     ts = sorted(a.elapsed_time(b) for a, b in ev)
     med = ts[len(ts) // 2]
     fl = flops.get(name, 0) * eng.P
-    print(f"{name:10s} dbg={os.environ.get('PPMS_DBG','0'):>3s} wm={os.environ.get('PPMS_WM','-')} med={med*1e3:8.1f} us  min={ts[0]*1e3:8.1f} us  {fl/med/1e9:7.1f} TFLOP/s(alg)")
+    print(f"{name:10s} v{getattr(op, 'version', '-')} dbg={os.environ.get('PPMS_DBG','0'):>3s} wm={os.environ.get('PPMS_WM','-')} med={med*1e3:8.1f} us  min={ts[0]*1e3:8.1f} us  {fl/med/1e9:7.1f} TFLOP/s(alg)")
