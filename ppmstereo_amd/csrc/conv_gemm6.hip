@@ -23,6 +23,11 @@ namespace {
 
 constexpr int NT6 = 256;
 constexpr int MAXP6 = 14;                     // LDS-DMA pieces (16 B) per thread and window
+// Pieces per thread and window as a COMPILE-TIME constant of the kernel variant (CR = rows of a window column): the loop's vmcnt waits count
+// them, and s_waitcnt takes an immediate (a run-time count through a switch cost a 25-branch decision tree per k-step).  16-row columns
+// (x sweeps up to 15 taps: 27 x 16 rows; two 13-column chunks without spatial taps): 14; 18- / 20-row columns (3x3, (1,5,1), (1,3,1)): 9.
+// A window with fewer rows issues the surplus pieces as reads of the zero page into the buffer's padding.
+__host__ __device__ constexpr int conv6_np(int cr) { return cr == 16 ? 14 : 9; }
 constexpr int NBT6 = 13;                      // 16-pixel blocks (columns) per tile
 constexpr int STG6_ROWS = 7 * 16;             // pixels a wave stages per epilogue pass
 
@@ -39,8 +44,8 @@ struct Geo6 {
     int nchunk, n0;          // windows per temporal tap (all segments), windows of segment 0
     int cpw;                 // input channels per window: 32, GEMM mode 64
     int lz0;                 // windows whose index inside the tap is >= lz0 hold bf16-exact activations (all-zero lo plane): hi x lo products skipped
-    int npieces;             // DMA pieces per thread and window
-    int wbytes;              // bytes of one window buffer (npieces * 4 KiB)
+    int npieces;             // DMA pieces per thread and window that carry rows (<= conv6_np(WH), which is what every window issues)
+    int wbytes;              // bytes of one window buffer (conv6_np(WH) * 4 KiB)
     int64_t P;
 #ifdef PPMS_CONV6_TIMING
     long long* dbg;
@@ -49,32 +54,29 @@ struct Geo6 {
 
 #ifdef PPMS_CONV6_TIMING
 static long long* g_conv6_dbg = nullptr;
+// debug build only (tools/conv6_phase_probe.py): wave 0 of every workgroup leaves [workgroup][K] = wall clock (100 MHz) and [workgroup][8 + K] =
+// shader cycle counter at: 0 entry, 1 loop start, 2 loop end, 3 exit (the clock the part holds in the loop = cycles / wall time)
 #define CONV6_STAMP(K)                                                                    \
-    if (g.dbg != nullptr && (__builtin_amdgcn_readfirstlane(threadIdx.x) & 255) == 0)     \
-        g.dbg[(int64_t)blockIdx.x * 8 + (K)] = wall_clock64();
+    if (g.dbg != nullptr && (__builtin_amdgcn_readfirstlane(threadIdx.x) & 255) == 0) {   \
+        g.dbg[(int64_t)blockIdx.x * 16 + (K)] = wall_clock64();                           \
+        g.dbg[(int64_t)blockIdx.x * 16 + 8 + (K)] = (long long)__builtin_amdgcn_s_memtime(); \
+    }
 #else
 #define CONV6_STAMP(K)
 #endif
 
-__device__ __forceinline__ void dma16_6(const void* src, char* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const PPMS_GLOBAL void*)(uintptr_t)src, (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
-__device__ __forceinline__ void vm_wait6(int n) {
-#define PPMS_VMW(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n) {
-        PPMS_VMW(1) PPMS_VMW(2) PPMS_VMW(3) PPMS_VMW(4) PPMS_VMW(5) PPMS_VMW(6) PPMS_VMW(7) PPMS_VMW(8) PPMS_VMW(9) PPMS_VMW(10) PPMS_VMW(11)
-        PPMS_VMW(12) PPMS_VMW(13) PPMS_VMW(14)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef PPMS_VMW
+// LDS-DMA of 16 B per lane: lane l's bytes land at LDS address m0 + 16 l.  Inline asm on purpose: for the compiler's own LDS-DMA (the
+// __builtin_amdgcn_global_load_lds form) the waitcnt pass puts a wait for that transfer in front of EVERY later inline-asm statement (each has
+// a memory clobber, so each "may read LDS") -- one exposed memory round trip per piece (measured: 70 of 376 us of the z/r conv).  The loop
+// orders these transfers itself (counted vmcnt + barrier at the window switch).
+__device__ __forceinline__ void dma16_6(const void* src, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_dst) : "memory");
 }
 
 #include "conv6_asm.h"
 
-// MB: 16-cout blocks per wave -- 4 (M = 256, 128) or 3 (M = 192)
-template <int MB>
+// MB: 16-cout blocks per wave -- 4 (M = 256, 128) or 3 (M = 192); CR: rows of a window column = 16 + y halo (16, 18, 20)
+template <int MB, int CR>
 __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const Geo6 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ppms_conv& p = pv;                       // by value in the kernel arguments (see conv_gemm2.hip)
@@ -102,15 +104,16 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     // prefetch for window w + 1 goes out in the first step of window w (the other buffer was released by the barrier that ended window w - 1)
     // ---- window slots: LDS piece q = tid + i * 256 (lane-linear destination); row = q >> 3, position q & 7 --------------------------------
     // one register per slot: pixel index (< 2^22) | 16-B unit inside the pixel's 32 (64) channels << 22 | plane << 25; ~0: padding (zero page)
-    unsigned sl[MAXP6];
+    constexpr int NP = conv6_np(CR);
+    unsigned sl[NP];
     {
         const int rows = g.WH * g.WC;
 #pragma unroll
-        for (int i = 0; i < MAXP6; ++i) {
+        for (int i = 0; i < NP; ++i) {
             const int q = tid + i * NT6;
             const int row = q >> 3, pos = q & 7;
             sl[i] = ~0u;
-            if (i < g.npieces && row < rows) {
+            if (row < rows) {
                 int sub = 0, wx, wy;
                 if (g.mode == 3) {
                     sub = row >= NBT6 * 16 ? 1 : 0;
@@ -134,13 +137,13 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     const int ld0 = p.seg[0].ld * 2, ld1 = p.seg[p.nseg - 1].ld * 2;          // bytes between pixels
     const char* zpage = (const char*)g_zero_page6;
     asm volatile("" : "+s"(zpage));
-    char* const wave_dst = smem + wave * 1024;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
+    const unsigned wave_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * 1024));
     // one DMA piece of window `win` (= temporal tap * nchunk + chunk) into buffer `buf`
-    int d_win = 0, d_buf = 0;
+    int d_buf = 0;
     const char *d_hi = nullptr, *d_lo = nullptr;
     int d_ld = 0;
-    auto dma_setup = [&](int win, int buf) {
-        const int kz = win / g.nchunk, chunk = win - kz * g.nchunk;
+    auto dma_setup = [&](int kz, int chunk, int buf) {
         const int dt = kz - ht;
         const int sg = (chunk >= g.n0) ? 1 : 0;
         const int c0 = (chunk - (sg ? g.n0 : 0)) * g.cpw * 2;                  // byte offset of the window's first channel
@@ -148,14 +151,17 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         d_hi = (sg ? sp1h : sp0h) + shift;
         d_lo = (sg ? sp1l : sp0l) + shift;
         d_ld = sg ? ld1 : ld0;
-        d_win = win, d_buf = buf;
+        d_buf = buf;
     };
     auto dma_piece = [&](int i) {
         const unsigned s = sl[i];
-        const unsigned pix = s & 0x3fffffu, unit = (s >> 22) & 7u;
-        const char* b = (s & (1u << 25)) ? d_lo : d_hi;
-        const char* src = (s != ~0u) ? b + (uint64_t)pix * (unsigned)d_ld + unit * 16 : zpage;
-        dma16_6(src, wave_dst + d_buf * g.wbytes + i * (NT6 * 16));
+        const unsigned pix = s & 0x3fffffu, unit16 = (s >> 18) & 0x70u;                  // (unit << 4)
+        // branch-free selects (as a ?: on pointers the compiler builds an exec-masked branch around the address arithmetic of every piece)
+        const uint64_t m_lo = (uint64_t)0 - (uint64_t)((s >> 25) & 1u), m_ok = (uint64_t)0 - (uint64_t)(s != ~0u);
+        const uint64_t b = ((uint64_t)(uintptr_t)d_hi & ~m_lo) | ((uint64_t)(uintptr_t)d_lo & m_lo);
+        const uint64_t a = b + (uint64_t)pix * (unsigned)d_ld + unit16;
+        const uint64_t src = (a & m_ok) | ((uint64_t)(uintptr_t)zpage & ~m_ok);
+        dma16_6((const void*)(uintptr_t)src, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16)));
     };
 
     // ---- weights: [k32-step][M/16][plane][64 lanes][16 B]; this wave's 2 MB fragments are contiguous ----------------------------------------
@@ -171,45 +177,56 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 #undef CONV6_LA
     };
 
-    // ---- B-operand addressing: row = (blk0 + n) * WH' + tap offset + li; chunk position (plane * 4 + lkg) ^ ((li + tap y) & 6) ---------------
-    const int colrows = g.mode == 3 ? 16 : g.WH;
-    unsigned coff[13];
-#pragma unroll
-    for (int n = 0; n < 13; ++n) coff[n] = (unsigned)((blk0 + n) * colrows * 128);
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
-    auto lane_addr = [&](int tyo) { return lds0 + (unsigned)(li * 128) + (unsigned)(((lkg ^ ((li + tyo) & 6)) & 7) << 4); };
+    // ---- B-operand addressing: row = (blk0 + n) * CR + tap offset + li; chunk position (plane * 4 + lkg) ^ ((li + tap y) & 6); the n * CR * 128
+    // part is an immediate of the read, hi and lo fragments differ in bit 6 ---------------------------------------------------------------
+    auto lane_addr = [&](int tyo) { return lds0 + (unsigned)(blk0 * CR * 128 + li * 128) + (unsigned)(((lkg ^ ((li + tyo) & 6)) & 7) << 4); };
 
     // temporal taps outside the readable frames contribute zeros: skip them (contiguous kz range)
     const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
     const int kz1 = (ht + T + p.t_halo - 1 - tf) < (p.kt - 1) ? (ht + T + p.t_halo - 1 - tf) : (p.kt - 1);
-    const int win0 = kz0 * g.nchunk;
-    const int nwin = (kz1 + 1 - kz0) * g.nchunk;
-    const int nsteps = nwin * g.nsweep;
+    // Window order.  A window = (temporal tap kz, chunk of cpw input channels).  Windows whose chunk is >= lz0 hold bf16-exact activations (an
+    // all-zero lo plane): their hi x lo products add exact zeros and are left out.  A branch per block cost more than it saved (2 340 scalar
+    // branches per wave of the z/r conv) and an if / else around two step bodies makes the accumulators phi nodes inside the loop (391 spilled
+    // registers), so the K loop runs in TWO PHASES, each with its own straight-line step body: phase 0 = the windows with chunk < lz0 of every
+    // tap (full product), phase 1 = the others (no hi x lo MFMAs).  The summation order is a fixed function of the descriptor.
+    const int nkz = kz1 + 1 - kz0;
+    const int nw0 = nkz * g.lz0, nw1 = nkz * (g.nchunk - g.lz0);
+    const int nwin = nw0 + nw1;
 
     f32x4 acc[4][13];
     u32x4 ring[4][2];
+    // current window (ckz, cch) and its successor in the order above (nkz_ < 0: none)
+    int ckz = kz0, cch = nw0 > 0 ? 0 : g.lz0;
+    auto next_window = [&](int kz, int ch, int& okz, int& och) {
+        const bool ph1 = ch >= g.lz0;
+        okz = kz, och = ch + 1;
+        if (och == (ph1 ? g.nchunk : g.lz0)) {
+            och = ph1 ? g.lz0 : 0;
+            if (++okz > kz1) {
+                if (ph1 || nw1 == 0) okz = -1;
+                else okz = kz0, och = g.lz0;
+            }
+        }
+    };
 
-#define CONV6_STEP(U, NBW, JJ)                                                                                                     \
+#define CONV6_STEP(U, NBW, SKIP, LASTSTEP)                                                                                         \
     {                                                                                                                              \
-        const int jj = (JJ);                                                                                                       \
-        const bool last = jj + 1 >= nsteps;                                                                                        \
         /* tap state of the NEXT step */                                                                                           \
         int n_sw = sw + 1, n_swx = swx + 1, n_off = off + g.inc, n_ty = tyo + g.yinc, n_w = w;                                      \
         if (n_swx == g.swx_n) n_swx = 0, n_off += g.jump, n_ty += g.ywrap;                                                          \
         const bool wend = n_sw == g.nsweep;                                                                                        \
-        if (wend) n_sw = 0, n_swx = 0, n_off = 0, n_ty = 0, n_w = w + 1;                                                            \
+        const bool last = (LASTSTEP) && wend && nxkz < 0; /* no step behind this one */                                            \
+        if (wend) n_sw = 0, n_swx = 0, n_off = 0, n_ty = 0, n_w = w ^ 1;                                                            \
         if (last) n_off = off, n_ty = tyo, n_w = w;                                                                                \
-        const unsigned cur_off = (unsigned)((w & 1) * g.wbytes + off * 128), nxt_off = (unsigned)((n_w & 1) * g.wbytes + n_off * 128); \
-        const unsigned lh = lane_addr(tyo), lhn = lane_addr(n_ty);                                                                  \
-        /* 1: this window's lo plane is all zero (shift, not ?: -- a select lands in a VGPR, and the asm wants a scalar register) */  \
-        const int lz = __builtin_amdgcn_readfirstlane((int)((unsigned)(g.lz0 - 1 - wchunk) >> 31));                                 \
-        const bool issue = sw == 0 && w + 1 < nwin; /* this step carries the DMA of the next window (into the other buffer) */     \
-        if (issue) dma_setup(win0 + w + 1, (w + 1) & 1);                                                                           \
-        const char* sbn = abase + (int64_t)(win0 * g.nsweep + (last ? jj : jj + 1)) * astep;                                        \
-        conv6_step<MB, NBW>(acc, areg[U], areg[(U) ^ 1], ring, lh, lhn, cur_off, nxt_off, coff, avoff0, avoff1, sbn, lz, [&](int h) { \
+        const unsigned bh = lane_addr(tyo) + (unsigned)(w * g.wbytes + off * 128), bhn = lane_addr(n_ty) + (unsigned)(n_w * g.wbytes + n_off * 128); \
+        const bool issue = sw == 0 && nxkz >= 0; /* this step carries the DMA of the next window (into the other buffer) */         \
+        if (issue) dma_setup(nxkz, nxch, w ^ 1);                                                                                   \
+        const int ksn = last ? (ckz * g.nchunk + cch) * g.nsweep + sw : (wend ? (nxkz * g.nchunk + nxch) * g.nsweep : (ckz * g.nchunk + cch) * g.nsweep + sw + 1); \
+        const char* sbn = abase + (int64_t)ksn * astep;                                                                            \
+        conv6_step<MB, NBW, CR, SKIP>(acc, areg[U], areg[(U) ^ 1], ring, bh, bh ^ 64u, bhn, bhn ^ 64u, avoff0, avoff1, sbn, [&](int h) { \
             if (issue) {                                                                                                           \
-                _Pragma("unroll") for (int i = 0; i < MAXP6; ++i)                                                                   \
-                    if (i % conv6_shape<MB, NBW>::HOOKS == h && i < g.npieces) dma_piece(i);                                        \
+                _Pragma("unroll") for (int i = 0; i < NP; ++i)                                                                      \
+                    if (i % conv6_shape<MB, NBW>::HOOKS == h) dma_piece(i);                                                         \
             }                                                                                                                      \
         });                                                                                                                        \
         sw = n_sw, swx = n_swx, off = n_off, tyo = n_ty;                                                                            \
@@ -219,11 +236,27 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
             __builtin_amdgcn_s_barrier();                                                                                          \
             w = n_w;                                                                                                               \
-            if (++wchunk == g.nchunk) wchunk = 0;                                                                                  \
-            conv6_prime<NBW>(ring, lhn, nxt_off, coff);                                                                             \
+            ckz = nxkz, cch = nxch;                                                                                                \
+            next_window(ckz, cch, nxkz, nxch);                                                                                     \
+            conv6_prime<NBW, CR>(ring, bhn, bhn ^ 64u);                                                                             \
+        } else if (issue) { /* the next step's weight fragments: everything but the NP pieces issued behind them */                  \
+            if constexpr (NP == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");                                               \
+            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                                                   \
         } else {                                                                                                                   \
-            vm_wait6(issue ? g.npieces : 0);                                                                                       \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                       \
         }                                                                                                                          \
+    }
+    // one phase: nst steps (phase 0 of a two-phase loop: an even number -- the host keeps lz0 * nsweep even --, so that phase 1 starts on weight
+    // register stage 0 again)
+#define CONV6_PHASE(NBW, SKIP, NST)                                                                                                \
+    {                                                                                                                              \
+        const int nst = (NST);                                                                                                     \
+        int j = 0;                                                                                                                 \
+        for (; j + 1 < nst; j += 2) {                                                                                              \
+            CONV6_STEP(0, NBW, SKIP, false)                                                                                        \
+            CONV6_STEP(1, NBW, SKIP, j + 2 >= nst)                                                                                 \
+        }                                                                                                                          \
+        if (j < nst) CONV6_STEP(0, NBW, SKIP, true)                                                                                \
     }
 #define CONV6_LOOP(NBW)                                                                                                            \
     {                                                                                                                              \
@@ -231,21 +264,18 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             acc[a][b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                                                            \
             asm volatile("" : "+a"(acc[a][b]));                                                                                     \
         }                                                                                                                          \
-        dma_setup(win0, 0);                                                                                                        \
-        _Pragma("unroll") for (int i = 0; i < MAXP6; ++i) if (i < g.npieces) dma_piece(i);                                          \
-        load_a(areg[0], win0 * g.nsweep);                                                                                          \
+        int nxkz, nxch;                                                                                                            \
+        next_window(ckz, cch, nxkz, nxch);                                                                                         \
+        dma_setup(ckz, cch, 0);                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < NP; ++i) dma_piece(i);                                                                \
+        load_a(areg[0], (ckz * g.nchunk + cch) * g.nsweep);                                                                        \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                           \
         __builtin_amdgcn_s_barrier();                                                                                              \
         int sw = 0, swx = 0, off = 0, tyo = 0, w = 0;                                                                               \
-        int wchunk = 0; /* index of the current window inside its temporal tap (win0 is a multiple of nchunk) */                   \
-        conv6_prime<NBW>(ring, lane_addr(0), 0u, coff);                                                                             \
+        conv6_prime<NBW, CR>(ring, lane_addr(0), lane_addr(0) ^ 64u);                                                               \
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory"); /* the zeroed accumulators are AGPR writes: wait states in front of the first MFMA */ \
-        int j = 0;                                                                                                                 \
-        for (; j + 1 < nsteps; j += 2) {                                                                                           \
-            CONV6_STEP(0, NBW, j)                                                                                                  \
-            CONV6_STEP(1, NBW, j + 1)                                                                                              \
-        }                                                                                                                          \
-        if (j < nsteps) CONV6_STEP(0, NBW, j)                                                                                      \
+        CONV6_PHASE(NBW, false, nw0 * g.nsweep)                                                                                    \
+        CONV6_PHASE(NBW, true, nw1 * g.nsweep)                                                                                     \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");                                        \
         _Pragma("unroll") for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(areg[0][k]), "v"(areg[1][k]));                          \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(ring[k][0]), "v"(ring[k][1]));                          \
@@ -257,6 +287,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     }
     CONV6_STAMP(2)
 #undef CONV6_LOOP
+#undef CONV6_PHASE
 #undef CONV6_STEP
     __syncthreads();                               // the window buffers become the epilogue's staging areas
 
@@ -387,10 +418,11 @@ static bool plan6(const ppms_conv* d, Geo6& g) {
         g.nsweep = d->kh * d->kw, g.swx_n = d->kw, g.inc = g.WH, g.jump = 1 - d->kw * g.WH, g.ywrap = 1;
     }
     const int rows = g.WH * g.WC;
+    if (g.lz0 < nchunk && ((g.lz0 * g.nsweep) & 1)) g.lz0 = nchunk;   // (phase 0 must hold an even number of steps: else every product is computed)
     g.npieces = (rows * 8 + NT6 - 1) / NT6;
-    g.wbytes = g.npieces * NT6 * 16;
+    g.wbytes = conv6_np(g.WH) * NT6 * 16;
     g.P = (int64_t)d->T * d->H * d->W;
-    return g.npieces <= MAXP6 && g.nsweep >= 2;
+    return (g.WH == 16 || g.WH == 18 || g.WH == 20) && g.npieces <= conv6_np(g.WH) && g.nsweep >= 2;
 }
 
 static bool conv6_volume_fits(const ppms_conv* d) { return (int64_t)d->T * d->H * d->W < (1ll << 22); }
@@ -464,15 +496,22 @@ extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, vo
     const size_t lds = conv6_lds(d, g);
     PPMS_REQUIRE(lds <= 160 * 1024, "conv_gemm6: LDS budget exceeded (%zu B)", lds);
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
+    PPMS_REQUIRE(g.WH == 16 || g.WH == 18 || g.WH == 20, "conv_gemm6: window columns of %d rows", g.WH);
     static ppms_device_once once;
     once.run([] {
-        (void)hipFuncSetAttribute((const void*)conv6_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv6_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define CONV6_ATTR(MBV, CRV) (void)hipFuncSetAttribute((const void*)conv6_kernel<MBV, CRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        CONV6_ATTR(4, 16) CONV6_ATTR(4, 18) CONV6_ATTR(4, 20) CONV6_ATTR(3, 16) CONV6_ATTR(3, 18) CONV6_ATTR(3, 20)
+#undef CONV6_ATTR
     });
 #ifdef PPMS_CONV6_TIMING
     g.dbg = g_conv6_dbg;
 #endif
-    if (d->M == 192) hipLaunchKernelGGL(conv6_kernel<3>, dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
-    else hipLaunchKernelGGL(conv6_kernel<4>, dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+#define CONV6_GO(MBV, CRV) hipLaunchKernelGGL((conv6_kernel<MBV, CRV>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g)
+    if (d->M == 192) {
+        if (g.WH == 16) CONV6_GO(3, 16); else if (g.WH == 18) CONV6_GO(3, 18); else CONV6_GO(3, 20);
+    } else {
+        if (g.WH == 16) CONV6_GO(4, 16); else if (g.WH == 18) CONV6_GO(4, 18); else CONV6_GO(4, 20);
+    }
+#undef CONV6_GO
     return ppms_check_launch("conv_gemm6");
 }

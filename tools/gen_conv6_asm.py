@@ -15,7 +15,7 @@ import os
 
 MF = "v_mfma_f32_16x16x32_bf16"
 ABL = int(os.environ.get("PPMS_CONV6_ABL", "0"))     # timing experiments only (wrong results): 1 drops the LDS fragment reads and their waits,
-                                                     # 2 the weight-fragment loads, 4 the MFMAs
+                                                     # 2 the weight-fragment loads, 4 the MFMAs, 8 the LDS-DMA pieces of the loop
 VARIANTS = [(4, 13), (3, 13), (4, 7), (4, 6)]        # (MB, NBW): M = 256, M = 192, the two pixel halves of M = 128
 
 
@@ -28,8 +28,9 @@ def slot(n, nbw):
 
 
 def a_blocks(mb, nbw):
-    """Which weight-fragment loads (k = 0 .. 2 MB - 1) of the NEXT step are issued in which block: spread over the first blocks of the step."""
-    nab = min(2 * mb, max(1, nbw - 3))
+    """Which weight-fragment loads (k = 0 .. 2 MB - 1) of the NEXT step are issued in which block: two per block over the first blocks of the step (the
+    step ends with a wait for them: the earlier they leave, the less of their L2 round trip is exposed)."""
+    nab = min(mb, max(1, nbw - 3))
     per = {}
     for k in range(2 * mb):
         per.setdefault(k * nab // (2 * mb), []).append(k)
@@ -55,7 +56,8 @@ class Emit:
         self.lines.append("        " + text)
 
 
-def step(mb, nbw):
+def step(mb, nbw, skip):
+    """skip: the step body without the hi x lo products (windows whose lo plane is all zero)."""
     assert nbw % 3 <= 1, "the ring has one spare slot"
     E = Emit()
     nab, aper = a_blocks(mb, nbw)
@@ -63,19 +65,19 @@ def step(mb, nbw):
         s = slot(n, nbw)
         # the fragments of block n were requested two blocks ago; the requests of block n + 1 may stay in flight
         E.asm("s_waitcnt lgkmcnt(2)")
-        # addresses of the requests issued in this block: block n + 2 of this step, or block n + 2 - NBW of the next one
+        # the requests issued in this block: block n + 2 of this step, or block n + 2 - NBW of the next one; the block's column offset inside
+        # the window is an immediate (CR = rows per window column is a template parameter)
         if n + 2 < nbw:
-            tgt, ts = f"lane_hi + cur_off + coff[{n + 2}]", slot(n + 2, nbw)
+            bh, bl, blk, ts = "bh", "bl", n + 2, slot(n + 2, nbw)
         else:
-            tgt, ts = f"lane_hi_nxt + nxt_off + coff[{n + 2 - nbw}]", slot(n + 2 - nbw, nbw)
-        E.c(f"{{ const unsigned ah_ = {tgt}, al_ = ah_ ^ 64u;")
+            bh, bl, blk, ts = "bhn", "bln", n + 2 - nbw, slot(n + 2 - nbw, nbw)
         loads = list(aper.get(n, []))
         for m in range(mb):                                   # hi x hi
             E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"acc[{m}][{n}]")], [("a", "v", f"a[{2 * m}]"), ("b", "v", f"ring[{s}][0]")])
             if m == 0:
-                E.asm("ds_read_b128 {d}, {p}", [("d", "+v", f"ring[{ts}][0]")], [("p", "v", "ah_")])
+                E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{ts}][0]")], [("p", "v", bh), ("o", "n", f"{blk} * CR * 128")])
             elif m == 1:
-                E.asm("ds_read_b128 {d}, {p}", [("d", "+v", f"ring[{ts}][1]")], [("p", "v", "al_")])
+                E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{ts}][1]")], [("p", "v", bl), ("o", "n", f"{blk} * CR * 128")])
             elif loads:
                 k = loads.pop(0)
                 E.asm(f"global_load_dwordx4 {{d}}, {{o}}, {{sb}} offset:{(k & 3) * 1024}", [("d", "+v", f"an[{k}]")],
@@ -87,14 +89,10 @@ def step(mb, nbw):
                 E.asm(f"global_load_dwordx4 {{d}}, {{o}}, {{sb}} offset:{(k & 3) * 1024}", [("d", "+v", f"an[{k}]")],
                       [("o", "v", "avoff0" if k < 4 else "avoff1"), ("sb", "s", "sb_next")])
         assert not loads
-        # hi x lo: one statement behind ONE scalar compare + branch (skip != 0: the window's lo plane is all zero, the products add exact zeros)
-        body = "\\n\\t".join(f"{MF} %{m}, %{mb + 1 + m}, %{mb}, %{m}" for m in range(mb))
-        outs = ", ".join(f'"+a"(acc[{m}][{n}])' for m in range(mb))
-        ins = ", ".join([f'"v"(ring[{s}][1])'] + [f'"v"(a[{2 * m}])' for m in range(mb)] + ['"s"(skip)'])
-        if not (ABL & 4):
-            E.c(f'asm volatile("s_cmp_lg_u32 %{2 * mb + 1}, 0\\n\\ts_cbranch_scc1 .Lc6s%=\\n\\t{body}\\n.Lc6s%=:" : {outs} : {ins} : "memory", "scc");')
-        E.c("}")
-        if n >= nab - 1:
+        if not skip:
+            for m in range(mb):                               # hi x lo
+                E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"acc[{m}][{n}]")], [("a", "v", f"a[{2 * m}]"), ("b", "v", f"ring[{s}][1]")])
+        if n >= nab - 1 and not (ABL & 8):      # (ABL 8: no DMA pieces -- the windows keep their first contents)
             E.c(f"hook({n - (nab - 1)});")
     return "\n".join(E.lines), nab
 
@@ -102,10 +100,8 @@ def step(mb, nbw):
 def prime(nbw):
     E = Emit()
     for n in range(2):
-        E.c(f"{{ const unsigned ah_ = lane_hi + cur_off + coff[{n}], al_ = ah_ ^ 64u;")
-        E.asm("ds_read_b128 {d}, {p}", [("d", "+v", f"ring[{slot(n, nbw)}][0]")], [("p", "v", "ah_")])
-        E.asm("ds_read_b128 {d}, {p}", [("d", "+v", f"ring[{slot(n, nbw)}][1]")], [("p", "v", "al_")])
-        E.c("}")
+        E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{slot(n, nbw)}][0]")], [("p", "v", "bh"), ("o", "n", f"{n} * CR * 128")])
+        E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{slot(n, nbw)}][1]")], [("p", "v", "bl"), ("o", "n", f"{n} * CR * 128")])
     return "\n".join(E.lines)
 
 
@@ -120,21 +116,25 @@ def gen():
 ''']
     out.append("template <int MB, int NBW> struct conv6_shape;")
     for mb, nbw in VARIANTS:
-        body, nab = step(mb, nbw)
+        _, nab = step(mb, nbw, False)
         out.append(f"template <> struct conv6_shape<{mb}, {nbw}> {{ static constexpr int HOOKS = {nbw - nab + 1}; }};   // blocks that call the hook")
     out.append("")
-    out.append("template <int MB, int NBW, class Hook>\n__device__ __forceinline__ void conv6_step(f32x4 (&acc)[4][13], const u32x4 (&a)[8], u32x4 (&an)[8], u32x4 (&ring)[4][2],\n"
-               "        unsigned lane_hi, unsigned lane_hi_nxt, unsigned cur_off, unsigned nxt_off, const unsigned (&coff)[13], unsigned avoff0, unsigned avoff1,\n"
-               "        const char* sb_next, int skip, Hook&& hook) {")
+    out.append("// CR: rows of a window column (16 + y halo): the column offsets of the fragment reads are immediates.  bh / bl: LDS address of this lane's hi / lo\n"
+               "// fragment of the wave's first block at the current tap (bl = bh ^ 64); bhn / bln: the same for the next step.  SKIP: the body without the\n"
+               "// hi x lo products (windows whose lo plane is all zero).\n"
+               "template <int MB, int NBW, int CR, bool SKIP, class Hook>\n__device__ __forceinline__ void conv6_step(f32x4 (&acc)[4][13], const u32x4 (&a)[8], u32x4 (&an)[8], u32x4 (&ring)[4][2],\n"
+               "        unsigned bh, unsigned bl, unsigned bhn, unsigned bln, unsigned avoff0, unsigned avoff1, const char* sb_next, Hook&& hook) {")
     first = True
     for mb, nbw in VARIANTS:
-        body, _ = step(mb, nbw)
-        out.append(("    if constexpr (" if first else "    } else if constexpr (") + f"MB == {mb} && NBW == {nbw}) {{\n" + body)
+        for skip in (False, True):
+            b0, _ = step(mb, nbw, skip)
+            out.append(("    if constexpr (" if first else "    } else if constexpr (") + f"MB == {mb} && NBW == {nbw} && {'SKIP' if skip else '!SKIP'}) {{\n" + b0)
+            first = False
         first = False
     out.append("    }\n}\n")
     out.append("// the requests for blocks 0 and 1 of a step (the loop's first step, and the first step behind every window switch: the tail requests of the\n"
                "// step in front of the barrier read a window that may not have landed yet and are simply issued again)\n"
-               "template <int NBW>\n__device__ __forceinline__ void conv6_prime(u32x4 (&ring)[4][2], unsigned lane_hi, unsigned cur_off, const unsigned (&coff)[13]) {")
+               "template <int NBW, int CR>\n__device__ __forceinline__ void conv6_prime(u32x4 (&ring)[4][2], unsigned bh, unsigned bl) {")
     first = True
     for nbw in sorted({v[1] for v in VARIANTS}, reverse=True):
         out.append(("    if constexpr (" if first else "    } else if constexpr (") + f"NBW == {nbw}) {{\n" + prime(nbw))
