@@ -73,6 +73,14 @@ __device__ __forceinline__ void dma16_6(const void* src, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_dst) : "memory");
 }
 
+#ifndef CONV6_SLACK
+#define CONV6_SLACK 0
+#endif
+#if CONV6_SLACK
+#define CONV6_SWITCH_SLACK asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#else
+#define CONV6_SWITCH_SLACK
+#endif
 #include "conv6_asm.h"
 
 // MB: 16-cout blocks per wave -- 4 (M = 256, 128) or 3 (M = 192); CR: rows of a window column = 16 + y halo (16, 18, 20)
@@ -235,6 +243,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             /* loads), every wave is done reading the old window                                                                  */ \
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
             __builtin_amdgcn_s_barrier();                                                                                          \
+            CONV6_SWITCH_SLACK                                                                                                     \
             w = n_w;                                                                                                               \
             ckz = nxkz, cch = nxch;                                                                                                \
             next_window(ckz, cch, nxkz, nxch);                                                                                     \
@@ -454,6 +463,10 @@ extern "C" int ppms_conv_gemm6_applicable(const ppms_conv* d) {
     const int64_t cus = ppms_num_cus();
     if (tiles < cus * 25 / 32) return 0;                                 // fewer workgroups than CUs: the K-sliced small-map kernels fill the chip better
     const double fill = (double)g.P / ((double)((tiles + cus - 1) / cus) * cus * 16 * NBT6);
+    // Without spatial taps nothing re-uses a window: every k32-step pair needs a fresh 53 KiB window (13 - 14 LDS-DMA instructions per wave, ~85
+    // cycles of issue each with one wave per SIMD and nobody to fill the gap), where conv_gemm5's two waves per SIMD hide them: measured no
+    // faster than conv_gemm5 / conv_gemm2 / gemm1 there (zr3_x 151 vs 149 us, q3_x 103 us, convf1 47 vs ~25 us).  Served (tests), never rated 1.
+    if (g.mode == 3) return 2;
     return fill >= 0.85 ? 1 : 2;
 }
 

@@ -535,7 +535,7 @@ class ScaleEngine:
     def _try_fragment_kernels(self, wname: str, d: L.Conv, m_split, keep) -> Optional[ConvOp]:
         """conv_gemm6 (one wave per SIMD, 16x16x32 MFMA, pack_conv6) where the library rates its tile fill, else conv_gemm5 (weights in
         MFMA-fragment order, pack_conv4, couts padded to 128) when it serves the conv."""
-        if TUNING["conv6"] and wname in self.pk.w6:
+        if TUNING["conv6"] and wname in self.pk.w6 and (TUNING.get("conv6_only") is None or wname in TUNING["conv6_only"]):
             packed6, bias6, meta6 = self.pk.w6[wname]
             d6 = L.Conv.from_buffer_copy(bytes(d))
             d6.w, d6.bias, d6.M = packed6.data_ptr(), bias6.data_ptr(), meta6["M"]

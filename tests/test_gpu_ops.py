@@ -750,6 +750,8 @@ def test_conv_gemm6_full_map_and_rating(lib):
     assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 1
     d.T, d.H, d.W = 5, 40, 64
     assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 0
+    d.T, d.H, d.W, d.kh, d.kw = 5, 80, 128, 1, 1                        # no spatial taps: served, but never the faster choice
+    assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 2
 
 
 def test_conv_gemm6_two_epilogue_halves(lib):

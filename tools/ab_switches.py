@@ -21,6 +21,8 @@ for _env, _key in _MAP.items():
         _engine.TUNING[_key] = os.environ[_env] != "0"
 if "PPMS_STREAM" in os.environ:
     _engine.TUNING["stream"] = {"0": False, "1": True}.get(os.environ["PPMS_STREAM"], os.environ["PPMS_STREAM"])
+if "PPMS_CONV6_ONLY" in os.environ:          # debugging: conv_gemm6 only for these weight names (comma separated)
+    _engine.TUNING["conv6_only"] = set(os.environ["PPMS_CONV6_ONLY"].split(","))
 if "PPMS_STREAM_HINT" in os.environ:
     _engine.TUNING["stream_hint"] = int(os.environ["PPMS_STREAM_HINT"])
 if "PPMS_FORK_MIN" in os.environ:
