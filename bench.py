@@ -11,6 +11,8 @@ outputs the loop consumes) are synthetic and resident in HBM before the timed re
 
 N > 1, T = 5 (config 2): every rank runs its own replica of the clip (T=5 does not divide across ranks without changing
 the result -- DESIGN.md section 6), scaling "weak", value = N * pixels / max-over-ranks time.
+N > 1, T = 5: behind the replica measurement the same ranks run ONE frame-sharded window (--sharded-T 40 --sharded-iters 20 = BASELINE config 4), checked
+against the unsharded result on rank 0 first; it is reported under `sharded` / `sharded_check`, never in `value`.
 N > 1, --T divisible by N and >= 2 frames per rank (configs 4-5, e.g. --T 40): the window's frames are SHARDED over the
 ranks (ppmstereo_amd.dist.FrameShard: all-gather of the memory keys once per scale and of the values / confidences every
 iteration, +-2 / +-1 frame halos for the temporal convs), scaling "strong", value = pixels / max-over-ranks time.
@@ -71,6 +73,27 @@ def cpu_baseline(T, H, W, iters, threads):
                 seconds_per_clip=total)
 
 
+def cpu_baseline_full(T, H, W, iters, threads, runs=3):
+    """SURVEY 8(d)'s procedure: the whole clip through the oracle's cascade (3 pyramid builds + iters//2, iters//2, iters iterations), 1 warm-up + `runs`
+    timed runs, the median.  ~6 minutes at config 2 on 16 threads: behind --cpu-baseline full only (the default line carries the sampled form;
+    profiles/rNN_cpu_baseline_full.json keeps one full run with the sampled figure of the same process beside it)."""
+    from oracle import ppm_oracle as O
+    from ppmstereo_amd import weights as Wm
+    from ppmstereo_amd.synth import synth_cascade_feats
+    torch.set_num_threads(threads)
+    Wt = Wm.hot_path_weights()
+    feats = synth_cascade_feats(T, H, W)
+    ts = []
+    for r in range(runs + 1):
+        t0 = time.perf_counter()
+        O.cascade(Wt, feats, iters, T, [], [])
+        ts.append(time.perf_counter() - t0)
+    timed = sorted(ts[1:])
+    med = timed[len(timed) // 2]
+    return dict(value=T * H * W / med, unit="disparity-px/s", cores=threads, kind="port", seconds_per_clip=med, runs_s=[round(t, 2) for t in ts],
+                sample=f"the whole T={T} {H}x{W} clip, iters={iters}: 1 warm-up + {runs} runs of the fp32 torch-CPU oracle's cascade, median ({med:.1f} s per clip)")
+
+
 def launch_ranks(n, argv):
     """One process per GPU on this node through torch.distributed.run (the same command line the driver uses), rendezvous on 127.0.0.1 at a free
     port; rank 0's JSON line goes to this process's stdout.  Returns the launcher's exit code (non-zero if any rank failed)."""
@@ -100,14 +123,83 @@ def dry_run(args, D, rank, world):
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
     frames = D.sum_over_ranks(float(shard.f if sharded else T))
+    sh_plan = None
+    if world > 1 and not sharded and args.sharded_T and args.sharded_T % world == 0 and args.sharded_T // world >= 2:
+        # the extra frame-sharded window of the real run (sharded_phase): planned and rehearsed on the stub (one all-reduce per repetition)
+        sh = D.FrameShard(rank, world, args.sharded_T)
+        D.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.sharded_steps):
+            time.sleep(1e-3)
+        D.barrier()
+        sh_el = D.max_over_ranks(time.perf_counter() - t1)
+        sh_frames = D.sum_over_ranks(float(sh.f))
+        sh_plan = dict(T=args.sharded_T, iters=args.sharded_iters, frames_per_gpu=sh.f, frames_over_ranks=sh_frames, ms_per_window=None,
+                       stub_ms=round(1e3 * sh_el / args.sharded_steps, 3), note="dry run: planned, not measured")
     if rank == 0:
-        print(json.dumps(dict(metric="disparity-px/s", value=None, unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+        print(json.dumps(dict(metric="disparity-px/s", value=None, unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup, sharded=sh_plan,
                               ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="strong" if sharded else "weak",
                               dry_run=True, backend=torch.distributed.get_backend() if world > 1 else None, frames_over_ranks=frames,
                               config=dict(workload="dry run: stub step, no GPU work", T=T, H=args.H, W=args.W, iters=args.iters,
                                           parallelism=(f"frames sharded {T // world}/GPU x{world}" if sharded else f"replicas x{world}")))))
     if world > 1:
         torch.distributed.destroy_process_group()
+
+
+SINGLE_GPU_T40_MS = 542.0     # one T=40 window at 320x512, iters=20 on ONE MI355X (profiles/r04_bench_T40_320x512_iters20_single_gpu.json)
+
+
+def sharded_phase(args, D, model, rank, world, dev):
+    """N > 1: ONE window of --sharded-T frames (BASELINE config 4: T = 40, iters = 20) frame-sharded over the same ranks -- the memory keys gathered once
+    per scale, the values + confidences every iteration, +-2 / +-1-frame halos for the temporal convolutions (ppmstereo_amd.dist.FrameShard; reference:
+    ppmstereo.py:277-307,524-550, ppmtereo_update.py:281-310,670-678) -- behind the replica measurement.  First a CHECK on the hardware this runs on: the
+    sharded cascade at reduced iteration counts against the same window computed unsharded on rank 0; a failed check ends the run with a non-zero
+    exit code on every rank.  Then --sharded-steps timed windows (barrier + synchronize on both sides, max over ranks).  Returns (sharded, check)."""
+    from ppmstereo_amd.synth import synth_cascade_feats
+    T, H, W, iters = args.sharded_T, args.H, args.W, args.sharded_iters
+    shard = D.FrameShard(rank, world, T)
+    full = synth_cascade_feats(T, H, W)                                           # host tensors: every rank builds the same window
+    local = {k: v[shard.lo:shard.hi].to(dev) for k, v in full.items()}
+    chk_iters = 2
+    d_sh, _ = model.cascade(local, chk_iters, T, shard=shard, test_mode=True)
+    torch.cuda.synchronize()
+    d_all, _ = shard.all_gather(d_sh.float().contiguous())                        # (T, 1, H, W) on every rank
+    err = 0.0
+    if rank == 0:
+        on_dev = {k: v.to(dev) for k, v in full.items()}
+        d_ref, _ = model.cascade(on_dev, chk_iters, T, test_mode=True)
+        torch.cuda.synchronize()
+        err = float((d_all.to(dev) - d_ref.float()).abs().max().item()) if torch.isfinite(d_all).all() else float("inf")
+        del on_dev, d_ref
+    del full
+    err = D.max_over_ranks(err)
+    tol = 1e-3                                                                    # px; measured on two / four ranks of one GPU: <= 5e-5 of the range
+    check = dict(max_abs_disparity_diff_px=err, tolerance_px=tol, iters=chk_iters, reference="the same window unsharded on rank 0", passed=bool(err <= tol))
+    if not check["passed"]:
+        if rank == 0:
+            print(json.dumps(dict(error="sharded_check failed", sharded_check=check)), file=sys.stderr)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        sys.exit(3)
+    model.cascade(local, iters, T, shard=shard, test_mode=True)                   # warm-up at the real iteration count
+    torch.cuda.synchronize()
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.sharded_steps):
+        d_sh, _ = model.cascade(local, iters, T, shard=shard, test_mode=True)
+    torch.cuda.synchronize()
+    D.barrier()
+    ms = 1e3 * D.max_over_ranks(time.perf_counter() - t0) / args.sharded_steps
+    assert torch.isfinite(d_sh).all()
+    cfg4 = (T, H, W, iters) == (40, 320, 512, 20)
+    out = dict(T=T, H=H, W=W, iters=iters, frames_per_gpu=shard.f, steps=args.sharded_steps, ms_per_window=round(ms, 3), px_per_s=round(T * H * W / (ms * 1e-3), 1),
+               scaling="strong", vs_single_gpu_542ms=(round(SINGLE_GPU_T40_MS / ms, 3) if cfg4 else None),
+               exchanges_per_iteration="6 (7 at the 1/16 scale): values + confidences (direct all-gather), +-2 frames of x (async), of h, of r*h, +-1 frame of the "
+                                       "hidden state and of the flow-head taps; keys + frame descriptors once per scale",
+               backend=torch.distributed.get_backend(),
+               note="one frame-sharded window behind the replica measurement; never part of `value`"
+                    + ("" if torch.distributed.get_backend() == "nccl" else "; NOT RCCL: a rehearsal over " + torch.distributed.get_backend()))
+    return out, check
 
 
 TIMING_EVERY = 20         # per-launch events in steps 0, 20, 40, ... of the timed region (one step's launches: 117 convs, 20 attention calls)
@@ -123,6 +215,8 @@ def main():
     ap.add_argument("--W", type=int, default=512)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", choices=("sampled", "full"), default="sampled", help="sampled (default): one iteration per scale, extrapolated by iteration "
+                    "count (~10 s); full: SURVEY 8(d)'s procedure, 1 warm-up + 3 whole-clip runs, median (~6 min) -- the sampled figure is printed beside it")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets around the attention / conv3 kernels")
     ap.add_argument("--no-encoders", action="store_true", help="skip the encoder / whole-call timings (fnet + cnet + SST block and "
                     "PPMStereo.forward_batch_test on a host video: once per clip, outside `value`, reported under `encoders` / `whole_call_ms`)")
@@ -131,6 +225,11 @@ def main():
                     "ppmstereo_amd.ppmstereo.ClipPipeline; measured 40.8 vs 41.8 ms per clip -- the 1/4 scale leaves ~16 CUs to the second stream); off by "
                     "default: the headline number is one clip after the other.  latency_ms_per_clip (one clip alone) is reported either way")
     ap.add_argument("--replicas", action="store_true", help="N > 1: force clip replicas even when T divides over the ranks")
+    ap.add_argument("--sharded-T", type=int, default=40, help="N > 1 with clip replicas as the measurement (the default T = 5 does not divide over the ranks): "
+                    "frames of the ONE extra window that is frame-sharded over the same ranks behind the timed region (BASELINE config 4: T = 40, 5 frames per GPU "
+                    "on 8 GPUs) and reported under `sharded` with its correctness check `sharded_check`; 0 = skip that phase")
+    ap.add_argument("--sharded-iters", type=int, default=20, help="iterations of that window (config 4: 20)")
+    ap.add_argument("--sharded-steps", type=int, default=3, help="timed repetitions of that window")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / argument plumbing only: the ranks form the process group, run a stub step "
                     "(no GPU work), take the barrier + max-over-ranks path and rank 0 prints a line with value = null (CPU rehearsal, tests/test_bench_launch.py)")
     args = ap.parse_args()
@@ -389,6 +488,9 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
         all_ms = D.max_over_ranks(time.perf_counter() - t_all) / n_all * 1e3
+    sharded_out = sharded_chk = None
+    if world > 1 and not sharded and args.sharded_T and args.sharded_T % world == 0 and args.sharded_T // world >= 2:
+        sharded_out, sharded_chk = sharded_phase(args, D, model, rank, world, dev)
     encoders = None
     if not args.no_encoders and world == 1 and (T, H, W) == (5, 320, 512):      # (N > 1: the ranks time their clips only)
         # SURVEY 8 rows f3-f5 on the same clip geometry: fnet on the 2T images, cnet on the T left images, SST on the 1/16 features
@@ -446,6 +548,11 @@ def main():
             # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
             cores = min(16, len(os.sched_getaffinity(0))) if hasattr(os, "sched_getaffinity") else min(16, os.cpu_count() or 1)
             cpu = cpu_baseline(T, H, W, iters, cores)
+            if args.cpu_baseline == "full":
+                sampled = cpu
+                cpu = cpu_baseline_full(T, H, W, iters, cores)
+                cpu["sampled_seconds_per_clip"] = sampled["seconds_per_clip"]
+                cpu["sampled_vs_full"] = round(sampled["seconds_per_clip"] / cpu["seconds_per_clip"], 4)
         label = BASELINE_CONFIGS.get((T, H, W, iters), "custom configuration")
         par = f"frames sharded {T // world}/GPU x{world} (RCCL all-gather of memory K/V + temporal halos)" if sharded else f"replicas x{world}"
         out = dict(metric="disparity-px/s", value=round(value, 1), unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -465,6 +572,7 @@ def main():
                              "latency_ms_per_clip = one clip alone" if pipe is not None else "off: clips strictly one after the other"),
                    roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None,
                    roofline_3=family_roof if (not args.no_kernel_timing and family) else None, roofline_hbm=hbm_roof, cpu_baseline=cpu,
+                   sharded=sharded_out, sharded_check=sharded_chk,
                    whole_call_ms=None if not encoders else encoders["whole_call_ms"],
                    library=os.path.relpath(L.lib_path(), ROOT), **({"encoders": encoders} if encoders else {}))
         print(json.dumps(out))

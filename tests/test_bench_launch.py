@@ -32,6 +32,11 @@ def test_bench_gpus_n_launches_n_ranks(n, T, scaling, par):
     assert out["n_gpus"] == n and out["dry_run"] and out["value"] is None and out["backend"] == "gloo"
     assert out["scaling"] == scaling and out["config"]["parallelism"] == par
     assert out["frames_over_ranks"] == (T if scaling == "strong" else n * T)          # an all-reduce over all N ranks ran
+    if scaling == "weak":                # replicas: the extra frame-sharded window (config 4: T = 40) is planned on the same ranks
+        sh = out["sharded"]
+        assert sh["T"] == 40 and sh["iters"] == 20 and sh["frames_per_gpu"] == 40 // n and sh["frames_over_ranks"] == 40 and sh["ms_per_window"] is None
+    else:
+        assert out["sharded"] is None
     assert out["ms_per_step"] >= n * 1.0                                               # max over ranks: the slowest stub (rank N-1 sleeps N ms)
 
 

@@ -127,9 +127,15 @@ def test_bench_gpus_2_runs_end_to_end_on_one_gpu_over_gloo(T, scaling):
     """`python bench.py --gpus 2`: two ranks launched by bench.py itself; T = 5 -> clip replicas (what the driver's scaling run does at
     config 2), T = 8 -> the window's frames sharded 4 + 4 with every exchange of dist.FrameShard inside the timed steps."""
     out = _bench_line(["--gpus", "2", "--T", str(T), "--H", "64", "--W", "256", "--iters", "4", "--steps", "2", "--warmup", "1",
-                       "--no-cpu-baseline", "--no-encoders"])
+                       "--no-cpu-baseline", "--no-encoders", "--sharded-T", "8", "--sharded-iters", "4", "--sharded-steps", "1"])
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["value"] > 0 and out["steps"] == 2
     px = T * 64 * 256
     want = (1 if scaling == "strong" else 2) * 2 * px / (out["ms_per_step"] * 2e-3)
     assert abs(out["value"] - want) <= 1e-3 * want          # value = whole-job pixels over the max-over-ranks time of exactly K steps
     assert ("sharded" in out["config"]["parallelism"]) == (scaling == "strong")
+    if scaling == "weak":                # replicas as the measurement: ONE extra frame-sharded window (here T = 8, 4 + 4 frames) on the same ranks, checked
+        sh, chk = out["sharded"], out["sharded_check"]          # against the unsharded result on rank 0 before it is timed
+        assert sh["T"] == 8 and sh["frames_per_gpu"] == 4 and sh["ms_per_window"] > 0 and sh["scaling"] == "strong" and "rehearsal" in sh["note"]
+        assert chk["passed"] and chk["max_abs_disparity_diff_px"] <= chk["tolerance_px"]
+    else:
+        assert out["sharded"] is None
