@@ -31,7 +31,6 @@ __host__ __device__ constexpr int conv6_np(int cr) { return cr == 16 ? 14 : 9; }
 constexpr int NBT6 = 13;                      // 16-pixel blocks (columns) per tile
 constexpr int STG6_ROWS = 7 * 16;             // pixels a wave stages per epilogue pass
 
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page6[64];     // zero-initialised: source of padded rows
 
 struct Geo6 {
     int tiles_x, tiles_y;
@@ -65,14 +64,20 @@ static long long* g_conv6_dbg = nullptr;
 #define CONV6_STAMP(K)
 #endif
 
-// LDS-DMA of 16 B per lane: lane l's bytes land at LDS address m0 + 16 l.  Inline asm on purpose: for the compiler's own LDS-DMA (the
-// __builtin_amdgcn_global_load_lds form) the waitcnt pass puts a wait for that transfer in front of EVERY later inline-asm statement (each has
-// a memory clobber, so each "may read LDS") -- one exposed memory round trip per piece (measured: 70 of 376 us of the z/r conv).  The loop
-// orders these transfers itself (counted vmcnt + barrier at the window switch).
-__device__ __forceinline__ void dma16_6(const void* src, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_dst) : "memory");
+// LDS-DMA of 16 B per lane through a buffer resource: lane l's bytes land at LDS address m0 + 16 l; the source is srd.base + off (32-bit, per lane), and
+// a lane whose offset lies beyond srd.num_records reads ZEROS (tools/probe/buf_lds_oob_probe.hip) -- the padding of a window costs no zero page and no
+// per-lane select.  Inline asm on purpose: for the compiler's own LDS-DMA (__builtin_amdgcn_global_load_lds) the waitcnt pass puts a wait for that
+// transfer in front of EVERY later inline-asm statement (each has a memory clobber, so each "may read LDS") -- one exposed memory round trip per
+// piece.  The loop orders these transfers itself (counted vmcnt + barrier at the window switch).
+__device__ __forceinline__ void dma16_6(unsigned off, const u32x4& srd, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(off), "s"(srd), "s"(lds_dst) : "memory");
 }
+constexpr unsigned CONV6_NUM_RECORDS = 0xFFFFFF00u;     // range of a window's buffer resource; CONV6_OOB is beyond it
+constexpr unsigned CONV6_OOB = 0xFFFFFFF0u;
 
+#ifndef CONV6_EPI_G
+#define CONV6_EPI_G 2
+#endif
 #ifndef CONV6_SLACK
 #define CONV6_SLACK 0
 #endif
@@ -111,16 +116,22 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 
     // prefetch for window w + 1 goes out in the first step of window w (the other buffer was released by the barrier that ended window w - 1)
     // ---- window slots: LDS piece q = tid + i * 256 (lane-linear destination); row = q >> 3, position q & 7 --------------------------------
-    // one register per slot: pixel index (< 2^22) | 16-B unit inside the pixel's 32 (64) channels << 22 | plane << 25; ~0: padding (zero page)
+    // per piece and input segment ONE register: the byte offset of the lane's 16 B from the window's base (= the segment's hi plane at the window's
+    // frame shift and first channel): pixel * bytes per pixel + 16-B unit inside the window's channels (+ the distance of the lo plane); padding:
+    // an offset beyond the buffer resource's range, which reads zeros.  (The host checks that every offset fits: conv6_offsets_fit.)
     constexpr int NP = conv6_np(CR);
-    unsigned sl[NP];
+    const int ld0 = p.seg[0].ld * 2, ld1 = p.seg[p.nseg - 1].ld * 2;          // bytes between pixels
+    const char* const sp0h = (const char*)p.seg[0].hi;
+    const char* const sp1h = (const char*)p.seg[p.nseg - 1].hi;
+    const unsigned pd0 = (unsigned)((const char*)p.seg[0].lo - sp0h), pd1 = (unsigned)((const char*)p.seg[p.nseg - 1].lo - sp1h);
+    unsigned off0[NP], off1[NP];
     {
         const int rows = g.WH * g.WC;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int q = tid + i * NT6;
             const int row = q >> 3, pos = q & 7;
-            sl[i] = ~0u;
+            off0[i] = off1[i] = CONV6_OOB;
             if (row < rows) {
                 int sub = 0, wx, wy;
                 if (g.mode == 3) {
@@ -132,45 +143,31 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
                 }
                 const int x = x0 + wx - g.hxl, y = y0 + wy - g.hyl;
                 const int c = pos ^ (wy & 6);                    // the 16-B chunk of the row this position holds: plane * 4 + k-group
-                if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H)
-                    sl[i] = (unsigned)((tf * H + y) * W + x) | ((unsigned)((c & 3) + 4 * sub) << 22) | ((unsigned)(c >> 2) << 25);
+                if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+                    const unsigned pix = (unsigned)((tf * H + y) * W + x), unit16 = (unsigned)(((c & 3) + 4 * sub) * 16);
+                    off0[i] = pix * (unsigned)ld0 + unit16 + ((c >> 2) ? pd0 : 0u);
+                    off1[i] = pix * (unsigned)ld1 + unit16 + ((c >> 2) ? pd1 : 0u);
+                }
             }
         }
     }
-    // every descriptor field the loop needs, fetched once
-    const char* const sp0h = (const char*)p.seg[0].hi;
-    const char* const sp0l = (const char*)p.seg[0].lo;
-    const char* const sp1h = (const char*)p.seg[p.nseg - 1].hi;
-    const char* const sp1l = (const char*)p.seg[p.nseg - 1].lo;
-    const int ld0 = p.seg[0].ld * 2, ld1 = p.seg[p.nseg - 1].ld * 2;          // bytes between pixels
-    const char* zpage = (const char*)g_zero_page6;
-    asm volatile("" : "+s"(zpage));
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
     const unsigned wave_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * 1024));
-    // one DMA piece of window `win` (= temporal tap * nchunk + chunk) into buffer `buf`
-    int d_buf = 0;
-    const char *d_hi = nullptr, *d_lo = nullptr;
-    int d_ld = 0;
+    // one DMA piece of window (temporal tap kz, chunk) into buffer `buf`: the window's buffer resource (base = the segment's hi plane + frame shift +
+    // first channel; stride 0; range CONV6_NUM_RECORDS) + the piece's offset
+    int d_buf = 0, d_seg = 0;
+    u32x4 d_srd = {0u, 0u, CONV6_NUM_RECORDS, 0x00020000u};
     auto dma_setup = [&](int kz, int chunk, int buf) {
         const int dt = kz - ht;
         const int sg = (chunk >= g.n0) ? 1 : 0;
         const int c0 = (chunk - (sg ? g.n0 : 0)) * g.cpw * 2;                  // byte offset of the window's first channel
         const int64_t shift = (int64_t)dt * HW * (sg ? ld1 : ld0) + c0;
-        d_hi = (sg ? sp1h : sp0h) + shift;
-        d_lo = (sg ? sp1l : sp0l) + shift;
-        d_ld = sg ? ld1 : ld0;
-        d_buf = buf;
+        const uint64_t base = (uint64_t)(uintptr_t)((sg ? sp1h : sp0h) + shift);
+        d_srd[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
+        d_srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
+        d_seg = sg, d_buf = buf;
     };
-    auto dma_piece = [&](int i) {
-        const unsigned s = sl[i];
-        const unsigned pix = s & 0x3fffffu, unit16 = (s >> 18) & 0x70u;                  // (unit << 4)
-        // branch-free selects (as a ?: on pointers the compiler builds an exec-masked branch around the address arithmetic of every piece)
-        const uint64_t m_lo = (uint64_t)0 - (uint64_t)((s >> 25) & 1u), m_ok = (uint64_t)0 - (uint64_t)(s != ~0u);
-        const uint64_t b = ((uint64_t)(uintptr_t)d_hi & ~m_lo) | ((uint64_t)(uintptr_t)d_lo & m_lo);
-        const uint64_t a = b + (uint64_t)pix * (unsigned)d_ld + unit16;
-        const uint64_t src = (a & m_ok) | ((uint64_t)(uintptr_t)zpage & ~m_ok);
-        dma16_6((const void*)(uintptr_t)src, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16)));
-    };
+    auto dma_piece = [&](int i) { dma16_6(d_seg ? off1[i] : off0[i], d_srd, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16))); };
 
     // ---- weights: [k32-step][M/16][plane][64 lanes][16 B]; this wave's 2 MB fragments are contiguous ----------------------------------------
     const char* abase = (const char*)p.w;
@@ -381,12 +378,15 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             using I5 = std::integral_constant<int, EPI_CLS_AUXPRE>;
             using G1 = std::integral_constant<int, 1>;
             using G2 = std::integral_constant<int, 2>;
+            using GL = std::integral_constant<int, CONV6_EPI_G>;
             const int cls = epilogue_class(e);
+            // (groups of CONV6_EPI_G 8-pixel steps: the operands of a group are fetched before its rows are finished -- one wave per SIMD has nobody to
+            //  hide a memory round trip behind, so the epilogue's time is its number of such round trips)
             if (cls == EPI_CLS_PLAIN) rows(I0{}, G2{});
-            else if (cls == EPI_CLS_PRE) rows(I1{}, G2{});
-            else if (cls == EPI_CLS_AUX) rows(I2{}, G2{});
-            else if (cls == EPI_CLS_GRU) rows(I3{}, G2{});
-            else if (cls == EPI_CLS_AUXPRE) rows(I5{}, G2{});
+            else if (cls == EPI_CLS_PRE) rows(I1{}, GL{});
+            else if (cls == EPI_CLS_AUX) rows(I2{}, GL{});
+            else if (cls == EPI_CLS_GRU) rows(I3{}, GL{});
+            else if (cls == EPI_CLS_AUXPRE) rows(I5{}, GL{});
             else rows(I4{}, G1{});
         }
         }
@@ -436,6 +436,17 @@ static bool plan6(const ppms_conv* d, Geo6& g) {
 
 static bool conv6_volume_fits(const ppms_conv* d) { return (int64_t)d->T * d->H * d->W < (1ll << 22); }
 
+// a window's LDS-DMA addresses a lane's bytes as (the segment's hi plane + frame shift) + a 32-bit offset that also spans the distance to the lo plane:
+// both planes of a segment must lie inside one 4 GiB range above the hi plane (ppmstereo_amd's SPTensor keeps them in one allocation)
+static bool conv6_offsets_fit(const ppms_conv* d) {
+    const int64_t P = (int64_t)d->T * d->H * d->W;
+    for (int s = 0; s < d->nseg; ++s) {
+        const int64_t pd = (const char*)d->seg[s].lo - (const char*)d->seg[s].hi;
+        if (pd <= 0 || pd + P * d->seg[s].ld * 2 + 4096 >= (int64_t)CONV6_NUM_RECORDS) return false;
+    }
+    return true;
+}
+
 static size_t conv6_lds(const ppms_conv* d, const Geo6& g) {
     size_t lds = (size_t)2 * g.wbytes;
     const size_t stg = (size_t)4 * STG6_ROWS * ((d->M == 192 ? 48 : 64) + 4) * 4;
@@ -449,6 +460,9 @@ static size_t conv6_lds(const ppms_conv* d, const Geo6& g) {
 extern "C" int ppms_conv_gemm6_applicable(const ppms_conv* d) {
     if (d == nullptr || (d->M != 256 && d->M != 192 && d->M != 128) || d->nseg < 1 || d->nseg > 2) return 0;
     if (d->m_split % 8 != 0 || !conv6_volume_fits(d)) return 0;
+    for (int s = 0; s < d->nseg; ++s)
+        if (d->seg[s].hi == nullptr || d->seg[s].lo == nullptr) return 0;
+    if (!conv6_offsets_fit(d)) return 0;
     if (!(d->kt & 1) || !(d->kh & 1) || !(d->kw & 1)) return 0;
     if (d->kw > 1 && d->kh > 1 && d->kh > 5) return 0;
     if (d->kw > 15 || d->kh > 5) return 0;
@@ -503,6 +517,7 @@ extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, vo
             PPMS_REQUIRE(e.aux_sp.hi && e.aux_sp.lo && e.aux_sp.ld % 4 == 0, "conv_gemm6: epilogue %d needs aux_sp", hlf);
         if (e.kind == PPMS_EPI_GRU) PPMS_REQUIRE(e.aux_f32 != nullptr, "conv_gemm6: GRU epilogue needs z");
     }
+    PPMS_REQUIRE(conv6_offsets_fit(d), "conv_gemm6: the lo plane of a segment must follow its hi plane inside one 4 GiB range (32-bit window offsets)");
     Geo6 g;
     PPMS_REQUIRE(plan6(d, g), "conv_gemm6: not a convolution this kernel serves (segments in multiples of 32 channels -- 64 without spatial taps --, "
                               "a halo'd 16 x 13 window of <= 14 DMA pieces per thread)");

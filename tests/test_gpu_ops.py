@@ -696,7 +696,7 @@ def test_conv_gemm6_skips_products_with_a_zero_lo_plane(lib, name, T, H, W, segs
     if k3[0] == 1:
         assert torch.equal(full, skip), name
     else:
-        assert maxdiff(full, skip) < 2e-6 * max(1.0, ref.abs().max().item()), name
+        assert maxdiff(full, skip) < 1e-5 * max(1.0, ref.abs().max().item()), name
     assert torch.equal(skip, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, m_pad=m_pad, lo_zero_from=lz)), "bit-reproducible"
     assert maxdiff(skip, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
 

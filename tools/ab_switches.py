@@ -30,4 +30,8 @@ if "PPMS_FORK_MIN" in os.environ:
 if "PPMS_YSWEEP" in os.environ:
     _engine.TUNING["ysweep"] = os.environ["PPMS_YSWEEP"] != "0"
     _engine.TUNING["win2d"] = os.environ["PPMS_YSWEEP"] == "2d"
+if "PPMS_LIB" in os.environ:                 # A/B of two builds on ONE box: another libppms.so (same ABI) instead of the in-tree one
+    from ppmstereo_amd import build as _build
+    _build.LIB = os.path.abspath(os.environ["PPMS_LIB"])
+    _build.build = lambda *a, **k: _build.LIB
 print("[ab_switches]", _engine.TUNING, file=sys.stderr)
