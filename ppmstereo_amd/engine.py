@@ -35,6 +35,7 @@ TOP_K = 5
 TUNING = dict(
     conv5=True,           # one 8-wave workgroup per CU, 7- / 8-block tiles (conv_gemm5.hip) where it applies
     conv6=True,           # one wave per SIMD on the 16x16x32 MFMA, 16 x 13-pixel tiles (conv_gemm6.hip, round 5) where the library rates its fill >= 85 %
+    conv6_pad2x=False,    # conv_gemm6 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 50 us instead of 63 + 117 us of K-sliced launch + reduce, but on the side stream it takes whole CUs from convc2: 35.5 vs 35.4 ms per clip)
     conv5_sliced=False,   # its K-sliced form on the 1/8, 1/16 maps: correct (tests) but slower than conv_gemm2's slicing there
     conv5_gemm=True,      # its GEMM mode for the 256-cout convs without a spatial sweep ((5,1,1) GRU pass, 1x1 heads)
     conv3=True,           # large-map kernel of round 1 (conv_gemm3.hip) where conv_gemm5 does not apply
@@ -542,7 +543,9 @@ class ScaleEngine:
             if m_split is None:
                 d6.m_split = meta6["M"]
             real6 = d6.epi[0].n_valid + (d6.epi[1].n_valid if d6.m_split < d6.M else 0)
-            if 2 * real6 > meta6["M"] and self.lib.ppms_conv_gemm6_applicable(C.byref(d6)) == 1:
+            # (couts filling only half of the padded rows -- convf2's 64 of 128 -- still pay: 3x3 128 -> 64 at the 1/4 scale costs ~45 us here against
+            #  63 + 117 us for conv_gemm2's K-sliced launch + its reduce launch; TUNING["conv6_pad2x"])
+            if (2 * real6 > meta6["M"] or (TUNING["conv6_pad2x"] and 2 * real6 == meta6["M"])) and self.lib.ppms_conv_gemm6_applicable(C.byref(d6)) == 1:
                 return ConvOp(d6, [packed6, bias6, *keep], 8, device=self.dev)
         if not TUNING["conv5"] or wname not in self.pk.w4:
             return None

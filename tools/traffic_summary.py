@@ -36,10 +36,12 @@ attn = summarise("attn", {"mem_attn64_kernel": 3, "mem_attn_kernel": 3, "attn_co
                  "one ppms_mem_attn call at the 1/4 scale (T=5, n=10240, 5 picked frames): attention kernel + fix-up pass + combine kernel, mean of the last 3 calls",
                  157286400)
 json.dump(attn, open(os.path.join(out, "attn_traffic.json"), "w"), indent=1)
-# zr1_0 at the 1/4 scale: activations [h | x] 512 ch + output 256 ch as split bf16 planes (4 B per value), weights 256x512x15 x 4 B, aux reads
+# zr1_0_x at the 1/4 scale as the loop runs it (hoisted block): activations [h | mf, hid] 384 ch in + 256 ch out as split bf16 planes (4 B per value), the
+# hoisted inp share 256 ch fp32 in, weights 256 x 384 x 15 x 4 B
 P = 5 * 80 * 128
-conv_alg = P * (512 + 256) * 4 + 256 * 512 * 15 * 4
-conv = summarise("conv", {"conv5_kernel": 3, "conv3_kernel": 3}, "one zr1_0 launch (1,1,15), 512 -> 256 channels, 5x80x128 pixels; mean of the last 3 launches", conv_alg)
+conv_alg = P * (384 + 256 + 256) * 4 + 256 * 384 * 15 * 4
+conv = summarise("conv", {"conv6_kernel": 3, "conv5_kernel": 3, "conv3_kernel": 3}, "one zr1_0_x launch (1,1,15), [h | mf, hid] 384 -> 256 channels + the hoisted fp32 share, "
+                 "5x80x128 pixels; mean of the last 3 launches", conv_alg)
 json.dump(conv, open(os.path.join(out, "conv_traffic.json"), "w"), indent=1)
 # pyramid build at the 1/4 scale: both feature maps once + the five pyramid levels once (1.9375 P W values)
 corr_alg = int(2 * 256 * P * 4 + 1.9375 * P * 128 * 4)
