@@ -78,6 +78,9 @@ constexpr unsigned CONV6_OOB = 0xFFFFFFF0u;
 #ifndef CONV6_EPI_G
 #define CONV6_EPI_G 2
 #endif
+#ifndef CONV6_XCD_ORDER
+#define CONV6_XCD_ORDER 0      // measured neutral (+-1 % on every 1/4-scale conv, the (3,3,3) flow-head conv -3 %): off; -DCONV6_XCD_ORDER=1 for A/B
+#endif
 #ifndef CONV6_SLACK
 #define CONV6_SLACK 0
 #endif
@@ -104,7 +107,16 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     const int wn = split ? (wave >> 1) : 0;
     const int nbw = split ? (wn ? 6 : 7) : NBT6;
     const int blk0 = wn ? 7 : 0;
+    // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one; each XCD has its own L2): XCD k gets the k-th eighth of the tile
+    // list, so that the x / y neighbours whose windows overlap in their halo columns fetch them through ONE L2 (placement is a speed hint only)
     int tile = blockIdx.x;
+#if CONV6_XCD_ORDER
+    {
+        const int nt = (int)gridDim.x, per = (nt + 7) >> 3, full = nt - 8 * (per - 1);      // XCDs 0 .. full-1 hold `per` tiles, the others per - 1
+        const int xcd = tile & 7, slot = tile >> 3;
+        tile = xcd < full ? xcd * per + slot : full * per + (xcd - full) * (per - 1) + slot;
+    }
+#endif
     const int tx = tile % g.tiles_x;
     tile /= g.tiles_x;
     const int ty = tile % g.tiles_y;
