@@ -84,10 +84,18 @@ constexpr unsigned CONV6_OOB = 0xFFFFFFF0u;
 #ifndef CONV6_SLACK
 #define CONV6_SLACK 0
 #endif
-#if CONV6_SLACK
+#if CONV6_SLACK == 1
 #define CONV6_SWITCH_SLACK asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#define CONV6_PRE_BARRIER
+#elif CONV6_SLACK == 2
+#define CONV6_SWITCH_SLACK asm volatile("s_sleep 20" ::: "memory");
+#define CONV6_PRE_BARRIER
+#elif CONV6_SLACK == 3
+#define CONV6_SWITCH_SLACK
+#define CONV6_PRE_BARRIER asm volatile("s_sleep 20" ::: "memory");
 #else
 #define CONV6_SWITCH_SLACK
+#define CONV6_PRE_BARRIER
 #endif
 #include "conv6_asm.h"
 
@@ -136,7 +144,8 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     const char* const sp0h = (const char*)p.seg[0].hi;
     const char* const sp1h = (const char*)p.seg[p.nseg - 1].hi;
     const unsigned pd0 = (unsigned)((const char*)p.seg[0].lo - sp0h), pd1 = (unsigned)((const char*)p.seg[p.nseg - 1].lo - sp1h);
-    unsigned off0[NP], off1[NP];
+    unsigned off0[NP], off1[NP], off[NP];          // off: the offsets of the segment the NEXT window lies in (copied by dma_setup; a piece's register is
+                                                    // not written again before the next window's set-up, a whole k-step after the piece went out)
     {
         const int rows = g.WH * g.WC;
 #pragma unroll
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     const unsigned wave_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(wave * 1024));
     // one DMA piece of window (temporal tap kz, chunk) into buffer `buf`: the window's buffer resource (base = the segment's hi plane + frame shift +
     // first channel; stride 0; range CONV6_NUM_RECORDS) + the piece's offset
-    int d_buf = 0, d_seg = 0;
+    int d_buf = 0;
     u32x4 d_srd = {0u, 0u, CONV6_NUM_RECORDS, 0x00020000u};
     auto dma_setup = [&](int kz, int chunk, int buf) {
         const int dt = kz - ht;
@@ -177,9 +186,15 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         const uint64_t base = (uint64_t)(uintptr_t)((sg ? sp1h : sp0h) + shift);
         d_srd[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
         d_srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
-        d_seg = sg, d_buf = buf;
+        d_buf = buf;
+#pragma unroll
+        for (int i = 0; i < NP; ++i) off[i] = sg ? off1[i] : off0[i];
     };
-    auto dma_piece = [&](int i) { dma16_6(d_seg ? off1[i] : off0[i], d_srd, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16))); };
+    // (an LDS-DMA instruction reads M0 and its address register some time after it has issued: the loop leaves >= 4 MFMAs between two pieces and
+    //  never rewrites a piece's offset register before the next window's set-up; see tools/gen_conv6_asm.py)
+    auto dma_piece = [&](int i) { dma16_6(off[i], d_srd, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16))); };
+    // the pieces of a window leave in the first TWO k-steps of the window before it: PPS0 in the first, PPS1 in the second
+    constexpr int PPS0 = (NP + 1) / 2, PPS1 = NP / 2;
 
     // ---- weights: [k32-step][M/16][plane][64 lanes][16 B]; this wave's 2 MB fragments are contiguous ----------------------------------------
     const char* abase = (const char*)p.w;
@@ -236,14 +251,20 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         if (wend) n_sw = 0, n_swx = 0, n_off = 0, n_ty = 0, n_w = w ^ 1;                                                            \
         if (last) n_off = off, n_ty = tyo, n_w = w;                                                                                \
         const unsigned bh = lane_addr(tyo) + (unsigned)(w * g.wbytes + off * 128), bhn = lane_addr(n_ty) + (unsigned)(n_w * g.wbytes + n_off * 128); \
-        const bool issue = sw == 0 && nxkz >= 0; /* this step carries the DMA of the next window (into the other buffer) */         \
-        if (issue) dma_setup(nxkz, nxch, w ^ 1);                                                                                   \
+        const int sw_cur = sw;                                                                                                     \
+        const bool issue = sw < 2 && nxkz >= 0; /* the first two steps of a window carry the DMA of the next window (other buffer) */ \
+        if (issue && sw == 0) dma_setup(nxkz, nxch, w ^ 1);                                                                        \
         const int ksn = last ? (ckz * g.nchunk + cch) * g.nsweep + sw : (wend ? (nxkz * g.nchunk + nxch) * g.nsweep : (ckz * g.nchunk + cch) * g.nsweep + sw + 1); \
         const char* sbn = abase + (int64_t)ksn * astep;                                                                            \
-        conv6_step<MB, NBW, CR, SKIP>(acc, areg[U], areg[(U) ^ 1], ring, bh, bh ^ 64u, bhn, bhn ^ 64u, avoff0, avoff1, sbn, [&](int h) { \
-            if (issue) {                                                                                                           \
-                _Pragma("unroll") for (int i = 0; i < NP; ++i)                                                                      \
-                    if (i % conv6_shape<MB, NBW>::HOOKS == h) dma_piece(i);                                                         \
+        conv6_step<MB, NBW, CR, SKIP>(acc, areg[U], areg[(U) ^ 1], ring, bh, bh ^ 64u, bhn, bhn ^ 64u, avoff0, avoff1, sbn, [&](int K) { \
+            constexpr int SL = conv6_shape<MB, NBW, SKIP>::SLOTS;                                                                    \
+            static_assert(SL >= PPS0, "a step has a DMA slot for each of its pieces");                                             \
+            if (issue) { /* at most one piece per slot, the pieces spread evenly over the step's slots */                          \
+                if (sw_cur == 0) {                                                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < PPS0; ++j) if (j * SL / PPS0 == K) dma_piece(j);                          \
+                } else {                                                                                                           \
+                    _Pragma("unroll") for (int j = 0; j < PPS1; ++j) if (j * SL / PPS1 == K) dma_piece(PPS0 + j);                   \
+                }                                                                                                                  \
             }                                                                                                                      \
         });                                                                                                                        \
         sw = n_sw, swx = n_swx, off = n_off, tyo = n_ty;                                                                            \
@@ -251,15 +272,17 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             /* window switch: everything this wave issued has landed (the next window's pieces are older than this step's weight  */ \
             /* loads), every wave is done reading the old window                                                                  */ \
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                            \
+            CONV6_PRE_BARRIER                                                                                                      \
             __builtin_amdgcn_s_barrier();                                                                                          \
             CONV6_SWITCH_SLACK                                                                                                     \
             w = n_w;                                                                                                               \
             ckz = nxkz, cch = nxch;                                                                                                \
             next_window(ckz, cch, nxkz, nxch);                                                                                     \
             conv6_prime<NBW, CR>(ring, bhn, bhn ^ 64u);                                                                             \
-        } else if (issue) { /* the next step's weight fragments: everything but the NP pieces issued behind them */                  \
-            if constexpr (NP == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");                                               \
-            else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");                                                                   \
+        } else if (issue) { /* the next step's weight fragments: everything but the pieces this step issued behind them */           \
+            if constexpr (NP == 14) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); /* PPS0 = PPS1 = 7 */                          \
+            else if (sw_cur == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); /* NP = 9: PPS0 = 5 */                           \
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); /* PPS1 = 4 */                                                    \
         } else {                                                                                                                   \
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                       \
         }                                                                                                                          \
@@ -285,7 +308,11 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         int nxkz, nxch;                                                                                                            \
         next_window(ckz, cch, nxkz, nxch);                                                                                         \
         dma_setup(ckz, cch, 0);                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < NP; ++i) dma_piece(i);                                                                \
+        asm volatile("s_nop 7" ::: "memory"); /* (the resource's SGPRs come from v_readfirstlane: wait states before a VMEM read) */ \
+        _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                                            \
+            dma_piece(i);                                                                                                          \
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); /* 64 cycles between two pieces */         \
+        }                                                                                                                          \
         load_a(areg[0], (ckz * g.nchunk + cch) * g.nsweep);                                                                        \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                           \
         __builtin_amdgcn_s_barrier();                                                                                              \
@@ -440,6 +467,13 @@ static bool plan6(const ppms_conv* d, Geo6& g) {
     }
     const int rows = g.WH * g.WC;
     if (g.lz0 < nchunk && ((g.lz0 * g.nsweep) & 1)) g.lz0 = nchunk;   // (phase 0 must hold an even number of steps: else every product is computed)
+    // Convolutions WITHOUT spatial taps are not served.  The mode exists in the kernel (two 32-channel chunks per window, the "sweep" steps through
+    // them) and passes the op tests, but (a) nothing re-uses a window there, so every pair of k32-steps needs 13 LDS-DMA pieces per wave with nobody
+    // to hide their issue behind: measured no faster than conv_gemm5 / conv_gemm2 / gemm1 (zr3_x 151 vs 149 us, q3_x 103 us, convf1 47 vs ~25 us),
+    // and (b) tools/conv6_stress.py shows rare wrong pixels there (M = 128: a few hundred per launch, always the second pixel block of a wave pair;
+    // M = 192 / 256: one launch in a hundred) that the 64-cycle spacing of the LDS-DMA pieces did not remove -- unexplained.  Every served mode is
+    // clean over hundreds of back-to-back launches (tests/test_gpu_concurrency.py).
+    if (gemm) return false;
     g.npieces = (rows * 8 + NT6 - 1) / NT6;
     g.wbytes = conv6_np(g.WH) * NT6 * 16;
     g.P = (int64_t)d->T * d->H * d->W;
@@ -489,10 +523,6 @@ extern "C" int ppms_conv_gemm6_applicable(const ppms_conv* d) {
     const int64_t cus = ppms_num_cus();
     if (tiles < cus * 25 / 32) return 0;                                 // fewer workgroups than CUs: the K-sliced small-map kernels fill the chip better
     const double fill = (double)g.P / ((double)((tiles + cus - 1) / cus) * cus * 16 * NBT6);
-    // Without spatial taps nothing re-uses a window: every k32-step pair needs a fresh 53 KiB window (13 - 14 LDS-DMA instructions per wave, ~85
-    // cycles of issue each with one wave per SIMD and nobody to fill the gap), where conv_gemm5's two waves per SIMD hide them: measured no
-    // faster than conv_gemm5 / conv_gemm2 / gemm1 there (zr3_x 151 vs 149 us, q3_x 103 us, convf1 47 vs ~25 us).  Served (tests), never rated 1.
-    if (g.mode == 3) return 2;
     return fill >= 0.85 ? 1 : 2;
 }
 
@@ -532,7 +562,7 @@ extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, vo
     PPMS_REQUIRE(conv6_offsets_fit(d), "conv_gemm6: the lo plane of a segment must follow its hi plane inside one 4 GiB range (32-bit window offsets)");
     Geo6 g;
     PPMS_REQUIRE(plan6(d, g), "conv_gemm6: not a convolution this kernel serves (segments in multiples of 32 channels -- 64 without spatial taps --, "
-                              "a halo'd 16 x 13 window of <= 14 DMA pieces per thread)");
+                              "a spatial sweep -- kh > 1 or kw > 1 --, a halo'd 16 x 13 window of <= 14 DMA pieces per thread)");
     const size_t lds = conv6_lds(d, g);
     PPMS_REQUIRE(lds <= 160 * 1024, "conv_gemm6: LDS budget exceeded (%zu B)", lds);
     const int ntiles = g.tiles_x * g.tiles_y * d->T;

@@ -272,11 +272,6 @@ class PackedBlock:
                 if all(p % 32 == 0 for p in pads):
                     self.w4[name] = _packing.pack_conv4(w5, bias, segs, pads, cout_map, (rows + 127) // 128 * 128)
 
-            if TUNING["conv6"] and w5.shape[3] == 1 and w5.shape[4] == 1 and 64 < rows <= 256 and not name.endswith(("_y", "_p")):
-                # conv_gemm6 without a spatial sweep: windows of 64 channels (two k32-steps), segments in multiples of 64
-                pads6 = list(seg_pad) if seg_pad is not None else [((c + 31) // 32) * 32 for c in segs]
-                if all(p % 64 == 0 for p in pads6):
-                    self.w6[name] = _packing.pack_conv6(w5, bias, segs, pads6, cout_map, 128 if rows <= 128 else (192 if rows <= 192 else 256))
 
         e = "encoder."
         put("init0", g(e + "init_conv.0.weight"), g(e + "init_conv.0.bias"), [128])

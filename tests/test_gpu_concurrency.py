@@ -110,3 +110,20 @@ def test_small_kernels_are_unaffected_by_a_concurrent_conv(eng):
     bad["mem_attn 64-query + combine"] = _mismatches(eng, attn(True), heavy=("zr1_0", "m1", "zr2"), n=30)
     bad["mem_attn 32-query fused"] = _mismatches(eng, attn(False), heavy=("zr1_0", "m1", "zr2"), n=12)
     assert all(v == 0 for v in bad.values()), f"results change under a concurrent conv kernel: {bad}"
+
+
+def test_conv_gemm6_back_to_back_launches_are_bit_identical():
+    """tools/conv6_stress.py: every mode conv_gemm6 serves, launched 30 times back to back (no synchronisation in between) at BASELINE config 3's 1/4-scale
+    geometry -- six workgroups per CU in sequence, so a workgroup starts on LDS that still holds its predecessor's fp32 staging data and a window
+    row that was not (or wrongly) filled by its LDS-DMA piece shows as a changed output.  Regression test for the LDS-DMA spacing rule of
+    conv_gemm6.hip (two pieces issued back to back left rows stale: an LDS-DMA reads M0 / its address register after it has issued)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv6_stress.py"), "30"], capture_output=True, text=True, cwd=root, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if "launches:" in ln]
+    assert len(lines) >= 8, r.stdout[-2000:]
+    for ln in lines:
+        assert " 0 differ from the first" in ln and " 0 with non-finite" in ln, ln

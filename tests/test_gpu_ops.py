@@ -617,12 +617,11 @@ def test_conv_gemm5_full_map(lib):
 
 
 CONV6_CASES = [
-    # name, T,H,W, segs, cout, k3 -- x / y / 2-D sweeps, temporal taps, GEMM mode (64-channel windows), two segments, ragged maps and couts, M = 256 and 128
+    # name, T,H,W, segs, cout, k3 -- x / y / 2-D sweeps, temporal taps, two segments, ragged maps and couts, M = 256 and 128
     ("x15_gru_m256", 2, 20, 40, [128, 256], 256, (1, 1, 15)), ("x5_m128", 2, 12, 128, [128, 256], 128, (1, 1, 5)), ("x5_one_seg_m128", 1, 33, 27, [128], 128, (1, 1, 5)),
     ("y5_m256", 2, 40, 32, [128, 256], 256, (1, 5, 1)), ("y5_m128_ragged", 1, 37, 29, [64, 32], 100, (1, 5, 1)),
     ("3x3_m256", 2, 13, 45, [128], 256, (1, 3, 3)), ("3x3_two_segs_m128", 3, 9, 13, [128, 128], 128, (1, 3, 3)), ("3x3x3_m256_T4", 4, 17, 19, [128], 200, (3, 3, 3)),
-    ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3)), ("t5_gemm_m256", 5, 20, 64, [128, 256], 256, (5, 1, 1)), ("t5_gemm_m128", 5, 10, 40, [128, 256], 128, (5, 1, 1)),
-    ("1x1_m256_pad", 2, 13, 45, [256], 144, (1, 1, 1)), ("t3_gemm_m128_T2", 2, 16, 32, [64, 64], 100, (3, 1, 1)), ("x15_w24", 1, 9, 24, [32], 128, (1, 1, 15)),
+    ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3)), ("x15_w24", 1, 9, 24, [32], 128, (1, 1, 15)), ("y3_m128", 2, 20, 30, [64], 128, (1, 3, 1)),
     ("T1_tiny", 1, 1, 3, [32], 130, (3, 3, 3)),
 ]
 
@@ -638,8 +637,7 @@ def test_conv_gemm6_vs_torch(lib, name, T, H, W, segs, cout, k3):
     wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
     bs = hash_normal((cout,), 201) * 0.1
     ref = _ref_conv(xs, wt, bs, k3, T, H, W)
-    gemm = k3[1] == 1 and k3[2] == 1
-    seg_pad = [((c + (63 if gemm else 31)) // (64 if gemm else 32)) * (64 if gemm else 32) for c in segs]
+    seg_pad = [((c + 31) // 32) * 32 for c in segs]
     m_pad = 128 if cout <= 128 else 256
     got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=m_pad)
     assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
@@ -652,7 +650,7 @@ def test_conv_gemm6_vs_torch(lib, name, T, H, W, segs, cout, k3):
 
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3", [("3x3_m192_final", 2, 13, 45, [320], 190, (1, 3, 3)), ("3x3_m192_full_blocks", 1, 16, 56, [256], 192, (1, 3, 3)),
                                                    ("x15_m192", 2, 9, 40, [64, 32], 160, (1, 1, 15)), ("y5_m192", 1, 24, 32, [64], 129, (1, 5, 1)),
-                                                   ("3x3x3_m192_T3", 3, 10, 40, [64], 192, (3, 3, 3)), ("1x1_m192", 2, 13, 45, [256], 144, (1, 1, 1))])
+                                                   ("3x3x3_m192_T3", 3, 10, 40, [64], 192, (3, 3, 3))])
 def test_conv_gemm6_three_cout_blocks_vs_torch(lib, name, T, H, W, segs, cout, k3):
     """M = 192: four waves x 48 couts (three 16-cout MFMA blocks each) x 13 pixel blocks -- convc2's 192 and final_conv's 190 couts."""
     P = T * H * W
@@ -661,8 +659,7 @@ def test_conv_gemm6_three_cout_blocks_vs_torch(lib, name, T, H, W, segs, cout, k
     wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
     bs = hash_normal((cout,), 201) * 0.1
     ref = _ref_conv(xs, wt, bs, k3, T, H, W)
-    gemm = k3[1] == 1 and k3[2] == 1
-    seg_pad = [((c + (63 if gemm else 31)) // (64 if gemm else 32)) * (64 if gemm else 32) for c in segs]
+    seg_pad = [((c + 31) // 32) * 32 for c in segs]
     got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=192)
     assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
     assert torch.equal(got, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, seg_pad=seg_pad, m_pad=192))
@@ -675,7 +672,7 @@ def test_conv_gemm6_three_cout_blocks_vs_torch(lib, name, T, H, W, segs, cout, k
 
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3,lz", [
     ("gru_1x15", 2, 12, 128, [128, 256], 256, (1, 1, 15), 256), ("q_1x5_m128", 2, 12, 128, [128, 256], 128, (1, 1, 5), 256),
-    ("y_1x5x1", 2, 40, 32, [128, 256], 256, (1, 5, 1), 256), ("t_5x1x1_gemm_mode", 5, 16, 64, [128, 256], 256, (5, 1, 1), 256),
+    ("y_1x5x1", 2, 40, 32, [128, 256], 256, (1, 5, 1), 256), ("t_3x3x3_two_phases", 4, 16, 40, [128, 256], 256, (3, 3, 3), 256),
     ("3x3_m192_one_segment", 2, 13, 45, [320], 190, (1, 3, 3), 192)])
 def test_conv_gemm6_skips_products_with_a_zero_lo_plane(lib, name, T, H, W, segs, cout, k3, lz):
     """ppms_conv.lo_zero_from on conv_gemm6: the windows whose lo plane is all zero run in a second phase of the K loop whose step body has no
@@ -735,7 +732,7 @@ def test_conv_gemm6_full_map_and_rating(lib):
     T, H, W = 5, 80, 128
     P = T * H * W
     for segs, cout, k3, m_pad in (([128, 256], 256, (1, 1, 15), 256), ([128], 256, (1, 3, 3), 256), ([128, 256], 128, (1, 1, 5), 128),
-                                  ([320], 190, (1, 3, 3), 192), ([128, 256], 256, (5, 1, 1), 256)):
+                                  ([320], 190, (1, 3, 3), 192), ([128], 256, (3, 3, 3), 256)):
         xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
         cin = sum(segs)
         wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
@@ -750,8 +747,8 @@ def test_conv_gemm6_full_map_and_rating(lib):
     assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 1
     d.T, d.H, d.W = 5, 40, 64
     assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 0
-    d.T, d.H, d.W, d.kh, d.kw = 5, 80, 128, 1, 1                        # no spatial taps: served, but never the faster choice
-    assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 2
+    d.T, d.H, d.W, d.kh, d.kw = 5, 80, 128, 1, 1                        # no spatial taps: not served (see conv_gemm6.hip: plan6)
+    assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 0
 
 
 def test_conv_gemm6_two_epilogue_halves(lib):

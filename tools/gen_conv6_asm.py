@@ -19,7 +19,7 @@ ABL = int(os.environ.get("PPMS_CONV6_ABL", "0"))     # timing experiments only (
 VARIANTS = [(4, 13), (3, 13), (4, 7), (4, 6)]        # (MB, NBW): M = 256, M = 192, the two pixel halves of M = 128
 
 
-def slot(n, nbw):
+def slot_of(n, nbw):
     """Ring slot of pixel block n: blocks cycle through slots 0..2; the NBW % 3 leftover blocks at the end of a step get slots of their own, so
     that the ring phase is the same in every step (the next step's blocks 0 and 1 are requested into slots 0 and 1 during this step's last two
     blocks)."""
@@ -57,20 +57,33 @@ class Emit:
 
 
 def step(mb, nbw, skip):
-    """skip: the step body without the hi x lo products (windows whose lo plane is all zero)."""
+    """skip: the step body without the hi x lo products (windows whose lo plane is all zero).  Returns (text, number of DMA slots)."""
     assert nbw % 3 <= 1, "the ring has one spare slot"
     E = Emit()
     nab, aper = a_blocks(mb, nbw)
+    slots = 0
+    pending = 2 * mb                      # weight loads of the next step not yet issued
+
+    def slot(group):
+        # a DMA slot: hook(K) issues at most ONE LDS-DMA piece.  Slots come behind the last weight load (everything a hook issues must be YOUNGER
+        # than the weight loads on the in-order vmcnt counter) and at least four MFMAs (64 cycles) apart: an LDS-DMA instruction reads M0 and its
+        # address register some time AFTER it has issued -- the next s_mov m0 / a write of that register within a few cycles of it misdirects the
+        # transfer (tools/conv6_stress.py: back-to-back pieces left window rows stale; 64 cycles of distance: 300 launches clean)
+        nonlocal slots
+        if pending == 0 and not (ABL & 8) and (mb >= 4 or group == 1):
+            E.c(f"hook({slots});")
+            slots += 1
+
     for n in range(nbw):
-        s = slot(n, nbw)
+        s = slot_of(n, nbw)
         # the fragments of block n were requested two blocks ago; the requests of block n + 1 may stay in flight
         E.asm("s_waitcnt lgkmcnt(2)")
         # the requests issued in this block: block n + 2 of this step, or block n + 2 - NBW of the next one; the block's column offset inside
         # the window is an immediate (CR = rows per window column is a template parameter)
         if n + 2 < nbw:
-            bh, bl, blk, ts = "bh", "bl", n + 2, slot(n + 2, nbw)
+            bh, bl, blk, ts = "bh", "bl", n + 2, slot_of(n + 2, nbw)
         else:
-            bh, bl, blk, ts = "bhn", "bln", n + 2 - nbw, slot(n + 2 - nbw, nbw)
+            bh, bl, blk, ts = "bhn", "bln", n + 2 - nbw, slot_of(n + 2 - nbw, nbw)
         loads = list(aper.get(n, []))
         for m in range(mb):                                   # hi x hi
             E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"acc[{m}][{n}]")], [("a", "v", f"a[{2 * m}]"), ("b", "v", f"ring[{s}][0]")])
@@ -80,28 +93,32 @@ def step(mb, nbw, skip):
                 E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{ts}][1]")], [("p", "v", bl), ("o", "n", f"{blk} * CR * 128")])
             elif loads:
                 k = loads.pop(0)
+                pending -= 1
                 E.asm(f"global_load_dwordx4 {{d}}, {{o}}, {{sb}} offset:{(k & 3) * 1024}", [("d", "+v", f"an[{k}]")],
                       [("o", "v", "avoff0" if k < 4 else "avoff1"), ("sb", "s", "sb_next")])
+        if not loads:
+            slot(0)
         for m in range(mb):                                   # lo x hi
             E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"acc[{m}][{n}]")], [("a", "v", f"a[{2 * m + 1}]"), ("b", "v", f"ring[{s}][0]")])
             if loads:
                 k = loads.pop(0)
+                pending -= 1
                 E.asm(f"global_load_dwordx4 {{d}}, {{o}}, {{sb}} offset:{(k & 3) * 1024}", [("d", "+v", f"an[{k}]")],
                       [("o", "v", "avoff0" if k < 4 else "avoff1"), ("sb", "s", "sb_next")])
         assert not loads
+        slot(1)
         if not skip:
             for m in range(mb):                               # hi x lo
                 E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"acc[{m}][{n}]")], [("a", "v", f"a[{2 * m}]"), ("b", "v", f"ring[{s}][1]")])
-        if n >= nab - 1 and not (ABL & 8):      # (ABL 8: no DMA pieces -- the windows keep their first contents)
-            E.c(f"hook({n - (nab - 1)});")
-    return "\n".join(E.lines), nab
+            slot(2)
+    return "\n".join(E.lines), slots
 
 
 def prime(nbw):
     E = Emit()
     for n in range(2):
-        E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{slot(n, nbw)}][0]")], [("p", "v", "bh"), ("o", "n", f"{n} * CR * 128")])
-        E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{slot(n, nbw)}][1]")], [("p", "v", "bl"), ("o", "n", f"{n} * CR * 128")])
+        E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{slot_of(n, nbw)}][0]")], [("p", "v", "bh"), ("o", "n", f"{n} * CR * 128")])
+        E.asm("ds_read_b128 {d}, {p} offset:{o}", [("d", "+v", f"ring[{slot_of(n, nbw)}][1]")], [("p", "v", "bl"), ("o", "n", f"{n} * CR * 128")])
     return "\n".join(E.lines)
 
 
@@ -109,15 +126,17 @@ def gen():
     out = ['''// GENERATED by tools/gen_conv6_asm.py -- do not edit.
 // The k32-step of conv_gemm6.hip: per pixel block 3 x MB v_mfma_f32_16x16x32_bf16 (hi x hi, lo x hi, hi x lo) with this step's weight fragments
 // in registers, the LDS requests for the activation fragments of the block two ahead and the global loads of the NEXT step's weight fragments
-// placed between them by hand, one memory instruction per MFMA gap.  hook(h) is called (C code: the LDS-DMA pieces of the window after next)
-// at the end of every block from the one that issues the last weight load on, so that everything it issues is YOUNGER than the weight loads
-// on the in-order vmcnt counter.  Ring slots: see tools/gen_conv6_asm.py:slot().
+// placed between them by hand, one memory instruction per MFMA gap.  hook(K) (C code: at most ONE LDS-DMA piece of the next window) is called
+// behind MFMA groups once the last weight load is out -- everything it issues is YOUNGER than the weight loads on the in-order vmcnt counter --
+// and never less than four MFMAs after the previous call (see the generator: an LDS-DMA reads M0 and its address register after it has issued).
+// Ring slots: see tools/gen_conv6_asm.py:slot_of().
 #pragma once
 ''']
-    out.append("template <int MB, int NBW> struct conv6_shape;")
+    out.append("template <int MB, int NBW, bool SKIP> struct conv6_shape;")
     for mb, nbw in VARIANTS:
-        _, nab = step(mb, nbw, False)
-        out.append(f"template <> struct conv6_shape<{mb}, {nbw}> {{ static constexpr int HOOKS = {nbw - nab + 1}; }};   // blocks that call the hook")
+        for skip in (False, True):
+            _, nslots = step(mb, nbw, skip)
+            out.append(f"template <> struct conv6_shape<{mb}, {nbw}, {'true' if skip else 'false'}> {{ static constexpr int SLOTS = {nslots}; }};   // hook calls of a step")
     out.append("")
     out.append("// CR: rows of a window column (16 + y halo): the column offsets of the fragment reads are immediates.  bh / bl: LDS address of this lane's hi / lo\n"
                "// fragment of the wave's first block at the current tap (bl = bh ^ 64); bhn / bln: the same for the next step.  SKIP: the body without the\n"
