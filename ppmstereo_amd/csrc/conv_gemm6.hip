@@ -78,6 +78,9 @@ constexpr unsigned CONV6_OOB = 0xFFFFFFF0u;
 #ifndef CONV6_EPI_G
 #define CONV6_EPI_G 2
 #endif
+#ifndef CONV6_ABL_NOWAIT_A
+#define CONV6_ABL_NOWAIT_A 0
+#endif
 #ifndef CONV6_XCD_ORDER
 #define CONV6_XCD_ORDER 0      // measured neutral (+-1 % on every 1/4-scale conv, the (3,3,3) flow-head conv -3 %): off; -DCONV6_XCD_ORDER=1 for A/B
 #endif
@@ -279,6 +282,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             ckz = nxkz, cch = nxch;                                                                                                \
             next_window(ckz, cch, nxkz, nxch);                                                                                     \
             conv6_prime<NBW, CR>(ring, bhn, bhn ^ 64u);                                                                             \
+        } else if (CONV6_ABL_NOWAIT_A) { /* timing experiment (wrong results): no wait for the next step's weight fragments */      \
         } else if (issue) { /* the next step's weight fragments: everything but the pieces this step issued behind them */           \
             if constexpr (NP == 14) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); /* PPS0 = PPS1 = 7 */                          \
             else if (sw_cur == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); /* NP = 9: PPS0 = 5 */                           \

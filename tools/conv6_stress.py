@@ -10,10 +10,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import ab_switches  # noqa: F401  (PPMS_LIB: another build of the library)
 from ppmstereo_amd import _lib as L
 from ppmstereo_amd.engine import ConvOp, epilogue
-from ppmstereo_amd.packing import pack_conv6
+from ppmstereo_amd.packing import pack_conv4, pack_conv6
 from ppmstereo_amd.weights import hash_normal
 DEV = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+VER = int(os.environ.get("VERSION", "8"))          # 8: conv_gemm6 (default), 5: conv_gemm5 (the same stress on the older kernel)
 T, H, W = (int(x) for x in os.environ.get("PROBE_SHAPE", "5,184,320").split(","))
 P = T * H * W
 L.load()
@@ -36,7 +37,7 @@ for name, segs, cout, k3 in cases:
         w5 = wt.reshape(cout, cin, k3[0], 1, k3[1] * k3[2])
     elif k3[1] > 1:
         w5 = wt.transpose(3, 4).contiguous()
-    packed, b, meta = pack_conv6(w5.to(DEV), (hash_normal((cout,), 201) * 0.1).to(DEV), segs, segs, None, 128 if cout <= 128 else 192 if cout <= 192 else 256)
+    packed, b, meta = (pack_conv6 if VER == 8 else pack_conv4)(w5.to(DEV), (hash_normal((cout,), 201) * 0.1).to(DEV), segs, segs, None, 128 if cout <= 128 else 192 if cout <= 192 else 256)
     outs = [L.SPTensor(P, meta['M'], DEV) for _ in range(2)]
     ops = []
     for o in outs:
@@ -48,7 +49,7 @@ for name, segs, cout, k3 in cases:
         d.kt, d.kh, d.kw = k3
         d.M = d.m_split = meta["M"]
         d.epi[0] = epilogue(act=L.ACT_RELU, n_valid=cout, out_sp=o.view())
-        ops.append(ConvOp(d, [packed, b, o] + xs, 8))
+        ops.append(ConvOp(d, [packed, b, o] + xs, VER))
     ops[0]()
     torch.cuda.synchronize()
     ref = outs[0].data.clone()

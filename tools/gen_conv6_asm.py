@@ -15,7 +15,7 @@ import os
 
 MF = "v_mfma_f32_16x16x32_bf16"
 ABL = int(os.environ.get("PPMS_CONV6_ABL", "0"))     # timing experiments only (wrong results): 1 drops the LDS fragment reads and their waits,
-                                                     # 2 the weight-fragment loads, 4 the MFMAs, 8 the LDS-DMA pieces of the loop
+                                                     # 2 the weight-fragment loads, 4 the MFMAs, 8 the LDS-DMA pieces of the loop, 32 the waits for the LDS fragment reads (the reads stay)
 VARIANTS = [(4, 13), (3, 13), (4, 7), (4, 6)]        # (MB, NBW): M = 256, M = 192, the two pixel halves of M = 128
 
 
@@ -43,7 +43,7 @@ class Emit:
 
     def asm(self, text, outs=(), ins=(), clob='"memory"'):
         op = text.split()[0]
-        if (ABL & 1 and (op == "ds_read_b128" or "lgkmcnt" in text)) or (ABL & 2 and op == "global_load_dwordx4") or (ABL & 4 and MF in text):
+        if (ABL & 32 and "lgkmcnt" in text) or (ABL & 1 and (op == "ds_read_b128" or "lgkmcnt" in text)) or (ABL & 2 and op == "global_load_dwordx4") or (ABL & 4 and MF in text):
             return
         ops = list(outs) + list(ins)
         for i, (nm, _, _) in enumerate(ops):

@@ -40,7 +40,7 @@ json.dump(attn, open(os.path.join(out, "attn_traffic.json"), "w"), indent=1)
 # hoisted inp share 256 ch fp32 in, weights 256 x 384 x 15 x 4 B
 P = 5 * 80 * 128
 conv_alg = P * (384 + 256 + 256) * 4 + 256 * 384 * 15 * 4
-conv = summarise("conv", {"conv6_kernel": 3, "conv5_kernel": 3, "conv3_kernel": 3}, "one zr1_0_x launch (1,1,15), [h | mf, hid] 384 -> 256 channels + the hoisted fp32 share, "
+conv = summarise("conv", {"conv6_kernel": 3}, "one zr1_0_x launch (1,1,15), [h | mf, hid] 384 -> 256 channels + the hoisted fp32 share, "
                  "5x80x128 pixels; mean of the last 3 launches", conv_alg)
 json.dump(conv, open(os.path.join(out, "conv_traffic.json"), "w"), indent=1)
 # pyramid build at the 1/4 scale: both feature maps once + the five pyramid levels once (1.9375 P W values)
