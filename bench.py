@@ -146,7 +146,7 @@ def dry_run(args, D, rank, world):
         torch.distributed.destroy_process_group()
 
 
-SINGLE_GPU_T40_MS = 542.0     # one T=40 window at 320x512, iters=20 on ONE MI355X (profiles/r04_bench_T40_320x512_iters20_single_gpu.json)
+SINGLE_GPU_T40_MS = 495.4     # one T=40 window at 320x512, iters=20 on ONE MI355X (profiles/r05_bench_T40_320x512_iters20_single_gpu.json; round 4: 542)
 
 
 def sharded_phase(args, D, model, rank, world, dev):
@@ -193,7 +193,8 @@ def sharded_phase(args, D, model, rank, world, dev):
     assert torch.isfinite(d_sh).all()
     cfg4 = (T, H, W, iters) == (40, 320, 512, 20)
     out = dict(T=T, H=H, W=W, iters=iters, frames_per_gpu=shard.f, steps=args.sharded_steps, ms_per_window=round(ms, 3), px_per_s=round(T * H * W / (ms * 1e-3), 1),
-               scaling="strong", vs_single_gpu_542ms=(round(SINGLE_GPU_T40_MS / ms, 3) if cfg4 else None),
+               scaling="strong", vs_single_gpu_495ms=(round(SINGLE_GPU_T40_MS / ms, 3) if cfg4 else None), vs_single_gpu_542ms=(round(542.0 / ms, 3) if cfg4 else None),
+               single_gpu_ms_reference=(SINGLE_GPU_T40_MS if cfg4 else None),
                exchanges_per_iteration="6 (7 at the 1/16 scale): values + confidences (direct all-gather), +-2 frames of x (async), of h, of r*h, +-1 frame of the "
                                        "hidden state and of the flow-head taps; keys + frame descriptors once per scale",
                backend=torch.distributed.get_backend(),
