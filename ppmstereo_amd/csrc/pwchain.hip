@@ -339,7 +339,138 @@ __global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// convf1 of the motion encoder (/root/reference/models/core/ppmtereo_update.py:62,87: Conv2d(2, 128, 7, padding=3) + relu on the flow) as ONE
+// launch: the 7x7x2 im2col rows [tap * 2 + c] (98 of 128 k values) of a 64-pixel tile are built in LDS straight from the fp32 flow -- in the
+// split-bf16 MFMA B-operand layout the chains above use -- and multiplied with the 1x1-packed weights (pack_conv2, 4 k-steps x 2 cout blocks).
+// Before, flow_patch7_kernel wrote the im2col tensor to memory (26 MB of 2-byte stores at the 1/4 scale) for an implicit-GEMM launch to read back.
+// Same arithmetic per output element (k order, split products, fp32 accumulate) as that pair of launches.
+constexpr int FC_TP = 64;                     // pixels per workgroup
+constexpr int FC_PLANE = FC_TP * ROWB;        // one 32-channel k-step of one plane: 4 KiB
+constexpr int FC_ACT = 4 * 2 * FC_PLANE;      // [kstep 4][plane 2][64 px][64 B] = 32 KiB
+constexpr int FC_W = 4 * 8192;                // one 64-cout block, K = 128: [kstep 4][plane 2][64][64 B] = 32 KiB
+constexpr int FC_STG = 2 * FC_TP * 128;       // output staging [plane][64 px][64 couts] = 16 KiB          (80 KiB: two workgroups per CU)
+
+__global__ __launch_bounds__(256) void flow_conv7_kernel(const float* __restrict__ flow, const char* __restrict__ w, const float* __restrict__ bias,
+                                                         ppms_sp out, int H, int W, int64_t P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* act = smem;
+    char* wsm = smem + FC_ACT;
+    char* stg = smem + FC_ACT + FC_W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t p0 = (int64_t)blockIdx.x * FC_TP;
+    u32x4 wreg[8];                            // the next cout block's weights: 32 KiB / 256 threads
+    auto load_w = [&](int mblk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = tid + i * 256;
+            const int ks = q >> 9, rem = q & 511;                 // 512 pieces (8 KiB) per k-step and cout block
+            wreg[i] = gload16(w + ((int64_t)(ks * 2 + mblk) * 512 + rem) * 16);
+        }
+    };
+    load_w(0);
+    {   // im2col: lane = pixel, a wave owns the 16-byte pieces (8 k values = 4 taps x 2 channels) wave, wave + 4, ... of every pixel row
+        const int64_t pix = p0 + lane;
+        const bool live = pix < P;
+        const int px = live ? (int)(pix % W) : 0, py = live ? (int)((pix / W) % H) : 0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int ch = __builtin_amdgcn_readfirstlane(wave + 4 * it);
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int tap = ch * 4 + i;
+                const int ky = tap / 7, kx = tap - ky * 7;
+                const int xx = px + kx - 3, yy = py + ky - 3;
+                float2 f = {0.0f, 0.0f};
+                if (tap < 49 && live && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H)
+                    f = *(const float2*)(flow + (pix + (int64_t)(ky - 3) * W + (kx - 3)) * 2);
+                v[2 * i] = f.x;
+                v[2 * i + 1] = f.y;
+            }
+            bf16x8 oh, ol;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16_t hh, ll;
+                split_bf16(v[j], hh, ll);
+                oh[j] = hh;
+                ol[j] = ll;
+            }
+            const int off = (ch >> 2) * 2 * FC_PLANE + swzp(lane, ch & 3);
+            *(bf16x8*)(act + off) = oh;
+            *(bf16x8*)(act + FC_PLANE + off) = ol;
+        }
+    }
+    const int mb = wave & 1, ph = wave >> 1;          // wave: couts [32 mb, 32 mb + 32) of the block x pixels [32 ph, 32 ph + 32)
+    for (int mblk = 0; mblk < 2; ++mblk) {
+        __syncthreads();                              // im2col rows written / the previous block's readers of wsm are done
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *(u32x4*)(wsm + (tid + i * 256) * 16) = wreg[i];
+        if (mblk == 0) load_w(1);
+        __syncthreads();
+        f32x16 acc = (f32x16){0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int k16 = 0; k16 < 2; ++k16) {
+                const int boff = ks * 2 * FC_PLANE + swzp(ph * 32 + r, 2 * k16 + h);
+                const bf16x8 bh = *(const bf16x8*)(act + boff), bl = *(const bf16x8*)(act + FC_PLANE + boff);
+                const int aoff = ks * 8192 + swzp(mb * 32 + r, 2 * k16 + h);
+                const bf16x8 ah = *(const bf16x8*)(wsm + aoff), al = *(const bf16x8*)(wsm + 4096 + aoff);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+        // epilogue: lane = pixel 32 ph + r, couts cl = 32 mb + 8 g + 4 h + j of the block -> staging rows of 128 B per pixel and plane (16-byte
+        // pieces rotated by the pixel index, so that the 32 rows a wave writes spread over the banks)
+        const int spx = ph * 32 + r;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = mb * 32 + 8 * g + 4 * h;
+            const f32x4 b4 = gld<f32x4>(bias + mblk * 64 + cl);
+            bf16x4 oh, ol;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y = acc[4 * g + j] + b4[j];
+                y = y < 0.0f ? 0.0f : y;
+                bf16_t hh, ll;
+                split_bf16(y, hh, ll);
+                oh[j] = hh;
+                ol[j] = ll;
+            }
+            const int so = spx * 128 + ((((cl >> 3) ^ spx) & 7) << 4) + (cl & 7) * 2;
+            *(bf16x4*)(stg + so) = oh;
+            *(bf16x4*)(stg + FC_TP * 128 + so) = ol;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                 // 64 px x 2 planes x 8 pieces
+            const int qd = tid + i * 256;
+            const int opx = qd >> 4, plane = (qd >> 3) & 1, ch = qd & 7;
+            const int64_t opix = p0 + opx;
+            if (opix < P) {
+                const u32x4 v = *(const u32x4*)(stg + plane * FC_TP * 128 + opx * 128 + (((ch ^ opx) & 7) << 4));
+                gstore16((bf16_t*)(plane ? out.lo : out.hi) + opix * out.ld + mblk * 64 + ch * 8, v);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int ppms_flow_conv7(const float* flow_nhwc, const void* w_packed, const float* bias, ppms_sp out, int BT, int H, int W, void* stream) {
+    PPMS_REQUIRE(flow_nhwc && w_packed && bias && out.hi && out.lo, "flow_conv7: null argument");
+    PPMS_REQUIRE(out.c == 128 && out.ld % 8 == 0 && out.ld >= 128 && ((uintptr_t)out.hi & 15) == 0 && ((uintptr_t)out.lo & 15) == 0,
+                 "flow_conv7: the output view must hold 128 channels (ld a multiple of 8, 16-byte aligned)");
+    PPMS_REQUIRE(BT > 0 && H > 0 && W > 0, "flow_conv7: bad map %dx%dx%d", BT, H, W);
+    constexpr size_t lds = FC_ACT + FC_W + FC_STG;
+    static ppms_device_once once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)flow_conv7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FC_ACT + FC_W + FC_STG)); });
+    const int64_t P = (int64_t)BT * H * W;
+    hipLaunchKernelGGL(flow_conv7_kernel, dim3(ceil_div(P, FC_TP)), dim3(256), lds, (hipStream_t)stream, flow_nhwc, (const char*)w_packed, bias, out, H, W, P);
+    return ppms_check_launch("flow_conv7");
+}
 
 extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
     PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");

@@ -50,6 +50,9 @@ TUNING = dict(
     stream_hint=0,        # its tile: 0 = the library chooses, 1 / 2 = 32- / 64-pixel tiles
     hid_exact=True,       # hoisted blocks: the GRU convs read [h | mf, hid] with weights (W_mf + W_mfg | beta W_mfg) instead of [h | mf, mfg]; hid is a
                           # bf16 tensor (all-zero lo plane), so the products with that plane are skipped (ppms_conv.lo_zero_from)
+    flow_conv7=False,     # convf1 as one launch building its 7x7 im2col rows in LDS (pwchain.hip: flow_conv7_kernel) instead of flow_patch7 + a 1x1 GEMM launch:
+                          # 26 + 36 us -> one launch at the 1/4 scale, but the flow branch runs on the side stream under the (longer) correlation encoder
+                          # chain: 35.9 vs 35.85 ms per clip, three alternations on one box -- off
     convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
     conv5_m192=True,      # conv_gemm5's three-cout-block layout for the 190 / 192-cout convs (else padded to 256 rows)
     fork_min_pixels=0,    # independent branches of an iteration run on the side stream only on maps with at least this many pixels (0: always)
@@ -597,6 +600,11 @@ class ScaleEngine:
         o["ffn2_0"] = self._conv("ffn2_0", [self.C2.view()], k1, E(act=L.ACT_GELU, n_valid=54, out_sp=self.T1.view()))
         o["ffn2_2"] = self._conv("ffn2_2", [self.T1.view()], k1, E(act=L.ACT_GELU, n_valid=256, out_sp=self.COR256.view()))
         o["convf1"] = self._conv("convf1", [self.PATCH.view()], k1, E(act=L.ACT_RELU, n_valid=128, out_sp=self.FLO1.view()))
+        if TUNING["flow_conv7"]:
+            wf1, bf1, mf1 = self.pk.w["convf1"]
+            assert mf1["nk"] == 4 and mf1["M"] == 128 and mf1["version"] == 2, mf1
+            o["flow_conv7"] = TimedCall(lambda: L.check(self.lib.ppms_flow_conv7(self.FLOW.data_ptr(), wf1.data_ptr(), bf1.data_ptr(), self.FLO1.view(),
+                                                                                 self.T, self.h, self.w, L.stream_ptr())))
         for par in (0, 1):
             cf, cf_next = self.CF[par], self.CF[1 - par]
             o[f"init2_{par}"] = self._conv("init2", [self.ZT.view(0, 64)], k3, E(n_valid=64, out_sp=cf.view(256, 64)))
@@ -810,8 +818,11 @@ class ScaleEngine:
     def motion_and_value(self):
         o, s, par = self.op, self._s(), self.parity
         with self._fork():                        # flow branch: convf1 (7x7 via im2col) -> convf2
-            L.check(self.lib.ppms_flow_patch7(self.FLOW.data_ptr(), self.PATCH.view(), self.T, self.h, self.w, self._s()))
-            o["convf1"]()
+            if "flow_conv7" in o:
+                o["flow_conv7"]()
+            else:
+                L.check(self.lib.ppms_flow_patch7(self.FLOW.data_ptr(), self.PATCH.view(), self.T, self.h, self.w, self._s()))
+                o["convf1"]()
             o[f"convf2_{par}"]()
         if not self.have_mhs:                     # init_conv(inp), ppmtereo_update.py:469-471
             o["init0"]()

@@ -1078,6 +1078,40 @@ def test_dwconv_gelu(lib, k, BT, H, W, cv):
     assert (got[:, cv:] == 0).all(), "channels outside the view must not be written"
 
 
+@pytest.mark.parametrize("BT,H,W", [(2, 9, 18), (1, 5, 7), (3, 20, 32), (5, 80, 128), (1, 3, 64)])
+def test_flow_conv7_vs_conv2d(lib, BT, H, W):
+    """convf1 + relu of the motion encoder (ppmtereo_update.py:452,477: Conv2d(2, 128, 7, padding=3) on the flow) as one launch building its
+    im2col rows in LDS, against F.conv2d on the same fp32 flow; ragged tiles (pixel counts off the 64-pixel tile), maps narrower than the 7-tap
+    reach, and against the two launches it replaces (flow_patch7 + the 1x1 implicit GEMM over the same pack: equal to a step of the split-bf16 storage)."""
+    from ppmstereo_amd.packing import pack_conv2
+    L = lib
+    P = BT * H * W
+    flow = (hash_normal((P, 2), 540) * 3.0).to(DEV)
+    wt = hash_normal((128, 2, 7, 7), 541) / math.sqrt(98)
+    bs = hash_normal((128,), 542) * 0.1
+    w1 = wt.permute(0, 2, 3, 1).reshape(128, 98, 1, 1)                              # k = tap * 2 + c, as the engine packs convf1
+    packed, bias, meta = pack_conv2(w1.to(DEV), bs.to(DEV), [98], [128])
+    assert meta["nk"] == 4 and meta["M"] == 128
+    out = L.SPTensor(P, 192, DEV)
+    L.check(L.load().ppms_flow_conv7(flow.data_ptr(), packed.data_ptr(), bias.data_ptr(), out.view(32, 128), BT, H, W, L.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = F.relu(F.conv2d(flow.cpu().reshape(BT, H, W, 2).permute(0, 3, 1, 2), wt, bs, padding=3)).permute(0, 2, 3, 1).reshape(P, 128)
+    got = out.to_f32().cpu()
+    assert maxdiff(got[:, 32:160], ref) < 3e-5 * max(1.0, ref.abs().max().item())
+    assert (got[:, :32] == 0).all() and (got[:, 160:] == 0).all(), "channels outside the view must not be written"
+    patch, out2 = L.SPTensor(P, 128, DEV), L.SPTensor(P, 128, DEV)
+    L.check(L.load().ppms_flow_patch7(flow.data_ptr(), patch.view(), BT, H, W, L.stream_ptr()))
+    from ppmstereo_amd.engine import ConvOp, epilogue
+    d = L.Conv()
+    d.seg[0], d.nseg = patch.view(), 1
+    d.w, d.bias, d.T, d.H, d.W, d.kt, d.kh, d.kw, d.M, d.m_split = packed.data_ptr(), bias.data_ptr(), BT, H, W, 1, 1, 1, 128, 128
+    d.epi[0] = epilogue(act=L.ACT_RELU, n_valid=128, out_sp=out2.view())
+    ConvOp(d, [packed, bias, patch, out2], 2, nslice=1)()
+    torch.cuda.synchronize()
+    assert maxdiff(out2.to_f32().cpu(), ref) < 3e-5 * max(1.0, ref.abs().max().item())
+    assert maxdiff(out2.to_f32().cpu(), got[:, 32:160]) < 1e-5 * max(1.0, ref.abs().max().item())    # (one step of the split-bf16 storage)
+
+
 @pytest.mark.parametrize("T,H,W", [(3, 5, 9), (1, 4, 6), (5, 10, 16)])
 def test_tap_gather_sum(lib, T, H, W):
     """FlowHead3D.conv2 (256 -> 2, 3x3x3) = 1x1 GEMM to 54 channels + shifted sum; checked against conv3d."""
