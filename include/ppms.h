@@ -310,6 +310,12 @@ int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
  * (ppmtereo_update.py:1024-1030).  dev_params: device copy of the parameter block built by the host
  * (ppmstereo_amd/engine.py: PwChain; layout checked with ppms_pwchain_param_bytes). */
 int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream);
+/* The same chain with its input tile looked up by the chain itself: CorrBlock1D.__call__ (corr.py:74-94; 4 levels x 9 taps at x + flow_x, as
+ * ppms_corr_lookup) of every pixel goes straight into the chain's first layer (channels 0..35 of its 64 padded inputs) -- the chain's `in` view is
+ * not read.  pyr: levels 0..3 of ppms_corr_build; flow_nhwc: fp32 [BT*H*W][2]; flow_sp_hi / _lo (optional, both or neither): SP planes that
+ * receive the flow as two channels at [pixel * flow_sp_ld + 0 / 1] (the motion features' last two channels, ppmtereo_update.py:480). */
+int ppms_pwchain_lookup(const void* dev_params, const float* const pyr[4], const float* flow_nhwc, void* flow_sp_hi, void* flow_sp_lo, int flow_sp_ld,
+                        int BT, int H, int W, void* stream);
 int ppms_pwchain_param_bytes(void);
 
 /* ---------------------------------------------------------------- update_block16 time / space attention pieces */

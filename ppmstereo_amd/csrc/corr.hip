@@ -2,6 +2,7 @@
 // Replaces CorrBlock1D of /root/reference/models/core/corr.py:55-104 (einsum :102, avg_pool2d :71,
 // grid_sample :21).  HBM-bound kernels: the volume is written once and gathered once per iteration.
 #include "common.h"
+#include "corr_lookup.h"
 
 // ------------------------------------------------------------------------------------------------
 // build: one workgroup per (epipolar line, 32-wide x1 tile); each wave owns 32-wide x2 tiles.
@@ -313,22 +314,6 @@ extern "C" int ppms_corr_build(const float* fmap1, const float* fmap2, float* co
 // ------------------------------------------------------------------------------------------------
 // lookup: 4 levels x 9 taps of linear interpolation at x + flow_x, zero padding, align_corners=True.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float lookup_tap(const float* __restrict__ L, int Wl, float xs, int lvl, int kk) {
-    // same fp32 op sequence as the reference: normalise (corr.py:14,85) then grid_sample's un-normalise
-    const float pos = (float)(kk - 4) + xs / (float)(1 << lvl);
-    const float wm1 = (float)(Wl - 1);
-    const float g = 2.0f * pos / wm1 - 1.0f;
-    const float p = ((g + 1.0f) / 2.0f) * wm1;
-    const float pf = floorf(p);
-    const float a = p - pf;
-    // far out-of-range positions (|p| beyond int range) contribute nothing
-    if (!(pf >= -1.0f && pf <= (float)Wl)) return 0.0f;
-    const int i0 = (int)pf, i1 = i0 + 1;
-    const float v0 = (i0 >= 0 && i0 < Wl) ? L[i0] : 0.0f;
-    const float v1 = (i1 >= 0 && i1 < Wl) ? L[i1] : 0.0f;
-    return (1.0f - a) * v0 + a * v1;
-}
-
 // fast path: 4 pixels x 64 channel slots per block, channel-last SP output (36 real + 28 zero channels).
 // One wave per pixel, lane = output channel, two loads per tap (neighbouring lanes of a level hit the same cache lines).  Round 3 tried
 // north_star's literal prescription -- a 12-float window per (pixel, level) staged by 48 lanes, taps picked with wave shuffles, 4 pixels

@@ -5,8 +5,52 @@
 // operand format) from layer to layer: one launch replaces three implicit-GEMM launches plus the depthwise 1x1 kernel.
 // Same arithmetic as the unfused path (bf16x3 split MFMA, fp32 accumulate, erf GELU).
 #include "common.h"
+#include "corr_lookup.h"
+
+// The chain's input tile looked up by the chain itself (chain A of the correlation encoder): the 36 taps of CorrBlock1D.__call__
+// (corr.py:74-94) of every pixel of the tile go straight into the LDS activation buffer -- the corr_lookup launch and its 64-channel
+// tensor (26 MB written and read back per iteration at the 1/4 scale) disappear.  Passed BY VALUE beside the parameter block: the pyramid
+// belongs to the clip, the parameter block to the engine.  l[0] == nullptr: the chain reads its input tensor.
+struct ppms_chain_lookup {
+    const float* l[4];        // pyramid levels 0..3, [pixel][W >> level] fp32
+    const float* flow;        // [pixel][2] fp32
+    void* flow_hi;            // optional SP copy of the flow (the last two motion-feature channels, ppmtereo_update.py:480): [pixel * flow_ld + 0 / 1]
+    void* flow_lo;
+    int flow_ld, H, W, pad;
+};
 
 namespace {
+
+// the 16-byte piece `ch8` (input channels 8 ch8 .. 8 ch8 + 7; 36 real taps, then zeros) of pixel `pix` as split bf16
+__device__ __forceinline__ void lookup_piece(const ppms_chain_lookup& lk, int64_t pix, int ch8, u32x4& vh, u32x4& vl) {
+    bf16x8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ch8 < 5) {
+        const float xs = (float)(int)(pix % lk.W) + lk.flow[pix * 2];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = ch8 * 8 + j;
+            if (ch < 36) {
+                const int lvl = ch / 9, kk = ch - lvl * 9;
+                const int Wl = lk.W >> lvl;
+                const float* L = (lvl == 0 ? lk.l[0] : lvl == 1 ? lk.l[1] : lvl == 2 ? lk.l[2] : lk.l[3]) + pix * Wl;
+                bf16_t hh, ll;
+                split_bf16(lookup_tap(L, Wl, xs, lvl, kk), hh, ll);
+                oh[j] = hh;
+                ol[j] = ll;
+            }
+        }
+    } else if (ch8 == 5 && lk.flow_hi != nullptr) {          // (an otherwise idle lane) the flow's SP copy
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16_t hh, ll;
+            split_bf16(lk.flow[pix * 2 + c], hh, ll);
+            ((bf16_t*)lk.flow_hi)[pix * lk.flow_ld + c] = hh;
+            ((bf16_t*)lk.flow_lo)[pix * lk.flow_ld + c] = ll;
+        }
+    }
+    vh = *(const u32x4*)&oh;
+    vl = *(const u32x4*)&ol;
+}
 
 constexpr int TP = 128;                      // pixels per workgroup
 constexpr int ROWB = 64;                     // bytes per LDS row: 32 channels x bf16
@@ -35,7 +79,7 @@ struct ChainParams {
 
 // (The parameter block stays behind a device pointer: passed by value in the kernel arguments -- as the conv descriptors are -- the layer
 // loop's dynamic index c.layer[l] sends the struct to scratch memory: chain B at the 1/4 scale 43 -> 54 us, nothing gained at 1/16.)
-__global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restrict__ cp) {
+__global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restrict__ cp, const ppms_chain_lookup lk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ChainParams& c = *cp;
     // Two activation buffers, used alternately, + one weight block: 80 KiB, so that TWO workgroups share a CU (three buffers: one
@@ -56,8 +100,12 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
         const int64_t pix = p0 + px;
         u32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
         if (pix < c.P) {
-            vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
-            vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
+            if (lk.l[0] != nullptr) {                          // (uniform)
+                lookup_piece(lk, pix, ch, vh, vl);
+            } else {
+                vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
+                vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
+            }
         }
         const int off = (ch >> 2) * 2 * ACT_PLANE + swzp(px, ch & 3);
         *(u32x4*)(bufX + off) = vh;
@@ -191,7 +239,7 @@ constexpr int ACT32_PLANE = TP32 * ROWB;     // 2 KiB
 constexpr int ACT32_BUF = 4 * ACT32_PLANE;   // [kstep 2][plane 2][32 px][64 B] = 8 KiB
 constexpr int W32_MAX = 4 * W_BLK;           // weights of a 256-cout layer: 64 KiB (reused as the output staging patch of the last layer)
 
-__global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __restrict__ cp) {
+__global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __restrict__ cp, const ppms_chain_lookup lk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ChainParams& c = *cp;
     char* bufX = smem;
@@ -205,8 +253,12 @@ __global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __res
         const int64_t pix = p0 + px;
         u32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
         if (pix < c.P) {
-            vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
-            vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
+            if (lk.l[0] != nullptr) {
+                lookup_piece(lk, pix, ch, vh, vl);
+            } else {
+                vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
+                vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
+            }
         }
         const int off = (ch >> 2) * 2 * ACT32_PLANE + swzp(px, ch & 3);
         *(u32x4*)(bufX + off) = vh;
@@ -472,8 +524,7 @@ extern "C" int ppms_flow_conv7(const float* flow_nhwc, const void* w_packed, con
     return ppms_check_launch("flow_conv7");
 }
 
-extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
-    PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");
+static int pwchain_launch(const void* dev_params, int64_t pixels, const ppms_chain_lookup& lk, void* stream) {
     constexpr size_t lds = 2 * ACT_BUF + W_BLK;                // 80 KiB: two workgroups per CU
     constexpr size_t lds32 = 2 * ACT32_BUF + W32_MAX;          // 80 KiB
     static ppms_device_once once;
@@ -482,11 +533,26 @@ extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream
         (void)hipFuncSetAttribute((const void*)pwchain32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ACT32_BUF + W32_MAX));
     });
     if (pixels <= 16384) {                                       // small maps: 32-pixel tiles, one phase per layer
-        hipLaunchKernelGGL(pwchain32_kernel, dim3(ceil_div(pixels, TP32)), dim3(256), lds32, (hipStream_t)stream, (const ChainParams*)dev_params);
+        hipLaunchKernelGGL(pwchain32_kernel, dim3(ceil_div(pixels, TP32)), dim3(256), lds32, (hipStream_t)stream, (const ChainParams*)dev_params, lk);
         return ppms_check_launch("pwchain");
     }
-    hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params);
+    hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params, lk);
     return ppms_check_launch("pwchain");
+}
+
+extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
+    PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");
+    ppms_chain_lookup lk = {};
+    return pwchain_launch(dev_params, pixels, lk, stream);
+}
+
+extern "C" int ppms_pwchain_lookup(const void* dev_params, const float* const pyr[4], const float* flow_nhwc, void* flow_sp_hi, void* flow_sp_lo, int flow_sp_ld,
+                                   int BT, int H, int W, void* stream) {
+    PPMS_REQUIRE(dev_params != nullptr && pyr != nullptr && pyr[0] && pyr[1] && pyr[2] && pyr[3] && flow_nhwc != nullptr, "pwchain_lookup: null operand");
+    PPMS_REQUIRE(BT > 0 && H > 0 && (W >> 3) >= 2, "pwchain_lookup: bad shape BT=%d H=%d W=%d (level 3 needs >= 2 columns)", BT, H, W);
+    PPMS_REQUIRE((flow_sp_hi == nullptr) == (flow_sp_lo == nullptr), "pwchain_lookup: the flow's SP copy needs both planes");
+    ppms_chain_lookup lk = {{pyr[0], pyr[1], pyr[2], pyr[3]}, flow_nhwc, flow_sp_hi, flow_sp_lo, flow_sp_ld, H, W, 0};
+    return pwchain_launch(dev_params, (int64_t)BT * H * W, lk, stream);
 }
 
 extern "C" int ppms_pwchain_param_bytes(void) { return (int)sizeof(ChainParams); }

@@ -50,6 +50,9 @@ TUNING = dict(
     stream_hint=0,        # its tile: 0 = the library chooses, 1 / 2 = 32- / 64-pixel tiles
     hid_exact=True,       # hoisted blocks: the GRU convs read [h | mf, hid] with weights (W_mf + W_mfg | beta W_mfg) instead of [h | mf, mfg]; hid is a
                           # bf16 tensor (all-zero lo plane), so the products with that plane are skipped (ppms_conv.lo_zero_from)
+    lookup_fused=False,   # the correlation lookup inside chain A's input stage (pwchain.hip: lookup_piece) instead of its own launch + the 64-channel CORR tensor:
+                          # one launch fewer per iteration, but the taps then come from 400 workgroups instead of 12 800 (chain A 28 -> ~55 us for the 17 us launch
+                          # it replaces at the 1/4 scale): 35.37 vs 35.40 ms per clip, three alternations -- off
     flow_conv7=False,     # convf1 as one launch building its 7x7 im2col rows in LDS (pwchain.hip: flow_conv7_kernel) instead of flow_patch7 + a 1x1 GEMM launch:
                           # 26 + 36 us -> one launch at the 1/4 scale, but the flow branch runs on the side stream under the (longer) correlation encoder
                           # chain: 35.9 vs 35.85 ms per clip, three alternations on one box -- off
@@ -218,13 +221,19 @@ class PwChain:
         self.pixels, self.keep, self.cp = pixels, keep, cp
         self.dev = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).clone().to(device)
         self.events = None
+        self.lookup = None            # callable -> (pyr_ptrs, flow_ptr, flow_sp_hi, flow_sp_lo, flow_sp_ld, BT, H, W): the chain looks its input up itself ...
+        self.lookup_armed = False     # ... in its NEXT launch (ScaleEngine.lookup() arms it; a caller's own correlation tensor is read from the input view)
 
     def __call__(self):
         ev = self.events if KERNEL_TIMING["on"] else None
         if ev is not None:
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
-        L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
+        if self.lookup is not None and self.lookup_armed:
+            self.lookup_armed = False
+            L.check(L.load().ppms_pwchain_lookup(self.dev.data_ptr(), *self.lookup(), L.stream_ptr()))
+        else:
+            L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
         if ev is not None:
             pair[1].record()
             ev.append(pair)
@@ -588,6 +597,9 @@ class ScaleEngine:
             # chain A: x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))      CORR -> C2
             o["chainA"] = PwChain(self.CORR.view(), self.C2.view(), [(w["ffn1_0"], 54, False, None), (w["ffn1_2"], 36, True, dw1)], self.P, [dw1[0]],
                                  device=self.dev)
+            if TUNING["lookup_fused"]:
+                fl = self.X.view(254, 2)
+                o["chainA"].lookup = lambda: (self.pyr_ptrs, self.FLOW.data_ptr(), fl.hi, fl.lo, 384, self.T, self.h, self.w)
             # chain B: x4 = gelu(x3 + pw x3); cor = gelu(ffn2(x4))              C1 -> COR256
             o["chainB"] = PwChain(self.C1.view(), self.COR256.view(), [(w["pw"], 36, True, None), (w["ffn2_0"], 54, False, None),
                                                                        (w["ffn2_2"], 256, False, None)], self.P, [], device=self.dev)
@@ -784,7 +796,13 @@ class ScaleEngine:
         self.STRIVE.fill_(1.0)
 
     # ------------------------------------------------------------------ iteration stages
-    def lookup(self):
+    def lookup(self, force: bool = False):
+        """force: run the stand-alone lookup launch (CORR holds the taps afterwards: stage-by-stage checks) even where chain A looks them up itself."""
+        if not force and "chainA" in self.op and self.op["chainA"].lookup is not None:
+            self.op["chainA"].lookup_armed = True   # chain A of the next motion_and_value() looks the taps up itself
+            return
+        if "chainA" in self.op:
+            self.op["chainA"].lookup_armed = False
         self.hbm["corr_lookup"]()
 
     def _lookup(self):

@@ -470,6 +470,36 @@ def test_test_mode_drops_only_dead_work(model):
     assert len(preds) == 20 and torch.equal(d, preds[-1]) and torch.equal(c, uncs[-1])
 
 
+def test_fused_launch_switches_do_not_change_the_cascade(model):
+    """The two launch fusions kept behind engine.TUNING switches (off by default: measured neutral in the clip) stay correct: the correlation
+    lookup inside chain A's tile staging (lookup_fused) reproduces the cascade bit for bit, convf1 as one launch with its im2col rows built in
+    LDS (flow_conv7) to a step of the split-bf16 storage of its output."""
+    from ppmstereo_amd import engine as E
+    T, H, Wd = 3, 64, 256
+    feats = {k: v.to(DEV) for k, v in synth_cascade_feats(T, H, Wd).items()}
+    blocks = (model.update_block16, model.update_block08, model.update_block04)
+
+    def run(**sw):
+        old = {k: E.TUNING[k] for k in sw}
+        E.TUNING.update(sw)
+        for b in blocks:
+            b._engines.clear()
+        try:
+            preds, uncs = [], []
+            model.cascade(feats, 4, T, preds, uncs)
+            return torch.stack(preds).float().cpu(), torch.stack(uncs).float().cpu()
+        finally:
+            E.TUNING.update(old)
+            for b in blocks:
+                b._engines.clear()
+
+    base = run(flow_conv7=False, lookup_fused=False)
+    lk = run(flow_conv7=False, lookup_fused=True)
+    assert torch.equal(base[0], lk[0]) and torch.equal(base[1], lk[1])
+    fc = run(flow_conv7=True, lookup_fused=False)
+    assert (fc[0] - base[0]).abs().mean() < 1e-4 and (fc[1] - base[1]).abs().max() < 1e-4, ((fc[0] - base[0]).abs().mean(), (fc[1] - base[1]).abs().max())
+
+
 def test_attention_is_a_convex_combination(model):
     """Softmax-weighted aggregation property at full 1/4-scale size (n = 10240, 5 frames): with V == const vector c per
     channel the output must equal bf16(c) whatever Q, K are."""

@@ -1176,6 +1176,42 @@ def test_pwchain_vs_unfused_layers(lib, P):
     assert maxdiff(out.to_f32(), ref) < 5e-5 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("BT,H,W", [(2, 9, 24), (3, 40, 144)])
+def test_pwchain_with_its_own_lookup_is_lookup_then_chain_bit_for_bit(lib, BT, H, W):
+    """Chain A with the correlation lookup in its input stage (ppms_pwchain_lookup: CorrBlock1D.__call__, corr.py:74-94, inside the chain's tile
+    staging) against ppms_corr_lookup + ppms_pwchain on the tensor in between: the same taps, the same chain -- equal bit for bit, on the small-map
+    kernel (432 pixels) and the large-map one (17 280 pixels, ragged last tile); the flow's SP copy (the motion features' last two channels) too."""
+    from ppmstereo_amd.corr import CorrBlock1D
+    from ppmstereo_amd.engine import PwChain
+    from ppmstereo_amd.packing import pack_conv2
+    L = lib
+    P = BT * H * W
+    f1, f2 = hash_normal((BT, 32, H, W), 560).to(DEV), hash_normal((BT, 32, H, W), 561).to(DEV)
+    pyr = CorrBlock1D(f1, f2).levels
+    flow = (hash_normal((P, 2), 562) * 6.0).to(DEV)                               # (reaches past both image borders)
+    mk = lambda co, ci, s: (hash_normal((co, ci, 1, 1), s) / math.sqrt(ci), hash_normal((co,), s + 1) * 0.1)
+    (w0, b0), (w2, b2) = mk(54, 36, 563), mk(36, 54, 565)
+    pk = lambda w, b, ci: pack_conv2(w.to(DEV), b.to(DEV), [ci], [64])
+    s64, t64 = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    s64[:36], t64[:36] = (hash_normal((36,), 567) * 0.5).to(DEV), (hash_normal((36,), 568) * 0.1).to(DEV)
+    layers = lambda: [(pk(w0, b0, 36), 54, False, None), (pk(w2, b2, 54), 36, True, (s64, t64))]
+    corr, out_a, out_b = L.SPTensor(P, 64, DEV), L.SPTensor(P, 64, DEV), L.SPTensor(P, 64, DEV)
+    fl_a, fl_b = L.SPTensor(P, 8, DEV), L.SPTensor(P, 8, DEV)
+    ptrs = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr[:4]])
+    L.check(L.load().ppms_corr_lookup(ptrs, flow.data_ptr(), 1, None, corr.view().hi, corr.view().lo, 64, fl_a.view(2, 2).hi, fl_a.view(2, 2).lo, 8, BT, H, W,
+                                      L.stream_ptr()))
+    PwChain(corr.view(), out_a.view(), layers(), P, [])()
+    fused = PwChain(corr.view(), out_b.view(), layers(), P, [])
+    vb = fl_b.view(2, 2)
+    fused.lookup, fused.lookup_armed = (lambda: (ptrs, flow.data_ptr(), vb.hi, vb.lo, 8, BT, H, W)), True
+    corr.set_f32(torch.full((P, 64), 7.0, device=DEV))                             # the fused chain must not read its input tensor
+    fused()
+    torch.cuda.synchronize()
+    assert torch.equal(out_a.to_f32(), out_b.to_f32())
+    assert torch.equal(fl_a.to_f32(), fl_b.to_f32()) and maxdiff(fl_b.to_f32()[:, 2:4], flow) < 1e-3
+    assert out_a.to_f32()[:, :36].abs().max() > 0.1
+
+
 @pytest.mark.parametrize("T,n", [(5, 640), (3, 77), (2, 1000)])
 def test_attn16_kernels(lib, T, n):
     """TimeAttnBlock core, LayerNorm(+residual) and LinearAttention kernels (attn16.hip) vs fp32 torch math
