@@ -491,7 +491,12 @@ def main():
         all_ms = D.max_over_ranks(time.perf_counter() - t_all) / n_all * 1e3
     sharded_out = sharded_chk = None
     if world > 1 and not sharded and args.sharded_T and args.sharded_T % world == 0 and args.sharded_T // world >= 2:
-        sharded_out, sharded_chk = sharded_phase(args, D, model, rank, world, dev)
+        try:
+            sharded_out, sharded_chk = sharded_phase(args, D, model, rank, world, dev)
+        except Exception as e:                     # (a failed CHECK leaves through sys.exit(3) inside; this is an exception of the extra phase itself)
+            # the replica measurement above is complete and unaffected: report it, with the failure of the extra window recorded in its place
+            sharded_out = dict(error=f"{type(e).__name__}: {e}"[:600], note="the frame-sharded window behind the replica measurement raised; `value` is unaffected")
+            sharded_chk = None
     encoders = None
     if not args.no_encoders and world == 1 and (T, H, W) == (5, 320, 512):      # (N > 1: the ranks time their clips only)
         # SURVEY 8 rows f3-f5 on the same clip geometry: fnet on the 2T images, cnet on the T left images, SST on the 1/16 features
@@ -576,8 +581,10 @@ def main():
                    sharded=sharded_out, sharded_check=sharded_chk,
                    whole_call_ms=None if not encoders else encoders["whole_call_ms"],
                    library=os.path.relpath(L.lib_path(), ROOT), **({"encoders": encoders} if encoders else {}))
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
+        if sharded_out is not None and "error" in sharded_out:
+            os._exit(0)                            # (the process group may be wedged behind the failed exchange: do not wait for a clean teardown)
         torch.distributed.destroy_process_group()
 
 
