@@ -89,6 +89,13 @@ class BasicEncoder(nn.Module):
         def put(name, w, b, cin_real, cin_pad):
             packed, bias, meta = _packing.pack_conv2(w.detach().to(device), b.detach().to(device), [cin_real], [cin_pad])
             pk[name] = (packed, bias, meta, tuple(w.shape[2:]))
+            kh, kw = w.shape[2:]
+            if kh == 3 and kw == 3 and cin_pad % 32 == 0 and 64 < w.shape[0] <= 128:
+                # the 3x3 layers with 96 / 128 couts (the 1/4-resolution stages): conv_gemm6 (conv_gemm6.hip; pack_conv6 with (ky, kx) flattened into
+                # the sweep axis, as engine.PackedBlock packs the update block's 3x3 convs) where the library rates its tile fill
+                w5 = w.detach().to(device)[:, :, None]
+                sweep = w5.reshape(w5.shape[0], w5.shape[1], 1, 1, kh * kw).contiguous()
+                pk[name + "@6"] = _packing.pack_conv6(sweep, b.detach().to(device), [cin_real], [cin_pad], None, 128)
 
         put("conv1", _s2d_weight(self.conv1.weight, 3), self.conv1.bias, 12, 32)
         for layer in (1, 2, 3):
@@ -172,6 +179,13 @@ class _FnetEngine:
             d.M = d.m_split = meta["M"]
             assert src.channels == meta["cpad"] and dst_f32.shape[1] == meta["M"], (name, src.channels, meta["cpad"], dst_f32.shape, meta["M"])
             d.epi[0] = epilogue(n_valid=meta["M"], out_f32=dst_f32, out_f32_ld=meta["M"])
+            if name + "@6" in pk and meta["M"] == 128:
+                packed6, bias6, meta6 = pk[name + "@6"]
+                d6 = L.Conv.from_buffer_copy(bytes(d))
+                d6.w, d6.bias = packed6.data_ptr(), bias6.data_ptr()
+                if meta6["M"] == 128 and self.lib.ppms_conv_gemm6_applicable(C.byref(d6)) == 1:
+                    self.ops.append(("conv", ConvOp(d6, [src, dst_f32, packed6, bias6], 8, device=device)))
+                    return
             self.ops.append(("conv", ConvOp(d, [src, dst_f32, packed, bias], 2, device=device)))
 
         def norm(src_f32: torch.Tensor, C_, hw, dst: L.SPTensor, relu: bool, res: Optional[L.SPTensor] = None):
