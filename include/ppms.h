@@ -151,8 +151,8 @@ int ppms_conv_gemm5_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int
  * blocks of 16 pixels: 51 200 pixels = 250 tiles on 256 CUs.  Weights in MFMA-fragment order for 16-cout x 32-channel blocks
  * (ppmstereo_amd/packing.py pack_conv6, sweep-ordered like pack_conv4), straight from L2 to registers one k32-step ahead; 32-channel
  * activation windows, column-major, double buffered by LDS-DMA through a buffer resource (the lo plane of a segment must follow its hi
- * plane inside one 4 GiB range), swept by the taps along x, along y (kh <= 5) or over all kh x kw taps: a spatial sweep is required (kh > 1
- * or kw > 1; convolutions without one stay on ppms_conv_gemm5 / ppms_gemm1).  Same descriptor and epilogues as ppms_conv_gemm5 except
+ * plane inside one 4 GiB range), swept by the taps along x, along y (kh <= 5) or over all kh x kw taps; without a spatial sweep (kh = kw = 1:
+ * (kt,1,1) and 1x1 convolutions) every k32-step streams its own window through a ring of three buffers.  Same descriptor and epilogues as ppms_conv_gemm5 except
  * out_vt; input segments in multiples of 32 channels.  applicable: 0 = not served, 1 = served and the 208-pixel tiles fill >= 85 % of the CU-slots of the launch's rounds,
  * 2 = served with a poor fill (a caller keeps ppms_conv_gemm5 there). */
 int ppms_conv_gemm6_applicable(const ppms_conv* desc);

@@ -13,7 +13,10 @@
 //     c ^ (wy & 6) (wy = row inside the window column): the fragment reads are conflict-free for every tap offset.
 // Window = halo'd patch stored COLUMN-major (row = wx * WH + wy), gathered by LDS-DMA with per-lane source addresses (zero page for padding),
 // double buffered, one barrier per window; the taps sweep the window from LDS.  Without a spatial sweep (kh = kw = 1: the temporal GRU pass,
-// 1x1 heads) a window holds TWO 32-channel chunks of the tile, one behind the other, and the "sweep" steps through them.
+// 1x1 layers) nothing re-uses a window: the STREAM form of the kernel (template parameter) gives every k32-step its own window (the tile's 208
+// pixels x 32 channels of one temporal tap: 7 LDS-DMA pieces per thread) in a ring of THREE buffers, issued two steps ahead.  (A first form with
+// two 32-channel chunks per window in the double-buffered loop waited for its whole window at every switch and showed rare wrong pixels under
+// back-to-back launches; the STREAM form is clean over hundreds of launches: tools/conv6_stress.py, tests/test_gpu_concurrency.py.)
 // Weights: pack_conv6 (ppmstereo_amd/packing.py): [k32-step][M/16][hi, lo][lane = 16 kg + r][8] = the MFMA A-operand images.
 #include "common.h"
 #include "conv_epilogue.h"
@@ -34,14 +37,14 @@ constexpr int STG6_ROWS = 7 * 16;             // pixels a wave stages per epilog
 
 struct Geo6 {
     int tiles_x, tiles_y;
-    int WH, WC;              // window column height (16 + y halo; even) and columns (13 + x halo); GEMM mode: 16 x 26 (two 13-column chunks)
+    int WH, WC;              // window column height (16 + y halo; even) and columns (13 + x halo)
     int hxl, hyl;            // halo on the left / above
-    int mode;                // 0: x sweep, 1: y sweep, 2: 2-D sweep, 3: GEMM (no spatial taps)
+    int mode;                // 0: x sweep, 1: y sweep, 2: 2-D sweep, 4: no spatial taps (the STREAM form: one k32-step per window)
     int nsweep;              // k32-steps per window
     int swx_n, inc, jump;    // the LDS row offset of the tap advances by inc per step and by jump more after every swx_n steps
     int yinc, ywrap;         // the tap's y offset (the swizzle phase of the fragment reads): += yinc per step, += 1 and back to ... see kernel
     int nchunk, n0;          // windows per temporal tap (all segments), windows of segment 0
-    int cpw;                 // input channels per window: 32, GEMM mode 64
+    int cpw;                 // input channels per window: 32
     int lz0;                 // windows whose index inside the tap is >= lz0 hold bf16-exact activations (all-zero lo plane): hi x lo products skipped
     int npieces;             // DMA pieces per thread and window that carry rows (<= conv6_np(WH), which is what every window issues)
     int wbytes;              // bytes of one window buffer (conv6_np(WH) * 4 KiB)
@@ -103,7 +106,9 @@ constexpr unsigned CONV6_OOB = 0xFFFFFFF0u;
 #include "conv6_asm.h"
 
 // MB: 16-cout blocks per wave -- 4 (M = 256, 128) or 3 (M = 192); CR: rows of a window column = 16 + y halo (16, 18, 20)
-template <int MB, int CR>
+// STREAM: convolutions WITHOUT spatial taps ((kt,1,1) and 1x1): a window = the tile's 208 pixels x 32 channels of one temporal tap, used by ONE k32-step
+// (nothing re-uses it), three window buffers, every step issues the window two steps ahead -- see CONV6_STEP1
+template <int MB, int CR, bool STREAM = false>
 __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const Geo6 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ppms_conv& p = pv;                       // by value in the kernel arguments (see conv_gemm2.hip)
@@ -157,18 +162,11 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             const int row = q >> 3, pos = q & 7;
             off0[i] = off1[i] = CONV6_OOB;
             if (row < rows) {
-                int sub = 0, wx, wy;
-                if (g.mode == 3) {
-                    sub = row >= NBT6 * 16 ? 1 : 0;
-                    const int rr = row - sub * NBT6 * 16;
-                    wx = rr >> 4, wy = rr & 15;
-                } else {
-                    wx = row / g.WH, wy = row - wx * g.WH;
-                }
+                const int wx = row / g.WH, wy = row - wx * g.WH;
                 const int x = x0 + wx - g.hxl, y = y0 + wy - g.hyl;
                 const int c = pos ^ (wy & 6);                    // the 16-B chunk of the row this position holds: plane * 4 + k-group
                 if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
-                    const unsigned pix = (unsigned)((tf * H + y) * W + x), unit16 = (unsigned)(((c & 3) + 4 * sub) * 16);
+                    const unsigned pix = (unsigned)((tf * H + y) * W + x), unit16 = (unsigned)((c & 3) * 16);
                     off0[i] = pix * (unsigned)ld0 + unit16 + ((c >> 2) ? pd0 : 0u);
                     off1[i] = pix * (unsigned)ld1 + unit16 + ((c >> 2) ? pd1 : 0u);
                 }
@@ -329,15 +327,96 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         _Pragma("unroll") for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(areg[0][k]), "v"(areg[1][k]));                          \
         _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(ring[k][0]), "v"(ring[k][1]));                          \
     }
+    // ---- STREAM form: one k32-step per window.  Step s multiplies window s (buffer w), while the LDS-DMA of window s + 1 (issued during step s - 1) is
+    // landing and the pieces of window s + 2 go out (NPS pieces, one per hook slot, behind the step's weight loads).  At the end of the step:
+    // vmcnt(NPS) = everything but those pieces has landed (the older window s + 1, the next step's weight fragments), barrier (every wave is done
+    // reading buffer w: it is window s + 3's target), the fragment ring is primed from window s + 1.  Same window order as above (two phases).
+    constexpr int NPS = 7;                            // pieces per thread and window: 208 rows x 8 positions / 256 threads = 6.5
+#define CONV6_STEP1(U, NBW, SKIP, LASTSTEP)                                                                                        \
+    {                                                                                                                              \
+        const bool last = (LASTSTEP) && nxkz < 0; /* no step behind this one */                                                    \
+        const bool issue = n2kz >= 0;             /* window s + 2 exists */                                                        \
+        const int bn = (w == 2) ? 0 : w + 1, b2 = (bn == 2) ? 0 : bn + 1;                                                           \
+        const unsigned bh = lane_addr(0) + (unsigned)(w * g.wbytes), bhn = lane_addr(0) + (unsigned)((last ? w : bn) * g.wbytes);    \
+        if (issue) dma_setup(n2kz, n2ch, b2);                                                                                      \
+        const int ksn = last ? (ckz * g.nchunk + cch) : (nxkz * g.nchunk + nxch);                                                   \
+        const char* sbn = abase + (int64_t)ksn * astep;                                                                            \
+        conv6_step<MB, NBW, CR, SKIP>(acc, areg[U], areg[(U) ^ 1], ring, bh, bh ^ 64u, bhn, bhn ^ 64u, avoff0, avoff1, sbn, [&](int K) { \
+            constexpr int SL = conv6_shape<MB, NBW, SKIP>::SLOTS;                                                                    \
+            static_assert(SL >= NPS, "a step has a DMA slot for each piece of a window");                                          \
+            if (issue) {                                                                                                           \
+                _Pragma("unroll") for (int j = 0; j < NPS; ++j) if (j * SL / NPS == K) dma_piece(j);                                \
+            }                                                                                                                      \
+        });                                                                                                                        \
+        if (!last) {                                                                                                               \
+            if (issue) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); /* NPS */                                       \
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                       \
+            __builtin_amdgcn_s_barrier();                                                                                          \
+            w = bn;                                                                                                                \
+            ckz = nxkz, cch = nxch, nxkz = n2kz, nxch = n2ch;                                                                       \
+            if (nxkz >= 0) next_window(nxkz, nxch, n2kz, n2ch);                                                                     \
+            conv6_prime<NBW, CR>(ring, bhn, bhn ^ 64u);                                                                             \
+        }                                                                                                                          \
+    }
+#define CONV6_PHASE1(NBW, SKIP, NST)                                                                                               \
+    {                                                                                                                              \
+        const int nst = (NST);                                                                                                     \
+        int j = 0;                                                                                                                 \
+        for (; j + 1 < nst; j += 2) {                                                                                              \
+            CONV6_STEP1(0, NBW, SKIP, false)                                                                                       \
+            CONV6_STEP1(1, NBW, SKIP, j + 2 >= nst)                                                                                \
+        }                                                                                                                          \
+        if (j < nst) CONV6_STEP1(0, NBW, SKIP, true)                                                                               \
+    }
+#define CONV6_LOOP1(NBW)                                                                                                           \
+    {                                                                                                                              \
+        _Pragma("unroll") for (int a = 0; a < MB; ++a) _Pragma("unroll") for (int b = 0; b < (NBW); ++b) {                          \
+            acc[a][b] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};                                                                            \
+            asm volatile("" : "+a"(acc[a][b]));                                                                                     \
+        }                                                                                                                          \
+        int nxkz, nxch, n2kz = -1, n2ch = 0;                                                                                       \
+        next_window(ckz, cch, nxkz, nxch);                                                                                         \
+        if (nxkz >= 0) next_window(nxkz, nxch, n2kz, n2ch);                                                                         \
+        _Pragma("unroll 1") for (int pw = 0; pw < 2; ++pw) { /* windows 0 and 1 into buffers 0 and 1 */                             \
+            if (pw == 1 && nxkz < 0) break;                                                                                        \
+            dma_setup(pw ? nxkz : ckz, pw ? nxch : cch, pw);                                                                       \
+            asm volatile("s_nop 7" ::: "memory");                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < NPS; ++i) {                                                                       \
+                dma_piece(i);                                                                                                      \
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); /* 64 cycles between two pieces */     \
+            }                                                                                                                      \
+        }                                                                                                                          \
+        load_a(areg[0], ckz * g.nchunk + cch);                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                              \
+        int w = 0;                                                                                                                 \
+        conv6_prime<NBW, CR>(ring, lane_addr(0), lane_addr(0) ^ 64u);                                                               \
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");                                                                           \
+        CONV6_PHASE1(NBW, false, nw0)                                                                                              \
+        CONV6_PHASE1(NBW, true, nw1)                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");                                        \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) asm volatile("" ::"v"(areg[0][k]), "v"(areg[1][k]));                          \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) asm volatile("" ::"v"(ring[k][0]), "v"(ring[k][1]));                          \
+    }
     CONV6_STAMP(1)
-    if (nbw == NBT6) CONV6_LOOP(13)
-    else if constexpr (MB == 4) {                  // (M = 128: the two pixel halves of the tile)
-        if (nbw == 7) CONV6_LOOP(7) else CONV6_LOOP(6)
+    if constexpr (STREAM) {
+        if (nbw == NBT6) CONV6_LOOP1(13)
+        else if constexpr (MB == 4) {
+            if (nbw == 7) CONV6_LOOP1(7) else CONV6_LOOP1(6)
+        }
+    } else {
+        if (nbw == NBT6) CONV6_LOOP(13)
+        else if constexpr (MB == 4) {              // (M = 128: the two pixel halves of the tile)
+            if (nbw == 7) CONV6_LOOP(7) else CONV6_LOOP(6)
+        }
     }
     CONV6_STAMP(2)
 #undef CONV6_LOOP
 #undef CONV6_PHASE
 #undef CONV6_STEP
+#undef CONV6_LOOP1
+#undef CONV6_PHASE1
+#undef CONV6_STEP1
     __syncthreads();                               // the window buffers become the epilogue's staging areas
 
     // ---- epilogue: accumulators (lane: pixel li, couts 16 m + 4 lkg ..) -> wave-private LDS patch [pixel][16 MB couts] -> 8 couts of one
@@ -441,10 +520,10 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 
 // window geometry for a descriptor; false when this kernel does not serve it
 static bool plan6(const ppms_conv* d, Geo6& g) {
-    const bool gemm = d->kw == 1 && d->kh == 1;
-    g.mode = gemm ? 3 : (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);
+    const bool stream = d->kw == 1 && d->kh == 1;         // no spatial taps: the STREAM form (one k32-step per window, three buffers)
+    g.mode = stream ? 4 : (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);
     const int hx = (g.mode == 0 || g.mode == 2) ? d->kw - 1 : 0, hy = (g.mode == 1 || g.mode == 2) ? d->kh - 1 : 0;
-    g.cpw = gemm ? 64 : 32;
+    g.cpw = 32;
     int nchunk = 0;
     for (int s = 0; s < d->nseg; ++s) {
         if (d->seg[s].c <= 0 || d->seg[s].c % g.cpw) return false;
@@ -456,12 +535,12 @@ static bool plan6(const ppms_conv* d, Geo6& g) {
     g.tiles_x = (d->W + NBT6 - 1) / NBT6;
     g.tiles_y = (d->H + 15) / 16;
     g.WH = 16 + hy;
-    g.WC = gemm ? 2 * NBT6 : NBT6 + hx;
+    g.WC = NBT6 + hx;
     g.hxl = hx >> 1;
     g.hyl = hy >> 1;
     g.yinc = 0, g.ywrap = 0;
-    if (g.mode == 3) {
-        g.nsweep = 2, g.swx_n = 1 << 30, g.inc = NBT6 * 16, g.jump = 0;
+    if (g.mode == 4) {
+        g.nsweep = 1, g.swx_n = 1 << 30, g.inc = 0, g.jump = 0;
     } else if (g.mode == 0) {
         g.nsweep = d->kw, g.swx_n = 1 << 30, g.inc = g.WH, g.jump = 0;
     } else if (g.mode == 1) {
@@ -471,16 +550,10 @@ static bool plan6(const ppms_conv* d, Geo6& g) {
     }
     const int rows = g.WH * g.WC;
     if (g.lz0 < nchunk && ((g.lz0 * g.nsweep) & 1)) g.lz0 = nchunk;   // (phase 0 must hold an even number of steps: else every product is computed)
-    // Convolutions WITHOUT spatial taps are not served.  The mode exists in the kernel (two 32-channel chunks per window, the "sweep" steps through
-    // them) and passes the op tests, but (a) nothing re-uses a window there, so every pair of k32-steps needs 13 LDS-DMA pieces per wave with nobody
-    // to hide their issue behind: measured no faster than conv_gemm5 / conv_gemm2 / gemm1 (zr3_x 151 vs 149 us, q3_x 103 us, convf1 47 vs ~25 us),
-    // and (b) tools/conv6_stress.py shows rare wrong pixels there (M = 128: a few hundred per launch, always the second pixel block of a wave pair;
-    // M = 192 / 256: one launch in a hundred) that the 64-cycle spacing of the LDS-DMA pieces did not remove -- unexplained.  Every served mode is
-    // clean over hundreds of back-to-back launches (tests/test_gpu_concurrency.py).
-    if (gemm) return false;
     g.npieces = (rows * 8 + NT6 - 1) / NT6;
-    g.wbytes = conv6_np(g.WH) * NT6 * 16;
+    g.wbytes = (stream ? 7 : conv6_np(g.WH)) * NT6 * 16;
     g.P = (int64_t)d->T * d->H * d->W;
+    if (stream) return g.npieces == 7;
     return (g.WH == 16 || g.WH == 18 || g.WH == 20) && g.npieces <= conv6_np(g.WH) && g.nsweep >= 2;
 }
 
@@ -498,7 +571,7 @@ static bool conv6_offsets_fit(const ppms_conv* d) {
 }
 
 static size_t conv6_lds(const ppms_conv* d, const Geo6& g) {
-    size_t lds = (size_t)2 * g.wbytes;
+    size_t lds = (size_t)(g.mode == 4 ? 3 : 2) * g.wbytes;
     const size_t stg = (size_t)4 * STG6_ROWS * ((d->M == 192 ? 48 : 64) + 4) * 4;
     return lds < stg ? stg : lds;
 }
@@ -565,8 +638,8 @@ extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, vo
     }
     PPMS_REQUIRE(conv6_offsets_fit(d), "conv_gemm6: the lo plane of a segment must follow its hi plane inside one 4 GiB range (32-bit window offsets)");
     Geo6 g;
-    PPMS_REQUIRE(plan6(d, g), "conv_gemm6: not a convolution this kernel serves (segments in multiples of 32 channels -- 64 without spatial taps --, "
-                              "a spatial sweep -- kh > 1 or kw > 1 --, a halo'd 16 x 13 window of <= 14 DMA pieces per thread)");
+    PPMS_REQUIRE(plan6(d, g), "conv_gemm6: not a convolution this kernel serves (segments in multiples of 32 channels, a halo'd 16 x 13 window of <= 14 DMA "
+                              "pieces per thread)");
     const size_t lds = conv6_lds(d, g);
     PPMS_REQUIRE(lds <= 160 * 1024, "conv_gemm6: LDS budget exceeded (%zu B)", lds);
     const int ntiles = g.tiles_x * g.tiles_y * d->T;
@@ -576,12 +649,17 @@ extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, vo
 #define CONV6_ATTR(MBV, CRV) (void)hipFuncSetAttribute((const void*)conv6_kernel<MBV, CRV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         CONV6_ATTR(4, 16) CONV6_ATTR(4, 18) CONV6_ATTR(4, 20) CONV6_ATTR(3, 16) CONV6_ATTR(3, 18) CONV6_ATTR(3, 20)
 #undef CONV6_ATTR
+        (void)hipFuncSetAttribute((const void*)conv6_kernel<4, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv6_kernel<3, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
 #ifdef PPMS_CONV6_TIMING
     g.dbg = g_conv6_dbg;
 #endif
 #define CONV6_GO(MBV, CRV) hipLaunchKernelGGL((conv6_kernel<MBV, CRV>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g)
-    if (d->M == 192) {
+    if (g.mode == 4) {
+        if (d->M == 192) hipLaunchKernelGGL((conv6_kernel<3, 16, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+        else hipLaunchKernelGGL((conv6_kernel<4, 16, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+    } else if (d->M == 192) {
         if (g.WH == 16) CONV6_GO(3, 16); else if (g.WH == 18) CONV6_GO(3, 18); else CONV6_GO(3, 20);
     } else {
         if (g.WH == 16) CONV6_GO(4, 16); else if (g.WH == 18) CONV6_GO(4, 18); else CONV6_GO(4, 20);

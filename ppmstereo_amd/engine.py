@@ -35,6 +35,7 @@ TOP_K = 5
 TUNING = dict(
     conv5=True,           # one 8-wave workgroup per CU, 7- / 8-block tiles (conv_gemm5.hip) where it applies
     conv6=True,           # one wave per SIMD on the 16x16x32 MFMA, 16 x 13-pixel tiles (conv_gemm6.hip, round 5) where the library rates its fill >= 85 %
+    conv6_stream=True,    # conv_gemm6's STREAM form for the (5,1,1) convs of the GRU's pass T (else conv_gemm5 / conv_gemm2)
     conv6_pad2x=False,    # conv_gemm6 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 50 us instead of 63 + 117 us of K-sliced launch + reduce, but on the side stream it takes whole CUs from convc2: 35.5 vs 35.4 ms per clip)
     conv5_sliced=False,   # its K-sliced form on the 1/8, 1/16 maps: correct (tests) but slower than conv_gemm2's slicing there
     conv5_gemm=True,      # its GEMM mode for the 256-cout convs without a spatial sweep ((5,1,1) GRU pass, 1x1 heads)
@@ -268,6 +269,12 @@ class PackedBlock:
             elif w5.shape[3] > 1:
                 sweep = w5.transpose(3, 4).contiguous()                      # y sweep: kh / kw swapped
             rows = (max(cout_map) + 1) if cout_map is not None else w5.shape[0]
+            if TUNING["conv6"] and TUNING["conv6_stream"] and w5.shape[2] > 1 and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith(("_y", "_p")):
+                # (kt,1,1) convs to 256 couts (the z/r conv of the GRU's pass T): conv_gemm6's STREAM form -- one k32-step per 32-channel window of a temporal
+                # tap, three window buffers (1/4 scale: 131 us against conv_gemm5's 155; the 128-cout q conv stays on conv_gemm2: 85 us against 89 there)
+                pads6 = list(seg_pad) if seg_pad is not None else [((c + 31) // 32) * 32 for c in segs]
+                if all(p % 32 == 0 for p in pads6):
+                    self.w6[name] = _packing.pack_conv6(w5, bias, segs, pads6, cout_map, 128 if rows <= 128 else (192 if rows <= 192 else 256))
             if TUNING["conv5"] and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
                 # conv_gemm5 serves 128, 192 and 256 rows (192: three 64-cout blocks dealt over the eight waves, round 4 -- convc2's 192 and
                 # final_conv's 190 couts no longer run padded to 256)

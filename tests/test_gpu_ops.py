@@ -623,6 +623,9 @@ CONV6_CASES = [
     ("3x3_m256", 2, 13, 45, [128], 256, (1, 3, 3)), ("3x3_two_segs_m128", 3, 9, 13, [128, 128], 128, (1, 3, 3)), ("3x3x3_m256_T4", 4, 17, 19, [128], 200, (3, 3, 3)),
     ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3)), ("x15_w24", 1, 9, 24, [32], 128, (1, 1, 15)), ("y3_m128", 2, 20, 30, [64], 128, (1, 3, 1)),
     ("T1_tiny", 1, 1, 3, [32], 130, (3, 3, 3)),
+    # no spatial taps: the STREAM form (one k32-step per window, three window buffers) -- the GRU's pass T, a plain 1x1, one frame, ragged maps
+    ("t5_gru_m256", 5, 20, 40, [128, 256], 256, (5, 1, 1)), ("t5_m128_ragged", 5, 17, 29, [128], 100, (5, 1, 1)), ("t3_m256_200", 4, 20, 30, [64, 32], 200, (3, 1, 1)),
+    ("1x1_m256", 2, 20, 30, [128], 256, (1, 1, 1)), ("t5_T1", 1, 9, 24, [32], 128, (5, 1, 1)), ("1x1_one_window", 1, 16, 13, [32], 128, (1, 1, 1)),
 ]
 
 
@@ -673,7 +676,8 @@ def test_conv_gemm6_three_cout_blocks_vs_torch(lib, name, T, H, W, segs, cout, k
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3,lz", [
     ("gru_1x15", 2, 12, 128, [128, 256], 256, (1, 1, 15), 256), ("q_1x5_m128", 2, 12, 128, [128, 256], 128, (1, 1, 5), 256),
     ("y_1x5x1", 2, 40, 32, [128, 256], 256, (1, 5, 1), 256), ("t_3x3x3_two_phases", 4, 16, 40, [128, 256], 256, (3, 3, 3), 256),
-    ("3x3_m192_one_segment", 2, 13, 45, [320], 190, (1, 3, 3), 192)])
+    ("3x3_m192_one_segment", 2, 13, 45, [320], 190, (1, 3, 3), 192), ("t5_stream_gru", 5, 12, 40, [128, 256], 256, (5, 1, 1), 256),
+    ("t5_stream_q_m128", 5, 12, 40, [128, 256], 128, (5, 1, 1), 256)])
 def test_conv_gemm6_skips_products_with_a_zero_lo_plane(lib, name, T, H, W, segs, cout, k3, lz):
     """ppms_conv.lo_zero_from on conv_gemm6: the windows whose lo plane is all zero run in a second phase of the K loop whose step body has no
     hi x lo MFMAs.  Same bits as the full product where both visit the windows in the same order (one temporal tap); with temporal taps the
@@ -732,7 +736,7 @@ def test_conv_gemm6_full_map_and_rating(lib):
     T, H, W = 5, 80, 128
     P = T * H * W
     for segs, cout, k3, m_pad in (([128, 256], 256, (1, 1, 15), 256), ([128], 256, (1, 3, 3), 256), ([128, 256], 128, (1, 1, 5), 128),
-                                  ([320], 190, (1, 3, 3), 192), ([128], 256, (3, 3, 3), 256)):
+                                  ([320], 190, (1, 3, 3), 192), ([128], 256, (3, 3, 3), 256), ([128, 256], 256, (5, 1, 1), 256), ([128, 256], 128, (5, 1, 1), 128)):
         xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
         cin = sum(segs)
         wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
@@ -747,8 +751,8 @@ def test_conv_gemm6_full_map_and_rating(lib):
     assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 1
     d.T, d.H, d.W = 5, 40, 64
     assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 0
-    d.T, d.H, d.W, d.kh, d.kw = 5, 80, 128, 1, 1                        # no spatial taps: not served (see conv_gemm6.hip: plan6)
-    assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 0
+    d.T, d.H, d.W, d.kh, d.kw, d.kt = 5, 80, 128, 1, 1, 5               # no spatial taps: the STREAM form
+    assert lib.load().ppms_conv_gemm6_applicable(C.byref(d)) == 1
 
 
 def test_conv_gemm6_two_epilogue_halves(lib):

@@ -20,7 +20,7 @@ P = T * H * W
 L.load()
 cases = [("x5_m128", [128], 128, (1, 1, 5)), ("3x3_m256", [128], 256, (1, 3, 3)), ("y5_m128", [128, 256], 128, (1, 5, 1)), ("x15_m256", [128, 256], 256, (1, 1, 15)),
          ("3x3_m192", [320], 190, (1, 3, 3)), ("3x3x3_m256", [128], 256, (3, 3, 3)), ("x5_m256_two_segs", [128, 256], 256, (1, 1, 5)), ("3x3_m128", [128, 128], 128, (1, 3, 3))]
-if os.environ.get("GEMM"):                # convolutions without spatial taps: the mode the library refuses (plan6) -- needs a build without that refusal
+if os.environ.get("GEMM", "1") != "0":    # convolutions without spatial taps: the STREAM form (one k32-step per window, three window buffers)
     cases += [("1x1_m128_K128", [128], 128, (1, 1, 1)), ("1x1_m128_K256", [256], 128, (1, 1, 1)), ("t5_m128", [128], 128, (5, 1, 1)), ("1x1_m192_K128", [128], 192, (1, 1, 1)),
               ("1x1_m256_K256", [256], 256, (1, 1, 1))]
 only = os.environ.get("CASES")
