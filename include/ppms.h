@@ -71,7 +71,10 @@ typedef struct ppms_epilogue {
     ppms_sp out_sp;               /* optional (hi == NULL: skip)                                   */
     float* out_f32;               /* optional [pixel][out_f32_ld]                                  */
     int32_t out_f32_ld;
-    void* out_vt;                 /* optional bf16 [frame][n_valid][H*W] (transposed, attention V) */
+    int32_t vt_f16;               /* format of out_vt: 0 = bf16(y); 1 = the fp16 image of bf16(y), saturated at +-65504 -- the same numbers
+                                   * (every bf16 value of magnitude 2^-14 .. 65504 is an fp16 value; below, fp16 subnormals keep 2^-25 absolute)
+                                   * in the operand format of ppms_mem_attn's PPMS_ATTN_P_FP16 mode.  (Sits in what was padding: ABI size unchanged.) */
+    void* out_vt;                 /* optional 16-bit [frame][n_valid][H*W] (transposed, attention V), format: vt_f16 */
     ppms_sp aux_sp;               /* residual / h                                                  */
     const float* aux_f32;         /* z                                                             */
     int32_t aux_f32_ld;
@@ -287,18 +290,25 @@ int ppms_attn_prep_q(const float* q, int ld, const float* pe, void* qb, int T, i
 /* K' = bf16(K_j * s_hat_ij + PE_j) for the picked frames (ppmstereo.py:541,547); kb: bf16 [T][ksel][n][128] */
 int ppms_attn_prep_k(const float* key, int ld, const float* pe, const int32_t* sel, const float* shat, void* kb, int T, int ksel,
                      int n, void* stream);
+enum { PPMS_ATTN_P_BF16 = 0, PPMS_ATTN_P_FP16 = 1 };   /* ppms_mem_attn: p_format */
 /* flash_attn_func call of ppmstereo.py:550 for all T clips + the aggregation of :552:
  * hid = bf16(softmax(Q K'^T * scale) V); mfg = mf + beta * hid.
- * qb: bf16 [T][n][128]; kb: bf16 [T][ksel][n][128]; vt: bf16 [T][128][n] (per-frame transposed values, picked through
- * sel); mf / mfg: SP views (128 channels).  out_bf16 (optional): bf16 [T][n][128] raw attention output.
+ * qb: bf16 [T][n][128]; kb: bf16 [T][ksel][n][128]; vt: 16-bit [T][128][n] (per-frame transposed values, picked through
+ * sel; format: p_format); mf / mfg: SP views (128 channels).  out_bf16 (optional): bf16 [T][n][128] raw attention output.
+ * p_format: the 16-bit format in which the unnormalised probabilities P~ = exp(S - m) enter the P~ V product on the matrix cores, and the
+ * format of vt.  The reference's shim evaluates that product with fp32 P and bf16-rounded V (tools/gen_golden.py:89-95; flash-attention itself
+ * rounds P~ to bf16).  PPMS_ATTN_P_BF16: P~ and vt in bf16 (8 significand bits on P~).  PPMS_ATTN_P_FP16: P~ in fp16 (11 bits), vt = the fp16
+ * image of the bf16-rounded values (ppms_epilogue.vt_f16 = 1): V is still "cast to bf16" as ppmstereo.py:550 does, Q K'^T is computed on
+ * bf16 operands either way, the MFMA count is the same -- an eighth of the P~ rounding error (what keeps the iters = 20 cascade inside 1e-3 px).
  * mf.hi == NULL: no aggregation -- the `mfg` view receives hid itself (hi plane = hid, lo plane = 0: bf16-exact channels, see
  * ppms_conv.lo_zero_from; the caller then feeds the convolutions [mf | hid] with weights (W_mf + W_mfg | beta W_mfg), the same sum). */
 int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
-                  ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, void* stream);
+                  ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, int p_format, void* stream);
 /* split_ws (optional, caller-owned, ppms_mem_attn_workspace_bytes(T, ksel, n) bytes, contents need not be
  * initialised): when given, every picked frame (or pair of picked frames) is processed by its own workgroups, which leave fp32 partials
  * (O, m, l) in the workspace, and a combine kernel merges them; with n % 64 == 0 this is the 64-queries-per-wave
- * LDS-DMA kernel (rescale-free accumulation + a fix-up pass for tiles it flags, see mem_attn.hip).  NULL = one fused
+ * LDS-DMA kernel (rescale-free accumulation + a fix-up pass for tiles it flags -- scores more than 2^60 (bf16 P~) / 2^16 (fp16 P~) above
+ * the softmax reference of their query, see mem_attn.hip).  NULL = one fused
  * launch of the 32-query online-softmax kernel.
  * frames_per_workgroup: the 64-query kernel gives a workgroup ONE picked frame, or TWO consecutive ones where the one-frame grid would
  * run at least two rounds on the chip (fewer partials to write and combine).  0 = the library's choice, 1 / 2 = this call uses that

@@ -13,7 +13,23 @@ from . import build as _build
 c_void_p, c_int, c_float, c_int64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
 EPI_STORE, EPI_RESID, EPI_RH, EPI_GRU, EPI_ADDF32 = range(5)
+ATTN_P_BF16, ATTN_P_FP16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_TANH, ACT_ELU1 = range(6)
+
+
+def vt_image(v: torch.Tensor, p_format: int) -> torch.Tensor:
+    """The 16-bit storage of ppms_mem_attn's transposed value operand for `p_format` (include/ppms.h), as a bfloat16-typed tensor:
+    bf16(v) itself, or -- ATTN_P_FP16 -- the fp16 numbers equal to those bf16 values (saturated at +-65504), bit-cast.  What the
+    to_v convolution's epilogue writes with ppms_epilogue.vt_f16; callers that build V^T themselves (tests, other hosts) use this."""
+    b = v.to(torch.bfloat16)
+    if p_format == ATTN_P_BF16:
+        return b.contiguous()
+    return b.float().clamp(-65504.0, 65504.0).to(torch.float16).contiguous().view(torch.bfloat16)
+
+
+def vt_values(vt: torch.Tensor, p_format: int) -> torch.Tensor:
+    """fp32 values held by a V^T storage tensor (inverse of vt_image)."""
+    return vt.float() if p_format == ATTN_P_BF16 else vt.view(torch.float16).float()
 
 
 class SP(C.Structure):
@@ -23,7 +39,7 @@ class SP(C.Structure):
 
 class Epilogue(C.Structure):
     _fields_ = [("kind", C.c_int32), ("act", C.c_int32), ("scale", c_float), ("n_valid", C.c_int32),
-                ("out_sp", SP), ("out_f32", c_void_p), ("out_f32_ld", C.c_int32), ("out_vt", c_void_p),
+                ("out_sp", SP), ("out_f32", c_void_p), ("out_f32_ld", C.c_int32), ("vt_f16", C.c_int32), ("out_vt", c_void_p),
                 ("aux_sp", SP), ("aux_f32", c_void_p), ("aux_f32_ld", C.c_int32), ("pre_f32_ld", C.c_int32),
                 ("pre_f32", c_void_p)]
 
@@ -112,7 +128,7 @@ _SIGS = {
     "ppms_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, SP, SP, c_int64, c_int, c_void_p]),
     "ppms_linear_attention_workspace_floats": (c_int64, [c_int, c_int, c_int, c_int]),
     "ppms_linear_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, SP, c_int, c_int, c_int, c_int, c_void_p]),
-    "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "ppms_mem_attn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, SP, SP, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ppms_mem_attn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
 }
 EXPORTS = tuple(_SIGS)

@@ -78,6 +78,16 @@ __device__ __forceinline__ void split_bf16(float x, bf16_t& hi, bf16_t& lo) {
     lo = (bf16_t)(x - (float)hi);
 }
 __device__ __forceinline__ float join_bf16(bf16_t hi, bf16_t lo) { return (float)hi + (float)lo; }
+// One element of the attention's transposed value operand V^T (ppms_epilogue.out_vt / vt_f16): bf16(y) as the reference casts V
+// (ppmstereo.py:550) -- or, f16 != 0, the fp16 number equal to that bf16 value (saturated at fp16's largest finite value), returned as
+// the 16 bits a bf16_t store writes.
+__device__ __forceinline__ bf16_t vt_enc(float y, int f16) {
+    const bf16_t b = (bf16_t)y;
+    if (!f16) return b;
+    float v = (float)b;
+    v = v > 65504.0f ? 65504.0f : (v < -65504.0f ? -65504.0f : v);      // (NaN passes)
+    return __builtin_bit_cast(bf16_t, (_Float16)v);
+}
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }      // library-accurate (QAM confidence path)
 

@@ -98,7 +98,7 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
             bf16_t* vp = (bf16_t*)e.out_vt + (frame * e.n_valid + cl) * hw + rem;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, (bf16_t)y[j]);
+                if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, vt_enc(y[j], e.vt_f16));
         }
     }
 }
@@ -124,7 +124,7 @@ __device__ __forceinline__ void epilogue_vt4(const ppms_epilogue& e, const float
     apply_act_n<4>(y, e.act, e.scale);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-        if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, (bf16_t)y[j]);
+        if (j < nv) gst<bf16_t>(vp + (int64_t)j * hw, vt_enc(y[j], e.vt_f16));
 }
 
 // Row form: v[0..7] = acc + bias for couts cl..cl+7 (local to this half, cl % 8 == 0) at pixel pix.

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(128 * WM * KG) void conv2_kernel(const ppms_conv pv
                     apply_act_n<8>(y, e.act, e.scale);
                     bf16x8 o8;
     #pragma unroll
-                    for (int j = 0; j < 8; ++j) o8[j] = (bf16_t)y[j];
+                    for (int j = 0; j < 8; ++j) o8[j] = vt_enc(y[j], e.vt_f16);
                     if (px < W && py < H && cl < e.n_valid) gst<bf16x8>(vrow + (int64_t)py * W + px, o8);
                 }
             }

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm1_kernel(const ppms_conv pv, const in
                 for (int j = 0; j < 8; ++j) y[j] = v[j];
                 apply_act_n<8>(y, e.act, e.scale);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vtp[(q * 8 + j) * 32 + px] = (bf16_t)y[j];
+                for (int j = 0; j < 8; ++j) vtp[(q * 8 + j) * 32 + px] = vt_enc(y[j], e.vt_f16);
             }
         }
     };

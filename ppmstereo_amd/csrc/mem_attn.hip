@@ -31,8 +31,14 @@ __device__ __forceinline__ u32x4 load16_guard(const bf16_t* row, int e0, int lim
     return v;
 }
 
-// TAIL = (n % 64 != 0): only that instantiation carries the per-key masking of a frame's last tile
-template <bool TAIL>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// TAIL = (n % 64 != 0): only that instantiation carries the per-key masking of a frame's last tile.
+// P16: the unnormalised probabilities P~ enter O^T += V^T P~ as fp16 (11 significand bits) instead of bf16 (8), and V^T holds the fp16 image of
+// the bf16-rounded values (ppms_epilogue.vt_f16: the same numbers -- the reference's cast of V to bf16, ppmstereo.py:550, is preserved -- in the
+// operand format of v_mfma_f32_*_f16).  Under the running maximum P~ <= 1, so fp16's range is no constraint here; probabilities below 2^-14 of the
+// row maximum keep an ABSOLUTE precision of 2^-25 (fp16 subnormals), which is 2^-25 of the denominator at most.
+template <bool TAIL, bool P16>
 __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
                                                           const bf16_t* __restrict__ vt, const int32_t* __restrict__ sel, int ksel,
                                                           float scale_log2, const float* __restrict__ beta_p, ppms_sp mf, ppms_sp mfg,
@@ -213,15 +219,27 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
         for (int kblk = 0; kblk < 2; ++kblk) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                bf16x8 pf;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)cur[kblk][8 * s2 + jj];
                 const int chunk = (kblk * 2 + s2) * 2 + h;
+                if constexpr (P16) {
+                    f16x8 pf;
 #pragma unroll
-                for (int dblk = 0; dblk < 4; ++dblk) {
-                    const int d = dblk * 32 + r;
-                    const bf16x8 vf = *(const bf16x8*)(vs + d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4));
-                    o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dblk], 0, 0, 0);
+                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (_Float16)cur[kblk][8 * s2 + jj];
+#pragma unroll
+                    for (int dblk = 0; dblk < 4; ++dblk) {
+                        const int d = dblk * 32 + r;
+                        const f16x8 vf = *(const f16x8*)(vs + d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4));
+                        o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, o[dblk], 0, 0, 0);
+                    }
+                } else {
+                    bf16x8 pf;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)cur[kblk][8 * s2 + jj];
+#pragma unroll
+                    for (int dblk = 0; dblk < 4; ++dblk) {
+                        const int d = dblk * 32 + r;
+                        const bf16x8 vf = *(const bf16x8*)(vs + d * 128 + ((chunk ^ ((d >> 1) & 7)) << 4));
+                        o[dblk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[dblk], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -353,6 +371,7 @@ static __device__ long long* g_attn_dbg_dev = nullptr;          // debug builds 
 
 __device__ __forceinline__ int att_kswz(int row) { return (row & 3) | ((row >> 1) & 12); }
 
+template <bool P16>
 __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __restrict__ qb, const bf16_t* __restrict__ kb,
                                                              const bf16_t* __restrict__ vt_g, const int32_t* __restrict__ sel, int ksel,
                                                              float scale_log2, int n, float* __restrict__ part_o, float* __restrict__ part_ml,
@@ -491,7 +510,8 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     }
     u32x4 ring[4], vt[8] = {}, pf[QB] = {};
     f32x4 lacc[QB] = {(f32x4){0}, (f32x4){0}, (f32x4){0}, (f32x4){0}};
-    u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    constexpr unsigned ONE2 = P16 ? 0x3c003c00u : 0x3f803f80u;      // two ones in the format of P~
+    u32x4 ones = {ONE2, ONE2, ONE2, ONE2};
     asm volatile("" : "+v"(ones));
     f32x2 pt[2], tt[2];
     attn64_prime(sa, ring, pt, tt, negm, scale_log2, kaddr);
@@ -505,8 +525,8 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
         const char* vp = v_tile(jn);
         const unsigned dst[8] = {st, st + 4096u, st + 8192u, st + 12288u, st + K_TILE, st + K_TILE + 4096u, st + K_TILE + 8192u, st + K_TILE + 12288u};
         const int delta = ((j + 1) & (ATT_NS - 1)) ? ATT_STAGE : -(ATT_NS - 1) * ATT_STAGE;      // stage of tile j -> stage of tile j + 1
-        attn64_substep<0>(sa, sb, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
-        attn64_substep<1>(sb, sa, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
+        attn64_substep<0, P16>(sa, sb, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
+        attn64_substep<1, P16>(sb, sa, qf, o, ring, vt, pf, pt, tt, lacc, ones, negm, scale_log2, kaddr, vaddr, delta, koff, voff, kp, vp, dst);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // tiles <= j + 2 have landed (this thread's share; the barrier covers the others')
 #if !defined(PPMS_ATTN_NOSYNC)
         __builtin_amdgcn_s_barrier();
@@ -516,11 +536,20 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     attn64_tail();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // no LDS-DMA may be in flight when the workgroup's LDS is handed on
     ATTN_STAMP(2)
+    if constexpr (P16) {
 #pragma unroll
-    for (int dblk = 0; dblk < 8; ++dblk)          // O^T[:, qb 3] += V^T P of the last sub-tile
-        o[dblk][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vt[dblk]), __builtin_bit_cast(bf16x8, pf[3]), o[dblk][3], 0, 0, 0);
-    lacc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[3]), lacc[3], 0, 0, 0);
-    // a score more than 2^60 above the reference (or a NaN) anywhere shows in the sum: the fix-up pass redoes the tile
+        for (int dblk = 0; dblk < 8; ++dblk)      // O^T[:, qb 3] += V^T P of the last sub-tile
+            o[dblk][3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, vt[dblk]), __builtin_bit_cast(f16x8, pf[3]), o[dblk][3], 0, 0, 0);
+        lacc[3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, ones), __builtin_bit_cast(f16x8, pf[3]), lacc[3], 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int dblk = 0; dblk < 8; ++dblk)
+            o[dblk][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, vt[dblk]), __builtin_bit_cast(bf16x8, pf[3]), o[dblk][3], 0, 0, 0);
+        lacc[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, ones), __builtin_bit_cast(bf16x8, pf[3]), lacc[3], 0, 0, 0);
+    }
+    // a score too far above the reference (or a NaN) anywhere shows in the sum: the fix-up pass redoes the tile.  bf16 P~: more than 2^60 above.
+    // fp16 P~: a probability beyond fp16's largest finite value (65 504 ~ 2^16) converts to +inf and the sum with it, so the bound is "l finite"
+    // (sums of finite fp16 values stay far below 2^60: at most 2^16 per key)
     bool bail = false;
 #pragma unroll
     for (int q = 0; q < QB; ++q) bail = bail || !(lacc[q][0] <= 0x1p60f);
@@ -606,26 +635,20 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
 #ifdef PPMS_ATTN_TIMING
 extern "C" void ppms_debug_attn_timing(long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dbg_dev), &p, sizeof(p)); }   // tools/attn_phase_probe.py
 #endif
-extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
-                             ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, void* stream) {
-    PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
-    PPMS_REQUIRE(ksel >= 1 && ksel <= 5 && T >= 1 && n >= 1, "mem_attn: bad sizes ksel=%d T=%d n=%d", ksel, T, n);
-    PPMS_REQUIRE(frames_per_workgroup >= 0 && frames_per_workgroup <= 2, "mem_attn: frames_per_workgroup must be 0 (automatic), 1 or 2, got %d", frames_per_workgroup);
-    PPMS_REQUIRE(((mf.hi && mf.lo && mf.ld % 8 == 0) || (!mf.hi && !mf.lo)) && mfg.hi && mfg.lo && mfg.ld % 8 == 0,
-                 "mem_attn: mf (or a NULL view: the output is hid itself) / mfg must be 16-B aligned SP views");
+template <bool P16>
+static void launch_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale_log2, const float* beta, ppms_sp mf,
+                            ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, hipStream_t st) {
     static ppms_device_once once;
     once.run([] {
-        (void)hipFuncSetAttribute((const void*)mem_attn_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        (void)hipFuncSetAttribute((const void*)mem_attn_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
-        (void)hipFuncSetAttribute((const void*)mem_attn64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)mem_attn_kernel<false, P16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)mem_attn_kernel<true, P16>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ATT_STAGE);
+        (void)hipFuncSetAttribute((const void*)mem_attn64_kernel<P16>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_NS * ATT_STAGE);
     });
-    const float scale_log2 = scale * 1.4426950408889634f;
     // split over the picked frames when a workspace is given (ppms_mem_attn_workspace_bytes) and there is more than one
     const bool use64 = split_ws != nullptr && n % KT == 0;      // (its state lives in the workspace partials)
     const bool split = use64 || (split_ws != nullptr && ksel > 1);
     float* part_o = split ? (float*)split_ws : nullptr;
     float* part_ml = split ? part_o + (size_t)T * ksel * n * D : nullptr;
-    hipStream_t st = (hipStream_t)stream;
     int nsp = ksel;                                             // partial sets per clip
     if (use64) {
         const int g64 = (int)ceil_div(n, 64 * NW);
@@ -634,17 +657,17 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         const int sps = frames_per_workgroup ? frames_per_workgroup : ((g64 * T * ksel >= 2 * ppms_num_cus() && ksel > 1) ? 2 : 1);
         nsp = (int)ceil_div(ksel, sps);
         dim3 grid64(g64, T, nsp), grid32(ceil_div(n, QW * NW), T, nsp);
-        hipLaunchKernelGGL(mem_attn64_kernel, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+        hipLaunchKernelGGL(mem_attn64_kernel<P16>, grid64, dim3(256), ATT_NS * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                            sel, ksel, scale_log2, n, part_o, part_ml, redo, sps);
-        hipLaunchKernelGGL(mem_attn_kernel<false>, grid32, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+        hipLaunchKernelGGL((mem_attn_kernel<false, P16>), grid32, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                            sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, redo, 2 * g64, sps);
     } else {
         dim3 grid(ceil_div(n, QW * NW), T, split ? ksel : 1);
         if (n % KT)
-            hipLaunchKernelGGL(mem_attn_kernel<true>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+            hipLaunchKernelGGL((mem_attn_kernel<true, P16>), grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                                sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, (int32_t*)nullptr, 0, 1);
         else
-            hipLaunchKernelGGL(mem_attn_kernel<false>, grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
+            hipLaunchKernelGGL((mem_attn_kernel<false, P16>), grid, dim3(256), 2 * ATT_STAGE, st, (const bf16_t*)qb, (const bf16_t*)kb, (const bf16_t*)vt,
                                sel, ksel, scale_log2, beta, mf, mfg, (bf16_t*)out_bf16, n, part_o, part_ml, (int32_t*)nullptr, 0, 1);
     }
     if (split) {
@@ -652,6 +675,21 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
         hipLaunchKernelGGL(attn_combine_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, st, part_o, part_ml, nsp, beta, mf, mfg,
                            (bf16_t*)out_bf16, n, total);
     }
+}
+
+extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t* sel, int ksel, float scale, const float* beta,
+                             ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, int p_format, void* stream) {
+    PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
+    PPMS_REQUIRE(ksel >= 1 && ksel <= 5 && T >= 1 && n >= 1, "mem_attn: bad sizes ksel=%d T=%d n=%d", ksel, T, n);
+    PPMS_REQUIRE(frames_per_workgroup >= 0 && frames_per_workgroup <= 2, "mem_attn: frames_per_workgroup must be 0 (automatic), 1 or 2, got %d", frames_per_workgroup);
+    PPMS_REQUIRE(p_format == PPMS_ATTN_P_BF16 || p_format == PPMS_ATTN_P_FP16, "mem_attn: p_format must be PPMS_ATTN_P_BF16 (0) or PPMS_ATTN_P_FP16 (1), got %d", p_format);
+    PPMS_REQUIRE(((mf.hi && mf.lo && mf.ld % 8 == 0) || (!mf.hi && !mf.lo)) && mfg.hi && mfg.lo && mfg.ld % 8 == 0,
+                 "mem_attn: mf (or a NULL view: the output is hid itself) / mfg must be 16-B aligned SP views");
+    const float scale_log2 = scale * 1.4426950408889634f;
+    if (p_format == PPMS_ATTN_P_FP16)
+        launch_mem_attn<true>(qb, kb, vt, sel, ksel, scale_log2, beta, mf, mfg, out_bf16, T, n, split_ws, frames_per_workgroup, (hipStream_t)stream);
+    else
+        launch_mem_attn<false>(qb, kb, vt, sel, ksel, scale_log2, beta, mf, mfg, out_bf16, T, n, split_ws, frames_per_workgroup, (hipStream_t)stream);
     return ppms_check_launch("mem_attn");
 }
 

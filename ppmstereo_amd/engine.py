@@ -60,6 +60,9 @@ TUNING = dict(
     convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
     conv5_m192=True,      # conv_gemm5's three-cout-block layout for the 190 / 192-cout convs (else padded to 256 rows)
     fork_min_pixels=0,    # independent branches of an iteration run on the side stream only on maps with at least this many pixels (0: always)
+    attn_p="fp16",        # format of the unnormalised probabilities P~ in the memory read-out's P~ V product (and of the V^T image the to_v conv writes):
+                          # "fp16" = 11 significand bits, "bf16" = 8 (what flash-attention itself uses) at the same MFMA count.  The reference fixtures were
+                          # generated with fp32 P (tools/gen_golden.py:89-95); with bf16 P~ the iters = 20 cascade ends 1.3e-3 px from them, with fp16 inside 1e-3
     conv5_pad2x=False,    # conv_gemm5 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 78 us instead of 65 + 143 us
                           # of the K-sliced form, but on the side stream it then competes with convc2 for whole CUs: clip time unchanged, 40.8 ms)
 )
@@ -80,6 +83,14 @@ def temporal_pe(T: int, channels: int) -> torch.Tensor:
     pe[:, 0::2] = torch.sin(ang)
     pe[:, 1::2] = torch.cos(ang)
     return pe
+
+
+def attn_p_format() -> int:
+    """TUNING["attn_p"] as ppms_mem_attn's p_format / ppms_epilogue.vt_f16 (include/ppms.h)."""
+    fmt = TUNING["attn_p"]
+    if fmt not in ("fp16", "bf16"):
+        raise ValueError(f"TUNING['attn_p'] must be 'fp16' or 'bf16', got {fmt!r}")
+    return L.ATTN_P_FP16 if fmt == "fp16" else L.ATTN_P_BF16
 
 
 def softmax_scale(c: int = 128) -> float:
@@ -167,7 +178,7 @@ class ConvOp:
 
 
 def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Optional[L.SP] = None, out_f32=None, out_f32_ld=0,
-             out_vt=None, aux_sp: Optional[L.SP] = None, aux_f32=None, aux_f32_ld=0, pre_f32=None, pre_off=0) -> L.Epilogue:
+             out_vt=None, aux_sp: Optional[L.SP] = None, aux_f32=None, aux_f32_ld=0, pre_f32=None, pre_off=0, vt_f16=None) -> L.Epilogue:
     e = L.Epilogue()
     e.kind, e.act, e.scale, e.n_valid = kind, act, scale, n_valid
     if out_sp is not None:
@@ -175,6 +186,7 @@ def epilogue(kind=L.EPI_STORE, act=L.ACT_NONE, scale=1.0, n_valid=0, out_sp: Opt
     e.out_f32 = None if out_f32 is None else out_f32.data_ptr()
     e.out_f32_ld = out_f32_ld
     e.out_vt = None if out_vt is None else out_vt.data_ptr()
+    e.vt_f16 = attn_p_format() if vt_f16 is None else int(vt_f16)      # (only read with out_vt)
     if aux_sp is not None:
         e.aux_sp = aux_sp
     e.aux_f32 = None if aux_f32 is None else aux_f32.data_ptr()
@@ -443,7 +455,8 @@ class ScaleEngine:
             self.PRE = {k: torch.empty(P, m, dtype=torch.float32, device=device) for k, m in
                         (("zr1_0", 256), ("q1", 128), ("zr2", 256), ("q2", 128), ("zr3", 256), ("q3", 128))}
             self._pre_stream, self._ev_pre, self._pre_pending = torch.cuda.Stream(device=device), torch.cuda.Event(), False
-        self.VT = torch.zeros(T, 128, n, dtype=torch.bfloat16, device=device)
+        self.attn_p = attn_p_format()         # fixed per engine: the to_v descriptor (built below) and every mem_attn call agree on V^T's format
+        self.VT = torch.zeros(T, 128, n, dtype=torch.bfloat16, device=device)      # (16-bit storage: bf16, or the fp16 image of bf16 values)
         self.VTG = self.VT if shard is None else torch.zeros(Tg, 128, n, dtype=torch.bfloat16, device=device)     # values of every frame
         self.KG = None if shard is None else f32(Tg * n, 128)                                                     # keys of every frame
         self.QB = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=device)
@@ -634,7 +647,7 @@ class ScaleEngine:
                                             nslice=1 if (TUNING["convf2_unsliced"] and self.P >= 32768) else None)
             o[f"final_{par}"] = self._conv_padded("final", [cf.view()], k3, E(act=L.ACT_RELU, n_valid=126, out_sp=mf),
                                            E(act=L.ACT_RELU, n_valid=64, out_sp=cf_next.view(256, 64)), m_split=128)
-        o["to_v"] = self._conv("to_v", [mf], k1, E(n_valid=128, out_sp=self.VAL.view(), out_vt=self.VT))
+        o["to_v"] = self._conv("to_v", [mf], k1, E(n_valid=128, out_sp=self.VAL.view(), out_vt=self.VT, vt_f16=self.attn_p))
         o["unc0"] = self._conv("unc0", [H[0].view(), self.VAL.view()], k3, E(act=L.ACT_RELU, n_valid=128, out_sp=self.U1.view()))
         if self.pk.attn is not None:                 # update_block16: time / space attention on x = [inp, mf, mfg]
             o["ta_fc"] = self._conv("ta_fc", [self.O1.view()], k1, E(L.EPI_RESID, n_valid=384, out_sp=self.XT.view(), aux_sp=X.view()))
@@ -904,7 +917,7 @@ class ScaleEngine:
         mf_in = L.SP(None, None, 0, 0) if self.hid_mode else self.X.view(128, 128)
         L.check(self.lib.ppms_mem_attn(self.QB.data_ptr(), self.KB.data_ptr(), self.VTG.data_ptr(), sel, self.ksel, self.scale,
                                        self.pk.beta.data_ptr(), mf_in, self.X.view(256, 128), L.ptr(out_bf16), self.T, self.n,
-                                       self.ATT_WS.data_ptr(), 0, s))
+                                       self.ATT_WS.data_ptr(), 0, self.attn_p, s))
         self._x_hid = self.hid_mode
         if ev is not None:
             ev[1].record()
@@ -924,6 +937,19 @@ class ScaleEngine:
         fam = {k: v for k, v in self.op.items() if isinstance(v, (ConvOp, PwChain, TimedCall))}
         fam.update({f"to_qk_{i}": v for i, v in enumerate(self._qk_ops.values())})
         return fam
+
+    def attn_redo_count(self):
+        """(tiles, flagged): how many (clip, split, 256-query block) tiles the LAST mem_attn call of this engine ran on the 64-query kernel and how
+        many of them that kernel handed to its fix-up pass (a score more than 2^16 -- fp16 P~ -- or 2^60 -- bf16 -- above the query's softmax
+        reference).  Diagnostics (tools/parity_ab.py, bench.py); synchronises.  (0, 0) when the 64-query kernel does not serve this geometry."""
+        if self.n % 64:
+            return 0, 0
+        flags = self.ATT_WS.view(torch.int32)[self.T * self.ksel * self.n * 130:]
+        g64 = (self.n + 255) // 256
+        used = self.T * self.ksel * g64                       # an upper bound on the tiles of the call (two-frame splits use fewer)
+        f = flags[:used * 2:2]
+        torch.cuda.synchronize()
+        return int(used), int((f != 0).sum().item())
 
     def enable_attn_timing(self, launches: int):
         """HIP events (on the stream the kernel is launched on) around the next `launches` mem_attn launches."""

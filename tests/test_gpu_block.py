@@ -508,14 +508,14 @@ def test_attention_is_a_convex_combination(model):
     qb = hash_normal((T, n, 128), 950).to(torch.bfloat16).to(DEV)
     kb = hash_normal((T, 5, n, 128), 951).to(torch.bfloat16).to(DEV)
     cvec = hash_normal((128,), 952)
-    vt = cvec.to(torch.bfloat16)[None, :, None].expand(T, 128, n).contiguous().to(DEV)
+    vt = L.vt_image(cvec[None, :, None].expand(T, 128, n), L.ATTN_P_FP16).to(DEV)
     sel = torch.arange(5, dtype=torch.int32)[None].expand(T, 5).contiguous().to(DEV)
     X = L.SPTensor(T * n, 256, DEV)
     beta = torch.tensor([1.0], device=DEV)
     raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
     ws = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, 5, n)), dtype=torch.uint8, device=DEV)
     L.check(L.load().ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 5, 0.05, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                                   raw.data_ptr(), T, n, ws.data_ptr(), 0, L.stream_ptr()))
+                                   raw.data_ptr(), T, n, ws.data_ptr(), 0, L.ATTN_P_FP16, L.stream_ptr()))
     want = cvec.to(torch.bfloat16).float()
     got = raw.float().cpu()
     assert (got - want).abs().max() <= 0.01 * want.abs().max(), "softmax weights do not sum to one"

@@ -88,7 +88,7 @@ def test_small_kernels_are_unaffected_by_a_concurrent_conv(eng):
     def attn(split):
         def f():
             L.check(lib.ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 5, 0.0522, beta.data_ptr(), Xa.view(0, 128),
-                                      Xa.view(128, 128), raw.data_ptr(), T, n, ws.data_ptr() if split else None, 0, L.stream_ptr()))
+                                      Xa.view(128, 128), raw.data_ptr(), T, n, ws.data_ptr() if split else None, 0, L.ATTN_P_BF16, L.stream_ptr()))
             return raw.float()
         return f
 

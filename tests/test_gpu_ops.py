@@ -474,7 +474,19 @@ def test_gemm1_two_halves_and_transposed_v(lib, T, H, W):
     y = out.to_f32()
     assert maxdiff(y, x2 @ wv[:, :, 0, 0].t()) < 3e-5 * 4
     want = out.own()[0].reshape(T, H * W, 128).permute(0, 2, 1)          # the hi plane IS bf16(y)
-    assert torch.equal(vt, want), "V^T must be the bf16 rounding of the SP output (its hi plane), transposed"
+    from ppmstereo_amd.engine import attn_p_format
+    assert torch.equal(vt, L.vt_image(want, attn_p_format())), "V^T must be the bf16 rounding of the SP output (its hi plane), transposed, in TUNING['attn_p']'s format"
+    # both formats explicitly (ppms_epilogue.vt_f16): bf16 itself / the fp16 image of the same numbers
+    for fmt in (L.ATTN_P_BF16, L.ATTN_P_FP16):
+        vt2 = torch.zeros_like(vt)
+        d.epi[0] = epilogue(n_valid=128, out_sp=out.view(), out_vt=vt2, vt_f16=fmt)
+        ConvOp(d, [x2t, packed, b, out, vt2], 6)()
+        torch.cuda.synchronize()
+        assert torch.equal(vt2, L.vt_image(want, fmt))
+        # the same numbers: exactly, for every bf16 value in fp16's normal range; to 2^-25 absolute below it (fp16 subnormals)
+        held, w32 = L.vt_values(vt2, fmt), want.float()
+        normal = w32.abs() >= 2.0 ** -14
+        assert torch.equal(held[normal], w32[normal]) and (held - w32).abs().max().item() <= 2.0 ** -25
 
 
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3,nslice", [
@@ -943,16 +955,21 @@ def test_qam_select_sequence(lib):
 
 
 # ------------------------------------------------------------------------------------------------ memory attention
-def _attn_check(got, ref, operands, scale):
-    """Per-element bound in bf16 ulps OF THE ELEMENT (not of the tensor's range).  bf16 keeps 8 significant bits: round to
-    nearest moves a value by at most 2^-8 of itself (half an ulp).  With bf16 operands as the oracle uses them the kernel's
-    two extra roundings give err <= 2^-8 * (P |V|) (probabilities rounded to bf16 before the PV product, worst case: all
-    errors aligned) + 2^-8 |ref| (the bf16 result) + 1e-6 fp32 slop; and the typical error must sit far inside that worst
-    case (rounding errors do not all line up)."""
+P_FORMATS = [pytest.param(1, id="p_fp16"), pytest.param(0, id="p_bf16")]      # ppms_mem_attn's p_format (include/ppms.h)
+
+
+def _attn_check(got, ref, operands, scale, p_format=0):
+    """Per-element bound in ulps OF THE ELEMENT (not of the tensor's range).  bf16 keeps 8 significant bits: round to
+    nearest moves a value by at most 2^-8 of itself (half an ulp); fp16 keeps 11: 2^-11.  With bf16 operands as the oracle uses
+    them the kernel's two extra roundings give err <= eps_P * (P |V|) (probabilities rounded to p_format before the PV product,
+    worst case: all errors aligned; eps_P = 2^-8 for bf16 P~, 2^-11 for fp16 P~ -- fp16's subnormal tail adds at most 2^-25 per
+    key relative to the row maximum, covered by the slop) + 2^-8 |ref| (the bf16 result) + 1e-6 fp32 slop; and the typical error
+    must sit far inside that worst case (rounding errors do not all line up)."""
+    eps_p = 2.0 ** -11 if p_format == 1 else 2.0 ** -8
     for i, (Q, K, V, _, _) in enumerate(operands):
         Qb, Kb, Vb = (t.to(torch.bfloat16).float() for t in (Q, K, V))
         P = torch.softmax((Qb @ Kb.t()) * scale, dim=-1)
-        bound = 2.0 ** -8 * (P @ Vb.abs()) + 2.0 ** -8 * ref[i].abs() + 1e-6
+        bound = eps_p * (P @ Vb.abs()) + 2.0 ** -8 * ref[i].abs() + 1e-6
         err = (got[i] - ref[i]).abs()
         assert torch.isfinite(got[i]).all()
         worst = (err / bound).max().item()
@@ -961,10 +978,11 @@ def _attn_check(got, ref, operands, scale):
 
 
 # attn_frames: ppms_mem_attn's frames_per_workgroup argument (0 = the library's choice, which needs a 1/4-scale-sized grid to pick 2)
+@pytest.mark.parametrize("p_format", P_FORMATS)
 @pytest.mark.parametrize("attn_frames", [0, 2])
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5), (5, 320, 5)])      # (320: a partly filled 256-query block)
-def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
+def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames, p_format):
     """prep_q + prep_k + mem_attn against play_inputs + flash_attn_math (ppmstereo.py:517-552)."""
     L = lib
     if attn_frames and not (split and n % 64 == 0):
@@ -992,7 +1010,7 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
     qk = torch.cat([cl(q), cl(key)], 1).contiguous().to(DEV)
     qb = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
     kb = torch.zeros(T, ksel_frames, n, 128, dtype=torch.bfloat16, device=DEV)
-    vt = value.reshape(T, 128, n).to(torch.bfloat16).contiguous().to(DEV)
+    vt = L.vt_image(value.reshape(T, 128, n), p_format).to(DEV)
     ped, seld, shatd = pe.to(DEV), sel.to(DEV), shat.to(DEV)
     lib_ = L.load()
     s = L.stream_ptr()
@@ -1004,15 +1022,15 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
     raw = torch.zeros(T, n, 128, dtype=torch.bfloat16, device=DEV)
     ws = torch.empty(int(lib_.ppms_mem_attn_workspace_bytes(T, ksel_frames, n)), dtype=torch.uint8, device=DEV) if split else None
     L.check(lib_.ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), seld.data_ptr(), ksel_frames, scale, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                               raw.data_ptr(), T, n, L.ptr(ws), attn_frames, s))
+                               raw.data_ptr(), T, n, L.ptr(ws), attn_frames, p_format, s))
     torch.cuda.synchronize()
     # operands: bit-exact bf16 of the oracle's fp32 operands
     Q0, K0, _, _, _ = O.play_inputs(q, key, pe, value, score, mask, 0)
     assert torch.equal(qb[0].float().cpu(), Q0.to(torch.bfloat16).float())
     assert torch.equal(kb[0].reshape(-1, 128).float().cpu(), K0.to(torch.bfloat16).float())
-    # output, per element: the kernel rounds P to bf16 before the PV product (like flash-attention) and the result to bf16
-    # |err_d| <= 2^-8 * sum_k p_k |v_kd| (P rounding, worst case) + half a bf16 ulp of the element (final rounding)
-    _attn_check(raw.float().cpu(), ref, [(O.play_inputs(q, key, pe, value, score, mask, i)) for i in range(T)], scale)
+    # output, per element: the kernel rounds P to p_format before the PV product (flash-attention: bf16) and the result to bf16
+    # |err_d| <= eps_P * sum_k p_k |v_kd| (P rounding, worst case) + half a bf16 ulp of the element (final rounding)
+    _attn_check(raw.float().cpu(), ref, [(O.play_inputs(q, key, pe, value, score, mask, i)) for i in range(T)], scale, p_format)
     mfg = X.to_f32(128, 128).cpu()
     # mfg is stored split (hi + lo): ~2^-16 relative
     assert maxdiff(mfg, cl(mf) + 0.5 * raw.float().cpu().reshape(T * n, 128)) < 1e-4
@@ -1020,19 +1038,21 @@ def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames):
     X.own()[1, :, 128:] = 1.0
     raw2 = torch.zeros_like(raw)
     L.check(lib_.ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), seld.data_ptr(), ksel_frames, scale, beta.data_ptr(), L.SP(None, None, 0, 0), X.view(128, 128),
-                               raw2.data_ptr(), T, n, L.ptr(ws), attn_frames, s))
+                               raw2.data_ptr(), T, n, L.ptr(ws), attn_frames, p_format, s))
     torch.cuda.synchronize()
     assert torch.equal(raw2, raw)
     assert torch.equal(X.own()[0, :, 128:].reshape(T, n, 128), raw) and (X.own()[1, :, 128:] == 0).all()
 
 
+@pytest.mark.parametrize("p_format", P_FORMATS)
 @pytest.mark.parametrize("attn_frames", [0, 2])
-@pytest.mark.parametrize("boost", [40.0, 3.0])
-def test_mem_attn_sharp_softmax(lib, boost, attn_frames):
+@pytest.mark.parametrize("boost", [40.0, 3.0, 0.7])
+def test_mem_attn_sharp_softmax(lib, boost, attn_frames, p_format):
     """(attn_frames = 2: the dominating key sits in the SECOND frame of the workgroup's pair, whose scores are taken relative to the first
     frame's reference.)  One key per query dominates and sits in a late tile.  boost = 40: the score jumps ~650 log2 units above the
-    first keys, far beyond what the rescale-free 64-query kernel carries (2^60): its workgroups raise their redo flags
-    and the 32-query online-softmax kernel recomputes them.  boost = 3: ~50 log2 units, carried in-kernel (P up to 2^50)."""
+    first keys, far beyond what the rescale-free 64-query kernel carries (2^60 with bf16 P~, 2^16 with fp16 P~): its workgroups raise their
+    redo flags and the 32-query online-softmax kernel recomputes them.  boost = 3: ~50 log2 units -- carried in-kernel with bf16 P~ (P up to
+    2^50), redone with fp16 P~.  boost = 0.7: ~11 log2 units, carried in-kernel by both (the flags say which path ran)."""
     L = lib
     from ppmstereo_amd.engine import softmax_scale
     T, n = 2, 512
@@ -1041,7 +1061,7 @@ def test_mem_attn_sharp_softmax(lib, boost, attn_frames):
     v = hash_normal((T, 128, n), 902)
     for i in range(n):
         k[0, 1, (i * 7 + 300) % n] += boost * q[0, i] / q[0, i].norm()
-    qb, kb, vt = q.to(torch.bfloat16).to(DEV), k.to(torch.bfloat16).to(DEV), v.to(torch.bfloat16).to(DEV)
+    qb, kb, vt = q.to(torch.bfloat16).to(DEV), k.to(torch.bfloat16).to(DEV), L.vt_image(v, p_format).to(DEV)
     sel = torch.tensor([[0, 1, 0, 0, 0], [0, 1, 0, 0, 0]], dtype=torch.int32, device=DEV)
     X = L.SPTensor(T * n, 256, DEV)
     beta = torch.tensor([1.0], device=DEV)
@@ -1049,12 +1069,22 @@ def test_mem_attn_sharp_softmax(lib, boost, attn_frames):
     scale = 1.0
     ws = torch.empty(int(L.load().ppms_mem_attn_workspace_bytes(T, 2, n)), dtype=torch.uint8, device=DEV)
     L.check(L.load().ppms_mem_attn(qb.data_ptr(), kb.data_ptr(), vt.data_ptr(), sel.data_ptr(), 2, scale, beta.data_ptr(), X.view(0, 128), X.view(128, 128),
-                                   raw.data_ptr(), T, n, ws.data_ptr(), attn_frames, L.stream_ptr()))
+                                   raw.data_ptr(), T, n, ws.data_ptr(), attn_frames, p_format, L.stream_ptr()))
+    torch.cuda.synchronize()
+    # which path ran: the redo flags of the 64-query kernel sit behind the partials in the workspace (ppms_mem_attn_workspace_bytes)
+    flags = ws.view(torch.int32)[T * 2 * n * 130:].cpu()
+    nsplit = 1 if attn_frames == 2 else 2
+    flags = flags[:T * nsplit * 2 * 2].reshape(T, nsplit, 2, 2)[..., 0]          # [clip][split][256-query block]
+    carried = boost < 1.0 or (boost == 3.0 and p_format == 0)
+    hit = flags[0, nsplit - 1]                                                   # clip 0, the split that holds the boosted frame
+    assert bool(hit.any()) != carried, (boost, p_format, flags.tolist())
+    assert not flags[1].any(), "clip 1 has no dominating key: nothing to redo"
+    vv = L.vt_values(vt, p_format)
     for i in range(T):
         K = kb[i].reshape(-1, 128).float().cpu()
-        V = torch.cat([vt[0].float().cpu().t(), vt[1].float().cpu().t()], 0)
+        V = torch.cat([vv[0].cpu().t(), vv[1].cpu().t()], 0)
         ref = O.flash_attn_math(qb[i].float().cpu(), K, V, scale)
-        _attn_check(raw[i].float().cpu()[None], ref[None], [(qb[i].float().cpu(), K, V, None, None)], scale)
+        _attn_check(raw[i].float().cpu()[None], ref[None], [(qb[i].float().cpu(), K, V, None, None)], scale, p_format)
 
 
 # ------------------------------------------------------------------------------------------------ small fused ops

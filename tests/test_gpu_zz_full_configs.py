@@ -56,11 +56,11 @@ def test_cascade_iters10_vs_reference(model):
     for i in range(20):
         e = np.abs(got - ref)[which == i]
         print(f"prediction {i:2d} ({'1/16' if i < 5 else '1/8' if i < 10 else '1/4'}): EPE vs reference {e.mean():.3e} px, max {e.max():.3e} px")
-        assert e.mean() < 1e-3, f"prediction {i}: EPE {e.mean()} over the north-star budget"
+        assert e.mean() < 5e-4, f"prediction {i}: EPE {e.mean()} (north-star budget 1e-3; measured <= 2.5e-4)"
     k, step = gd.keys["disparity"]
     e = np.abs(disp[None].float().cpu().numpy().reshape(-1)[::step] - gd.raw("disparity"))
     print(f"final disparity: EPE vs reference {e.mean():.3e} px, max {e.max():.3e} px")
-    assert e.mean() < 1e-3 and e.max() < 1e-2          # north-star budget: 1e-3 px EPE (measured 7.9e-4 with bf16 P)
+    assert e.mean() < 5e-4 and e.max() < 1e-2          # north-star budget: 1e-3 px EPE; measured 2.4e-4 with fp16 P~ (4.7e-4 with bf16 P~), profiles/r06_parity_ab.txt
     gd.check("uncertainty", unc[None], 2e-3)
 
 
@@ -89,8 +89,7 @@ def test_cascade_and_block_iters20_vs_reference(model):
     iterations of forward_update_block (fub04_it20).  The per-prediction table goes to profiles/rNN_parity.log (pytest -s).  The
     oracle itself -- fp32 everywhere but the bf16 attention operands -- is 3.5e-4 px from the reference at prediction 39
     (tests/test_oracle_golden.py): the recurrence amplifies bf16 rounding flips, and the distance grows with the iteration count.
-    The bounds asserted here are the reference's own reproducibility across FlashAttention block orders at this depth -- 1.1 - 1.3e-3 px at
-    prediction 39, 0.8 - 1.0e-3 over predictions 9 - 29 (tests/test_oracle_attention_envelope.py)."""
+    Asserted: < 1e-3 px on every prediction (north_star's tolerance)."""
     from ppmstereo_amd.corr import CorrBlock1D
     gd = Golden("cascade_it20")
     T, feats = it10_cascade_inputs()
@@ -109,13 +108,11 @@ def test_cascade_and_block_iters20_vs_reference(model):
     k, step = gd.keys["disparity"]
     e = np.abs(disp[None].float().cpu().numpy().reshape(-1)[::step] - gd.raw("disparity"))
     print(f"iters=20 final disparity: EPE vs reference {e.mean():.3e} px, max {e.max():.3e} px; worst prediction EPE {worst:.3e} px")
-    # FINDING (round 5, profiles/r05_parity.log): at iters=20 the HIP path is 1.3e-3 px from the reference's CPU output at prediction 39 (7.7e-4 at
-    # the end of the 1/8 scale, 9.8e-4 at prediction 29) -- over the 1e-3 budget that north_star states for config 2 (iters=10: 4.7e-4).  The
-    # fp32 oracle itself is 3.5e-4 px away there, and the oracle with flash-attention's bf16 P moves by 7.3e-4 px after HALF as many
-    # iterations: the recurrence doubles the effect of bf16 rounding flips of the attention read-out every ~10
-    # iterations.  Reported, not tuned away; the assertion keeps the measured level from growing.
-    assert e.mean() < 2e-3 and worst < 2e-3, (e.mean(), worst)
-    assert np.abs(got - ref)[which < 30].mean() < 1e-3               # the first 30 predictions (10 / 10 / 10 iterations) stay inside the budget
+    # north_star's budget -- 1e-3 px EPE -- on EVERY one of the 40 predictions and on the final disparity.  Round 5 (bf16 P~ in the memory
+    # read-out's P~ V product, what flash-attention itself does) ended 1.32e-3 px from the fixture at prediction 39; with fp16 P~ at the same MFMA
+    # count (TUNING["attn_p"], include/ppms.h: PPMS_ATTN_P_FP16) the worst prediction is 6.8e-4 px (profiles/r06_parity_ab.txt; the fp32 oracle
+    # itself sits at 3.5e-4 there: the recurrence amplifies any rounding difference).
+    assert e.mean() < 1e-3 and worst < 1e-3, (e.mean(), worst)
     gd.check("uncertainty", unc[None], 4e-3)
     gd = Golden("fub04_it20")
     T, h, w, iters = 5, 16, 64, 20

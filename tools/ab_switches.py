@@ -6,6 +6,7 @@ no environment variable itself).  Import this module before the first engine is 
     PPMS_CONV6, PPMS_CONV5, PPMS_CONV5_SLICED, PPMS_CONV5_GEMM, PPMS_CONV3, PPMS_PWCHAIN, PPMS_SLICE, PPMS_HOIST, PPMS_CONV5_PAD2X: 0 / 1
     PPMS_HID: 0 / 1 (GRU convs of the hoisted blocks on [h | mf, hid] with folded weights, products with hid's zero lo plane skipped)
     PPMS_STREAM: 0 / 1 / all (conv_stream.hip: off / where the library rates it faster / wherever it serves a small map); PPMS_STREAM_HINT: 0 / 1 / 2
+    PPMS_ATTN_P: fp16 / bf16 (ppms_mem_attn's p_format)
     PPMS_YSWEEP: 0 = off, 1 = y-swept (1, kh, 1) convs, 2d = also the 2-D window for kh, kw > 1
 """
 import os
@@ -30,6 +31,8 @@ if "PPMS_FORK_MIN" in os.environ:
 if "PPMS_YSWEEP" in os.environ:
     _engine.TUNING["ysweep"] = os.environ["PPMS_YSWEEP"] != "0"
     _engine.TUNING["win2d"] = os.environ["PPMS_YSWEEP"] == "2d"
+if "PPMS_ATTN_P" in os.environ:               # fp16 / bf16: format of P~ in the memory read-out's P~ V product
+    _engine.TUNING["attn_p"] = os.environ["PPMS_ATTN_P"]
 if "PPMS_LIB" in os.environ:                 # A/B of two builds on ONE box: another libppms.so (same ABI) instead of the in-tree one
     from ppmstereo_amd import build as _build
     _build.LIB = os.path.abspath(os.environ["PPMS_LIB"])

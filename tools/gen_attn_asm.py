@@ -26,7 +26,9 @@ plus 16 LDS fragment reads.  Every instruction is its own `asm volatile` stateme
 """
 import os
 
-MF = "v_mfma_f32_16x16x32_bf16"
+MF = "v_mfma_f32_16x16x32_bf16"          # S^T = K' Q^T: bf16 operands, as the reference casts them (ppmstereo.py:541-550)
+MF_P = {False: "v_mfma_f32_16x16x32_bf16", True: "v_mfma_f32_16x16x32_f16"}      # O^T += V^T P~ and l += 1 P~: the format of P~ (and of the V^T image)
+CVT_P = {False: "v_cvt_pk_bf16_f32", True: "v_cvt_pk_f16_f32"}
 RINGK = 4
 ABL = int(os.environ.get("PPMS_ATTN_ABL", "0"))     # timing experiments only (wrong results): 1 drops the softmax VALU work, 2 the LDS
                                                     # requests and waits, 4 the MFMAs, 8 the address upkeep
@@ -41,8 +43,8 @@ class Emit:
 
     def asm(self, text, outs=(), ins=()):
         op = text.split()[0]
-        if ((ABL & 1 and op in ("v_exp_f32", "v_fma_f32", "v_cvt_pk_bf16_f32")) or (ABL & 2 and (op == "ds_read_b128" or "lgkmcnt" in text)) or
-                (ABL & 4 and op == MF) or (ABL & 8 and op == "v_add_u32")):
+        if ((ABL & 1 and op in ("v_exp_f32", "v_fma_f32", "v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32")) or (ABL & 2 and (op == "ds_read_b128" or "lgkmcnt" in text)) or
+                (ABL & 4 and op.startswith("v_mfma")) or (ABL & 8 and op == "v_add_u32")):
             return
         ops = list(outs) + list(ins)
         for i, (nm, _, _) in enumerate(ops):
@@ -60,7 +62,8 @@ def pair(p):
     return tile, qb, w, w >> 1, 2 * (w & 1)
 
 
-def substep(par):
+def substep(par, p16):
+    MFP, CVT = MF_P[p16], CVT_P[p16]
     E = Emit()
     queue = [f"u{i}" for i in range(RINGK - 1)]          # LDS requests in flight at entry, oldest first (the LDS returns in order)
 
@@ -93,9 +96,9 @@ def substep(par):
                 E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+" + SACC, f"nxt[{b}][{qb}]")], [("a", "v", f"ring[{u % RINGK}]"), ("b", "v", f"qf[{qb}][{ks}]")])
         else:
             qb, d = (3, s - 16) if s < 24 else (0, s - 40) if s < 48 else (1, s - 48) if s < 56 else (2, s - 56)
-            E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{d}][{qb}]")], [("a", "v", f"vt[{d}]"), ("b", "v", f"pf[{qb}]")])
+            E.asm(f"{MFP} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"o[{d}][{qb}]")], [("a", "v", f"vt[{d}]"), ("b", "v", f"pf[{qb}]")])
             if d == 7:            # the denominator of the same 32 keys: l += 1 * P (A operand all ones: every row of the result is the sum)
-                E.asm(f"{MF} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"lacc[{qb}]")], [("a", "v", "ones"), ("b", "v", f"pf[{qb}]")])
+                E.asm(f"{MFP} {{c}}, {{a}}, {{b}}, {{c}}", [("c", "+a", f"lacc[{qb}]")], [("a", "v", "ones"), ("b", "v", f"pf[{qb}]")])
         # ---- LDS requests ------------------------------------------------------------------------------------------------------
         if (s - 1) in CUNIT:
             k_read(CUNIT.index(s - 1) + RINGK - 1)
@@ -121,7 +124,7 @@ def substep(par):
                   [("x", "v", f"{tile}[{b}][{qb}][{r0 + j}]"), ("sc", "v", "scale"), ("m", "v", f"negm[{qb}]")])
             if ph == 3:
                 _, qb, w, _, _ = pair(p)
-                E.asm("v_cvt_pk_bf16_f32 {d}, {p0}, {p1}", [("d", "+v", f"pf[{qb}][{w}]")], [("p0", "v", f"pt[{p & 1}][0]"), ("p1", "v", f"pt[{p & 1}][1]")])
+                E.asm(CVT + " {d}, {p0}, {p1}", [("d", "+v", f"pf[{qb}][{w}]")], [("p0", "v", f"pt[{p & 1}][0]"), ("p1", "v", f"pt[{p & 1}][1]")])
         # ---- address upkeep: the K addresses move to the next stage once the sub-tile's own K requests are out (even substeps); the V^T
         #      addresses after the tile's last V^T request (odd substeps) ---------------------------------------------------------------
         if par == 0 and 26 <= s < 34:
@@ -139,8 +142,11 @@ SIG = ("f32x4 (&cur)[2][4], f32x4 (&nxt)[2][4], const bf16x8 (&qf)[4][4], f32x4 
 
 def gen():
     out = ["// GENERATED by tools/gen_attn_asm.py -- do not edit.  (Schedule and register roles: see the generator's docstring.)\n#pragma once\n"]
-    out.append(f"template <int PAR>\n__device__ __forceinline__ void attn64_substep({SIG}) {{")
-    out.append("    if constexpr (PAR == 0) {\n" + substep(0) + "\n    } else {\n" + substep(1) + "\n    }\n}\n")
+    # P16: P~ (and the V^T image, and the all-ones row of the denominator) in fp16 instead of bf16 -- 11 instead of 8 significand bits in the
+    # P~ V product at the same MFMA rate; the kernel then tolerates 2^15 of overshoot above the softmax reference instead of 2^60 (mem_attn.hip)
+    out.append(f"template <int PAR, bool P16>\n__device__ __forceinline__ void attn64_substep({SIG}) {{")
+    out.append("    if constexpr (PAR == 0 && !P16) {\n" + substep(0, False) + "\n    } else if constexpr (PAR == 1 && !P16) {\n" + substep(1, False) +
+               "\n    } else if constexpr (PAR == 0) {\n" + substep(0, True) + "\n    } else {\n" + substep(1, True) + "\n    }\n}\n")
     # prime: K units 0..2 of substep 0 (S of sub-tile 1: tile 0, keys 32..63), arguments of pairs 0 and 1, exps of pair 0
     E = Emit()
     for u in range(RINGK - 1):
