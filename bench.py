@@ -110,6 +110,60 @@ def launch_ranks(n, argv):
     return subprocess.run(cmd, env=env).returncode
 
 
+class ExtraPhaseGuard:
+    """Keeps the EXTRA frame-sharded window (N > 1, behind the replica measurement) from costing the replica measurement or hiding a failure.
+
+    The replica line is complete before the extra phase starts; `emit(reason)` prints it (rank 0) with the failure recorded under `sharded`.  A rank
+    whose extra phase raises calls fail(): emit + a fresh non-zero exit (os._exit: the process group may be wedged behind the failed exchange, no
+    teardown is attempted; never a re-exec).  The OTHER ranks are then blocked inside a collective, in C, where no Python signal handler runs: a
+    helper thread waits on the signal wake-up pipe (signal.set_wakeup_fd: written by the C-level handler at once, whatever the main thread is doing)
+    and on a deadline -- on the launcher's SIGTERM (torch.distributed.run terminates the remaining ranks when one fails) or at the deadline it emits
+    and exits non-zero too.  So: rank 0's line is printed exactly once whichever rank fails, and every rank of a failed run exits non-zero."""
+
+    EXIT_CODE = 4
+
+    def __init__(self, emit, timeout_s: float):
+        import select
+        import signal
+        import threading
+        self._emit, self._lock, self._finished = emit, threading.Lock(), False
+        self._r, self._w = os.pipe()
+        os.set_blocking(self._w, False)
+        self._old_handler = signal.signal(signal.SIGTERM, lambda *_: None)          # (main thread) C-level handler -> wake-up pipe
+        self._old_fd = signal.set_wakeup_fd(self._w, warn_on_full_buffer=False)
+
+        def watch():
+            ready, _, _ = select.select([self._r], [], [], timeout_s)
+            if self._finished:
+                return
+            self.fail("the launcher's SIGTERM arrived during the extra frame-sharded window (another rank failed)" if ready
+                      else f"the extra frame-sharded window did not complete within {timeout_s:.0f} s")
+
+        self._thread = threading.Thread(target=watch, daemon=True)
+        self._thread.start()
+
+    def fail(self, reason: str):
+        with self._lock:                         # first caller wins (main thread's exception vs the watcher)
+            if self._finished:
+                return
+            self._finished = True
+            try:
+                self._emit(reason)
+                sys.stdout.flush(), sys.stderr.flush()
+            finally:
+                os._exit(self.EXIT_CODE)
+
+    def finish(self):
+        import signal
+        with self._lock:
+            self._finished = True
+        os.write(self._w, b"\0")                 # wake the watcher
+        self._thread.join()
+        signal.set_wakeup_fd(self._old_fd)
+        signal.signal(signal.SIGTERM, self._old_handler)
+        os.close(self._r), os.close(self._w)
+
+
 def dry_run(args, D, rank, world):
     """--dry-run: everything around the measurement (rendezvous, barrier, max-over-ranks, frame-shard planning, the one JSON line from rank 0)
     with a stub in place of the step.  No GPU, no kernels, value = null: a rehearsal of the launch path, never a measurement."""
@@ -123,25 +177,40 @@ def dry_run(args, D, rank, world):
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0)
     frames = D.sum_over_ranks(float(shard.f if sharded else T))
-    sh_plan = None
+    out = dict(metric="disparity-px/s", value=None, unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup, sharded=None,
+               ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="strong" if sharded else "weak",
+               dry_run=True, backend=torch.distributed.get_backend() if world > 1 else None, frames_over_ranks=frames,
+               config=dict(workload="dry run: stub step, no GPU work", T=T, H=args.H, W=args.W, iters=args.iters,
+                           parallelism=(f"frames sharded {T // world}/GPU x{world}" if sharded else f"replicas x{world}")))
     if world > 1 and not sharded and args.sharded_T and args.sharded_T % world == 0 and args.sharded_T // world >= 2:
-        # the extra frame-sharded window of the real run (sharded_phase): planned and rehearsed on the stub (one all-reduce per repetition)
-        sh = D.FrameShard(rank, world, args.sharded_T)
-        D.barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.sharded_steps):
-            time.sleep(1e-3)
-        D.barrier()
-        sh_el = D.max_over_ranks(time.perf_counter() - t1)
-        sh_frames = D.sum_over_ranks(float(sh.f))
-        sh_plan = dict(T=args.sharded_T, iters=args.sharded_iters, frames_per_gpu=sh.f, frames_over_ranks=sh_frames, ms_per_window=None,
-                       stub_ms=round(1e3 * sh_el / args.sharded_steps, 3), note="dry run: planned, not measured")
+        # the extra frame-sharded window of the real run (sharded_phase): planned and rehearsed on the stub (one all-reduce per repetition), under the
+        # same guard: the replica line above is complete, a failure of the extra phase (--inject-sharded-failure RANK: that rank raises in front of a
+        # collective the others have entered) must still print it once, with the error, and end every rank non-zero
+        def emit(reason):
+            if rank == 0:
+                print(json.dumps(dict(out, sharded=dict(error=reason, note="the frame-sharded window behind the replica measurement failed; `value` is unaffected"))), flush=True)
+            else:
+                print(f"[bench rank {rank}] extra sharded phase: {reason}", file=sys.stderr, flush=True)
+
+        guard = ExtraPhaseGuard(emit, args.sharded_timeout)
+        try:
+            sh = D.FrameShard(rank, world, args.sharded_T)
+            D.barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.sharded_steps):
+                time.sleep(1e-3)
+            if args.inject_sharded_failure == rank:
+                raise RuntimeError(f"injected failure on rank {rank}")
+            D.barrier()
+            sh_el = D.max_over_ranks(time.perf_counter() - t1)
+            sh_frames = D.sum_over_ranks(float(sh.f))
+        except Exception as e:                   # noqa: BLE001
+            guard.fail(f"{type(e).__name__}: {e}"[:600])
+        guard.finish()
+        out["sharded"] = dict(T=args.sharded_T, iters=args.sharded_iters, frames_per_gpu=sh.f, frames_over_ranks=sh_frames, ms_per_window=None,
+                              stub_ms=round(1e3 * sh_el / args.sharded_steps, 3), note="dry run: planned, not measured")
     if rank == 0:
-        print(json.dumps(dict(metric="disparity-px/s", value=None, unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup, sharded=sh_plan,
-                              ms_per_step=round(1e3 * elapsed / args.steps, 3), higher_is_better=True, scaling="strong" if sharded else "weak",
-                              dry_run=True, backend=torch.distributed.get_backend() if world > 1 else None, frames_over_ranks=frames,
-                              config=dict(workload="dry run: stub step, no GPU work", T=T, H=args.H, W=args.W, iters=args.iters,
-                                          parallelism=(f"frames sharded {T // world}/GPU x{world}" if sharded else f"replicas x{world}")))))
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -154,7 +223,7 @@ def sharded_phase(args, D, model, rank, world, dev):
     per scale, the values + confidences every iteration, +-2 / +-1-frame halos for the temporal convolutions (ppmstereo_amd.dist.FrameShard; reference:
     ppmstereo.py:277-307,524-550, ppmtereo_update.py:281-310,670-678) -- behind the replica measurement.  First a CHECK on the hardware this runs on: the
     sharded cascade at reduced iteration counts against the same window computed unsharded on rank 0; a failed check ends the run with a non-zero
-    exit code on every rank.  Then --sharded-steps timed windows (barrier + synchronize on both sides, max over ranks).  Returns (sharded, check)."""
+    exit code (3) on every rank, after rank 0 has printed the replica line with the failed check in it.  Then --sharded-steps timed windows (barrier + synchronize on both sides, max over ranks).  Returns (sharded, check)."""
     from ppmstereo_amd.synth import synth_cascade_feats
     T, H, W, iters = args.sharded_T, args.H, args.W, args.sharded_iters
     shard = D.FrameShard(rank, world, T)
@@ -175,12 +244,8 @@ def sharded_phase(args, D, model, rank, world, dev):
     err = D.max_over_ranks(err)
     tol = 1e-3                                                                    # px; measured on two / four ranks of one GPU: <= 5e-5 of the range
     check = dict(max_abs_disparity_diff_px=err, tolerance_px=tol, iters=chk_iters, reference="the same window unsharded on rank 0", passed=bool(err <= tol))
-    if not check["passed"]:
-        if rank == 0:
-            print(json.dumps(dict(error="sharded_check failed", sharded_check=check)), file=sys.stderr)
-        if world > 1:
-            torch.distributed.destroy_process_group()
-        sys.exit(3)
+    if not check["passed"]:                  # (agreed by all ranks: err is the max over ranks) -- main prints the replica line with the failed check, exit code 3
+        return None, check
     model.cascade(local, iters, T, shard=shard, test_mode=True)                   # warm-up at the real iteration count
     torch.cuda.synchronize()
     D.barrier()
@@ -190,7 +255,8 @@ def sharded_phase(args, D, model, rank, world, dev):
     torch.cuda.synchronize()
     D.barrier()
     ms = 1e3 * D.max_over_ranks(time.perf_counter() - t0) / args.sharded_steps
-    assert torch.isfinite(d_sh).all()
+    if not torch.isfinite(d_sh).all():
+        raise RuntimeError("non-finite disparities in the timed frame-sharded window")
     cfg4 = (T, H, W, iters) == (40, 320, 512, 20)
     out = dict(T=T, H=H, W=W, iters=iters, frames_per_gpu=shard.f, steps=args.sharded_steps, ms_per_window=round(ms, 3), px_per_s=round(T * H * W / (ms * 1e-3), 1),
                scaling="strong", vs_single_gpu_495ms=(round(SINGLE_GPU_T40_MS / ms, 3) if cfg4 else None), vs_single_gpu_542ms=(round(542.0 / ms, 3) if cfg4 else None),
@@ -203,6 +269,7 @@ def sharded_phase(args, D, model, rank, world, dev):
     return out, check
 
 
+BUILD_MODE = None
 TIMING_EVERY = 20         # per-launch events in steps 0, 20, 40, ... of the timed region (one step's launches: 117 convs, 20 attention calls)
 
 
@@ -231,6 +298,8 @@ def main():
                     "on 8 GPUs) and reported under `sharded` with its correctness check `sharded_check`; 0 = skip that phase")
     ap.add_argument("--sharded-iters", type=int, default=20, help="iterations of that window (config 4: 20)")
     ap.add_argument("--sharded-steps", type=int, default=3, help="timed repetitions of that window")
+    ap.add_argument("--sharded-timeout", type=float, default=240.0, help="deadline (s) of that extra phase: past it every rank prints / records the failure and exits non-zero")
+    ap.add_argument("--inject-sharded-failure", type=int, default=-1, help=argparse.SUPPRESS)      # --dry-run only: this rank raises inside the extra phase (tests)
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / argument plumbing only: the ranks form the process group, run a stub step "
                     "(no GPU work), take the barrier + max-over-ranks path and rank 0 prints a line with value = null (CPU rehearsal, tests/test_bench_launch.py)")
     args = ap.parse_args()
@@ -253,6 +322,10 @@ def main():
     dev = torch.device("cuda", torch.cuda.current_device())
 
     from ppmstereo_amd import _lib as L
+    from ppmstereo_amd import build as _build0
+    global BUILD_MODE
+    BUILD_MODE = "reused" if _build0._fresh(_build0._digest()) else "compiled"      # before the first L.load(): was the library on disk the committed sources?
+    L.load()
     from ppmstereo_amd import weights as Wm
     from ppmstereo_amd.ppmstereo import PPMStereoHotPath
     from ppmstereo_amd.synth import synth_cascade_feats
@@ -381,7 +454,7 @@ def main():
     px = T * H * W
     value = (1 if sharded else world) * args.steps * px / elapsed
     ksel = min(5, T)
-    roofs, family_roof = [], None
+    roofs, family_roof, consistency = [], None, {}
     if not args.no_kernel_timing:
         # ---- memory attention: algorithmic FLOPs of one launch = 4 * n * (ksel * n) * 128 * (clips of this rank)
         tot_flop, tot_ms, n_launch, per_scale = 0.0, 0.0, 0, {}
@@ -424,13 +497,19 @@ def main():
             if c_n:
                 cach = c_flop / (c_ms * 1e-3) / 1e12
                 cpeak = c_flop / (c_bound_ms * 1e-3) / 1e12           # the launch mix's own bound: dense bf16 / (flop-weighted MFMAs per product), >= 833.3
-                # every sampled step launches the same list (round 4's line held two steps' launches for one sampled step: 234 = 2 x 117)
-                assert all(len(ms) % n_sampled == 0 for ms in conv3_ms.values()), {k: len(ms) for k, ms in conv3_ms.items()}
-                ctraffic = None
-                tfile = _latest_profile("conv_traffic.json")
+                # every sampled step launches the same list (round 4's line held two steps' launches for one sampled step: 234 = 2 x 117): a
+                # diagnostic field, never an abort behind the timed region
+                consistency["launches_per_sampled_step_equal"] = all(len(ms) % n_sampled == 0 for ms in conv3_ms.values())
+                # HBM bytes of one launch: only an IN-SITU figure counts (a launch inside a clip, inputs cold: profiles/rNN_conv_traffic_insitu.json, tools/traffic_pmc.sh).
+                # The back-to-back probe launches of rounds 2-5 read their inputs from the Infinity Cache (0.69x the algorithmic bytes in round 5: not physical
+                # as HBM traffic of the clip), so those files are no longer quoted here
+                ctraffic, ctraffic_note = None, "null: no in-situ PMC figure committed (back-to-back probe launches hit the Infinity Cache: 0.69x the algorithmic bytes, profiles/r05_conv_traffic.json -- not evidence)"
+                tfile = _latest_profile("conv_traffic_insitu.json")
                 if tfile and (T, H, W) == (5, 320, 512):
                     ctraffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-                roofs.append(dict(bound="mfma", kernel="conv5_kernel / conv3_kernel (large-map implicit-GEMM convolutions, bf16x3 split MFMA; per_op names the kernel), "
+                    ctraffic_note = "HBM bytes per launch of the conv6 family INSIDE a clip (all launches of rocprofv3 --pmc passes over whole clips, summed / launches), " + os.path.basename(tfile)
+                names = sorted({f"conv{6 if op.version == 8 else op.version}_kernel" for (sc, name), op in conv3.items() if conv3_ms[(sc, name)]}, reverse=True)
+                roofs.append(dict(bound="mfma", kernel=" / ".join(names) + " (large-map implicit-GEMM convolutions, bf16x3 split MFMA; per_op names the kernel of every launch), "
                                                        "every launch in every 20th step of the timed region (step 0, 20, ...); "
                                                        "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / (MFMAs per product): 3 "
                                                        "(hi*hi + lo*hi + hi*lo), less the hi*lo products skipped for input channels with an all-zero lo plane "
@@ -439,15 +518,17 @@ def main():
                                   mfma_per_product=round(BF16_DENSE_PEAK_TFLOPS / cpeak, 4), frac_of_three_mfma_bound=round(cach / CONV_BOUND_TFLOPS, 4),
                                   mfma_issued_tflops=round(cach * BF16_DENSE_PEAK_TFLOPS / cpeak, 1),
                                   frac_of_bf16_dense=round(cach / BF16_DENSE_PEAK_TFLOPS, 4), traffic=ctraffic,
-                                  traffic_note="HBM bytes of ONE zr1_0 launch at the 1/4 scale, profiles/rNN_conv_traffic.json",
+                                  traffic_note=ctraffic_note,
                                   launches=c_n, avg_ms=round(c_ms / c_n, 4), total_ms_per_step=round(c_ms / n_sampled, 3),
                                   flop_per_launch=c_flop / c_n, per_op=per_op))
         roofs.sort(key=lambda r: -r["total_ms_per_step"])          # the kernel with the largest share of a step first
         if pipe is None and not sharded:
-            # consistency: the two families run one after the other inside a step (the convs' own two streams overlap each other, which can only
-            # shorten the step), so their event sums cannot exceed the step by more than the event overhead of the sampled step
+            # consistency (a reported field, not an abort): the two families run one after the other inside a step.  Launches of the convs' two streams
+            # overlap each other -- both event pairs then count the shared interval, so the SUM of event times may legitimately exceed the wall time of
+            # the step; a sum far above it would mean double-counted launches (round 4)
             tot = sum(r["total_ms_per_step"] for r in roofs)
-            assert tot <= max(step_ms[0], 1e3 * elapsed / args.steps) * 1.05, (tot, step_ms[0], 1e3 * elapsed / args.steps)
+            consistency["event_sum_ms"] = round(tot, 3)
+            consistency["event_sum_within_step"] = bool(tot <= max(step_ms[0], 1e3 * elapsed / args.steps) * 1.05)
         # ---- the whole convolution family of a step, all three scales: every implicit-GEMM launch (large-map and small-map kernels, the
         # slice-reduce halves, the once-per-scale hoisted shares and q/k projections), the fused per-pixel chains, the depthwise 7x7 -- against
         # the reference's algorithmic conv FLOPs (14.128 MFLOP per pixel and iteration at 1/4 and 1/8, 17.75 at 1/16)
@@ -489,14 +570,6 @@ def main():
         torch.cuda.synchronize()
         D.barrier()
         all_ms = D.max_over_ranks(time.perf_counter() - t_all) / n_all * 1e3
-    sharded_out = sharded_chk = None
-    if world > 1 and not sharded and args.sharded_T and args.sharded_T % world == 0 and args.sharded_T // world >= 2:
-        try:
-            sharded_out, sharded_chk = sharded_phase(args, D, model, rank, world, dev)
-        except Exception as e:                     # (a failed CHECK leaves through sys.exit(3) inside; this is an exception of the extra phase itself)
-            # the replica measurement above is complete and unaffected: report it, with the failure of the extra window recorded in its place
-            sharded_out = dict(error=f"{type(e).__name__}: {e}"[:600], note="the frame-sharded window behind the replica measurement raised; `value` is unaffected")
-            sharded_chk = None
     encoders = None
     if not args.no_encoders and world == 1 and (T, H, W) == (5, 320, 512):      # (N > 1: the ranks time their clips only)
         # SURVEY 8 rows f3-f5 on the same clip geometry: fnet on the 2T images, cnet on the T left images, SST on the 1/16 features
@@ -548,6 +621,7 @@ def main():
         encoders["whole_call_px_per_s"] = round(T * H * W / (call_ms * 1e-3), 1)
         encoders["whole_call_note"] = ("PPMStereo.forward_batch_test(host video) -> host disparity: H2D + encoders + SST + cascade + D2H, "
                                        "one window; PCIe inclusive, not `value`")
+    out = None
     if rank == 0:
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -561,10 +635,17 @@ def main():
                 cpu["sampled_vs_full"] = round(sampled["seconds_per_clip"] / cpu["seconds_per_clip"], 4)
         label = BASELINE_CONFIGS.get((T, H, W, iters), "custom configuration")
         par = f"frames sharded {T // world}/GPU x{world} (RCCL all-gather of memory K/V + temporal halos)" if sharded else f"replicas x{world}"
+        from ppmstereo_amd import build as _build
+        from ppmstereo_amd import engine as _eng
+        try:
+            stamp = open(_build.STAMP).read().strip()
+        except OSError:
+            stamp = ""
         out = dict(metric="disparity-px/s", value=round(value, 1), unit="disparity-px/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=round(1e3 * elapsed / args.steps, 3), ms_per_step_median=round(statistics.median(step_ms), 3),
                    ms_per_step_min=round(min(step_ms), 3), higher_is_better=True, scaling="strong" if sharded else "weak", vs_baseline=None, dtype="bf16",
-                   precision="attention: bf16 MFMA, fp32 softmax/accumulate; convs: bf16x3 split MFMA (fp32-accurate); correlation: fp32 MFMA",
+                   precision=f"attention: Q K'^T on bf16 MFMA, fp32 softmax, P~ V on {_eng.TUNING['attn_p']} MFMA (V = the bf16-rounded values), fp32 accumulate; "
+                             "convs: bf16x3 split MFMA (fp32-accurate); correlation: fp32 MFMA",
                    data="synthetic", frames_per_s=round((1 if sharded else world) * args.steps * T / elapsed, 2),
                    config=dict(workload=f"{label}: T={T} clip at {H}x{W}, iters={iters}, hot path only (3-scale cascade from encoder outputs: "
                                         "corr pyramid build + lookup, QAM pick, pick-and-play memory attention, ConvGRU3D update, heads, convex upsample, "
@@ -577,15 +658,43 @@ def main():
                    pipeline=("consecutive clips overlap: 1/16 + 1/8 scales of clip k + 1 on a second stream under the 1/4 scale of clip k (ClipPipeline); "
                              "latency_ms_per_clip = one clip alone" if pipe is not None else "off: clips strictly one after the other"),
                    roofline=roofs[0] if roofs else None, roofline_2=roofs[1] if len(roofs) > 1 else None,
-                   roofline_3=family_roof if (not args.no_kernel_timing and family) else None, roofline_hbm=hbm_roof, cpu_baseline=cpu,
-                   sharded=sharded_out, sharded_check=sharded_chk,
+                   roofline_3=family_roof if (not args.no_kernel_timing and family) else None, roofline_hbm=hbm_roof, roofline_consistency=consistency or None,
+                   cpu_baseline=cpu, sharded=None, sharded_check=None,
                    whole_call_ms=None if not encoders else encoders["whole_call_ms"],
-                   library=os.path.relpath(L.lib_path(), ROOT), **({"encoders": encoders} if encoders else {}))
+                   library=os.path.relpath(L.lib_path(), ROOT),
+                   # the library that ran: "reused" = libppms.so.stamp matched the digest of the committed sources + flags when this process loaded it (it IS
+                   # those sources, built earlier); "compiled" = this process (or a rank beside it) ran hipcc on them first
+                   build_mode=BUILD_MODE, library_stamp=stamp[:12], library_stamp_matches_sources=bool(stamp and stamp == _build._digest()),
+                   **({"encoders": encoders} if encoders else {}))
+    exit_code = 0
+    if world > 1 and not sharded and args.sharded_T and args.sharded_T % world == 0 and args.sharded_T // world >= 2:
+        # The replica measurement is complete (rank 0 holds its line).  The extra frame-sharded window runs under a guard: whichever rank fails in it --
+        # an exception, a hang, the launcher's SIGTERM -- rank 0 prints the line exactly once with the error under `sharded`, and every rank exits non-zero.
+        def emit(reason):
+            if rank == 0:
+                print(json.dumps(dict(out, sharded=dict(error=reason, note="the frame-sharded window behind the replica measurement failed; `value` is unaffected"))), flush=True)
+            else:
+                print(f"[bench rank {rank}] extra sharded phase: {reason}", file=sys.stderr, flush=True)
+
+        guard = ExtraPhaseGuard(emit, args.sharded_timeout)
+        sharded_out = sharded_chk = None
+        try:
+            sharded_out, sharded_chk = sharded_phase(args, D, model, rank, world, dev)
+        except Exception as e:                     # noqa: BLE001
+            guard.fail(f"{type(e).__name__}: {e}"[:600])
+        guard.finish()
+        if rank == 0:
+            out["sharded"], out["sharded_check"] = sharded_out, sharded_chk
+        if sharded_chk is not None and not sharded_chk["passed"]:
+            exit_code = 3                          # the check failed on the hardware (agreed by all ranks): the line says so, the exit code too
+            if rank == 0:
+                out["sharded"] = dict(error="sharded_check failed: the frame-sharded window differs from the unsharded one", note="`value` is unaffected")
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
-        if sharded_out is not None and "error" in sharded_out:
-            os._exit(0)                            # (the process group may be wedged behind the failed exchange: do not wait for a clean teardown)
         torch.distributed.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 if __name__ == "__main__":

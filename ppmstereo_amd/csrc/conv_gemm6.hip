@@ -67,6 +67,8 @@ static long long* g_conv6_dbg = nullptr;
 #define CONV6_STAMP(K)
 #endif
 
+// (M0: compiler-reserved on this target, written in the SAME statement that reads it; an "m0" clobber only draws "clobber list contains reserved
+// registers".)
 // LDS-DMA of 16 B per lane through a buffer resource: lane l's bytes land at LDS address m0 + 16 l; the source is srd.base + off (32-bit, per lane), and
 // a lane whose offset lies beyond srd.num_records reads ZEROS (tools/probe/buf_lds_oob_probe.hip) -- the padding of a window costs no zero page and no
 // per-lane select.  Inline asm on purpose: for the compiler's own LDS-DMA (__builtin_amdgcn_global_load_lds) the waitcnt pass puts a wait for that
@@ -185,14 +187,24 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         const int c0 = (chunk - (sg ? g.n0 : 0)) * g.cpw * 2;                  // byte offset of the window's first channel
         const int64_t shift = (int64_t)dt * HW * (sg ? ld1 : ld0) + c0;
         const uint64_t base = (uint64_t)(uintptr_t)((sg ? sp1h : sp0h) + shift);
-        d_srd[0] = __builtin_amdgcn_readfirstlane((unsigned)base);
-        d_srd[1] = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
+        // The resource words must be FIVE wait states old when a buffer_load reads them if a VALU instruction (v_readfirstlane) wrote them -- the
+        // documented "VALU writes SGPR -> VMEM reads that SGPR" hazard.  The compiler inserts those wait states for its own memory instructions only: the
+        // LDS-DMA pieces are inline asm, and tools/probe/lds_dma_hazard_probe.hip shows what the violation does on this part (0 wait states: the piece
+        // reads through a garbage descriptor -- a memory fault, or silently the PREVIOUS window's base: whole stale pieces, the symptom round 5 fenced by
+        // timing) and what is safe at any distance (M0, the offset VGPR and SALU-written resource words rewritten directly behind a piece: 3 x 10^8
+        // wave-pieces at 3.5 TB/s, none wrong; profiles/r06_lds_dma_hazard_probe.txt).  Today the compiler computes these words on the SALU (the window
+        // index is uniform) -- this statement makes the distance a property of the source instead of the register allocator's mood: the words pass through
+        // an asm statement that holds 5 wait states, so whatever produced them is at least that far from every piece.
+        unsigned w_lo = __builtin_amdgcn_readfirstlane((unsigned)base), w_hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32) & 0xffffu);
+        asm volatile("s_nop 4" : "+s"(w_lo), "+s"(w_hi));
+        d_srd[0] = w_lo;
+        d_srd[1] = w_hi;
         d_buf = buf;
 #pragma unroll
         for (int i = 0; i < NP; ++i) off[i] = sg ? off1[i] : off0[i];
     };
-    // (an LDS-DMA instruction reads M0 and its address register some time after it has issued: the loop leaves >= 4 MFMAs between two pieces and
-    //  never rewrites a piece's offset register before the next window's set-up; see tools/gen_conv6_asm.py)
+    // (round 5 spaced the pieces >= 4 MFMAs apart on the belief that an LDS-DMA reads M0 / its offset register late; the round-6 probe refutes that --
+    //  what bit was the VALU-written resource, see dma_setup -- but the spacing stays: a piece costs ~60 issue cycles, one per MFMA group hides it)
     auto dma_piece = [&](int i) { dma16_6(off[i], d_srd, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16))); };
     // the pieces of a window leave in the first TWO k-steps of the window before it: PPS0 in the first, PPS1 in the second
     constexpr int PPS0 = (NP + 1) / 2, PPS1 = NP / 2;

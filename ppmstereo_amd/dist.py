@@ -47,11 +47,12 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
-    """(rank, world, local_rank) from RANK / WORLD_SIZE / LOCAL_RANK; initialises the default group when world > 1."""
+def init_from_env(backend: Optional[str] = None, force: bool = False) -> tuple:
+    """(rank, world, local_rank) from RANK / WORLD_SIZE / LOCAL_RANK; initialises the default group when world > 1 (force: also for a
+    world of one -- the communicator of a single rank, which is how a one-GPU box exercises the RCCL code path: tests/test_gpu_rccl_world1.py)."""
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:          # RCCL on GPUs; PPMS_DIST_BACKEND=gloo rehearses the multi-rank paths on a box with fewer GPUs than ranks
@@ -150,10 +151,16 @@ class FrameShard:
 
     HALO = 2            # frames of slack on both sides of a rank's block in halo'd buffers (the GRU's (5,1,1) convs need 2)
 
-    def __init__(self, rank: int, world: int, T: int, group=None):
+    def __init__(self, rank: int, world: int, T: int, group=None, force_comm: bool = False):
+        """force_comm: a world of ONE still sends its exchanges through the process group's backend -- the library all-gather on one rank, the
+        direct gather as a grouped send + receive to the rank itself -- instead of the local copies a single rank needs.  The results are the same
+        bytes; it exists so that a one-GPU box runs the RCCL branch of every exchange (communicator, grouped point-to-point launch, asynchronous
+        handles, stream waits) before an 8-GPU node ever does."""
         if T % world != 0:
             raise ValueError(f"FrameShard: {T} frames do not divide over {world} ranks")
         self.rank, self.world, self.T, self.group = rank, world, T, group
+        # (RCCL / NCCL accept a send to the own rank inside a group; gloo does not: there a single rank keeps its local copies)
+        self.force_comm = bool(force_comm and world == 1 and dist.is_initialized() and dist.get_backend(group) == "nccl")
         self.f = T // world
         if world > 1 and self.f < self.HALO:
             raise ValueError("FrameShard: at least 2 frames per rank (the temporal GRU pass reads +-2 frames: one neighbour each side)")
@@ -161,7 +168,7 @@ class FrameShard:
 
     # ------------------------------------------------------------------ helpers
     def _stage(self, t: torch.Tensor) -> bool:
-        return self.world > 1 and t.is_cuda and dist.get_backend(self.group) != "nccl"
+        return (self.world > 1 or self.force_comm) and t.is_cuda and dist.get_backend(self.group) != "nccl"
 
     # ------------------------------------------------------------------ all-gather of frame blocks
     def all_gather(self, local: torch.Tensor, out: Optional[torch.Tensor] = None, async_op: bool = False):
@@ -170,7 +177,7 @@ class FrameShard:
         local = local.contiguous()
         if out is None:
             out = torch.empty((self.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        if self.world == 1:
+        if self.world == 1 and not self.force_comm:
             out.copy_(local)
             return out, _Done()
         if self._stage(local):
@@ -187,7 +194,7 @@ class FrameShard:
         rank's block of every tensor goes to each peer, the peers' blocks are received straight into their place in ``out``
         (contiguous slices), i.e. world - 1 sends + world - 1 receives per tensor in ONE group.  Returns a handle; with
         async_op the caller waits on it right before the gathered data is read."""
-        if self.world == 1:
+        if self.world == 1 and not self.force_comm:
             for local, out in pairs:
                 out.copy_(local)
             return _Done()
@@ -200,7 +207,7 @@ class FrameShard:
             src = local.cpu() if stage else local
             for peer in range(self.world):
                 dst = out[peer * m:(peer + 1) * m]
-                if peer == self.rank:
+                if peer == self.rank and not (self.force_comm and dst.data_ptr() != local.data_ptr()):
                     if dst.data_ptr() != local.data_ptr():
                         dst.copy_(local)
                     continue

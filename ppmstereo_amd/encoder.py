@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import packing as _packing
-from .engine import ConvOp, epilogue
+from .engine import TUNING, ConvOp, epilogue
 
 
 def _s2d_weight(w: torch.Tensor, pad: int) -> torch.Tensor:
@@ -179,7 +179,7 @@ class _FnetEngine:
             d.M = d.m_split = meta["M"]
             assert src.channels == meta["cpad"] and dst_f32.shape[1] == meta["M"], (name, src.channels, meta["cpad"], dst_f32.shape, meta["M"])
             d.epi[0] = epilogue(n_valid=meta["M"], out_f32=dst_f32, out_f32_ld=meta["M"])
-            if name + "@6" in pk and meta["M"] == 128:
+            if TUNING["conv6"] and name + "@6" in pk and meta["M"] == 128:      # (TUNING["conv6"] = False: every conv of the encoder on conv_gemm2, as the engine's fallback)
                 packed6, bias6, meta6 = pk[name + "@6"]
                 d6 = L.Conv.from_buffer_copy(bytes(d))
                 d6.w, d6.bias = packed6.data_ptr(), bias6.data_ptr()

@@ -143,6 +143,12 @@ class ConvOp:
         lz = int(d.lo_zero_from)
         if self.version not in (5, 8) or lz <= 0 or lz >= cin or lz % (16 if self.version == 5 else 32):
             return 3.0
+        if self.version == 8:
+            # conv_gemm6's K loop runs the windows with a lo plane first (phase 0) and needs an EVEN number of k32-steps there (its weight registers
+            # alternate between two stages): plan6 (conv_gemm6.hip) ignores lo_zero_from when (lo_zero_from / 32) * (k32-steps per window) is odd
+            nsweep = d.kh * d.kw if (d.kh > 1 or d.kw > 1) else 1
+            if ((lz // 32) * nsweep) & 1:
+                return 3.0
         return 3.0 - (cin - lz) / cin
 
     def __call__(self):
@@ -413,8 +419,8 @@ class ScaleEngine:
         """T: frames held by THIS engine.  shard (ppmstereo_amd.dist.FrameShard, optional): the window's frames are split in
         contiguous blocks over the ranks; T == shard.f, global frame ids shard.lo .. shard.hi - 1 (see dist.py for what is
         exchanged when)."""
-        if shard is not None and shard.world == 1:
-            shard = None
+        if shard is not None and shard.world == 1 and not getattr(shard, "force_comm", False):
+            shard = None                                   # (force_comm: a single rank that runs every exchange through its process group, dist.FrameShard)
         if shard is not None and T != shard.f:
             raise ValueError(f"sharded engine: {T} local frames, the shard holds {shard.f}")
         self.shard = shard

@@ -201,7 +201,7 @@ class SequenceUpdateBlock3D(nn.Module):
         device = torch.device(device)
         if device.index is None:
             device = torch.device("cuda", torch.cuda.current_device())
-        key = (T, h, w, str(device), None if shard is None else (shard.rank, shard.world, shard.T, id(shard.group)), slot)
+        key = (T, h, w, str(device), None if shard is None else (shard.rank, shard.world, shard.T, id(shard.group), bool(getattr(shard, "force_comm", False))), slot)
         pk = self.packed(device)
         if key not in self._engines:
             while len(self._engines) >= max(self.MAX_ENGINES, slot + 1):

@@ -58,3 +58,22 @@ def test_driver_command_shape_under_torchrun():
                        capture_output=True, text=True, cwd="/tmp", env=e, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _line(r.stdout)["n_gpus"] == 2
+
+
+@pytest.mark.parametrize("bad_rank", [0, 1])
+def test_extra_sharded_phase_failure_prints_the_replica_line_once_and_exits_nonzero(bad_rank):
+    """bench.ExtraPhaseGuard: the extra frame-sharded window (N > 1, behind the replica measurement) fails on ONE rank while the others sit in a collective.
+    Whichever rank it is, rank 0 prints its (complete) replica line exactly once with the failure under `sharded`, and the launcher comes back non-zero --
+    quickly: the blocked ranks leave on the launcher's SIGTERM (read from the signal wake-up pipe by a helper thread), not after a collective timeout."""
+    import time
+    t0 = time.time()
+    r = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--inject-sharded-failure", str(bad_rank), "--sharded-timeout", "120")
+    took = time.time() - t0
+    assert r.returncode != 0, (r.stdout, r.stderr[-1500:])
+    out = _line(r.stdout)
+    assert out["n_gpus"] == 2 and out["ms_per_step"] > 0 and "error" in out["sharded"], out
+    if bad_rank == 0:
+        assert "injected failure on rank 0" in out["sharded"]["error"]
+    else:
+        assert "SIGTERM" in out["sharded"]["error"] or "injected" in out["sharded"]["error"], out["sharded"]
+    assert took < 100, f"{took:.0f} s: the ranks waited for a timeout instead of leaving on the launcher's signal"

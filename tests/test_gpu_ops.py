@@ -644,7 +644,7 @@ CONV6_CASES = [
 @pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV6_CASES)
 def test_conv_gemm6_vs_torch(lib, name, T, H, W, segs, cout, k3):
     """conv_gemm6 (round 5): one wave per SIMD on v_mfma_f32_16x16x32_bf16, tiles of 16 rows x 13 columns, 32-channel windows stored column-major
-    (64-channel windows without spatial taps) -- M = 256 (4 waves x 64 couts x 13 pixel blocks) and M = 128 (2 x 64 couts x 7 / 6 blocks) -- vs torch
+    (the STREAM form without spatial taps: one 32-channel window per k32-step, three buffers) -- M = 256 (4 waves x 64 couts x 13 pixel blocks) and M = 128 (2 x 64 couts x 7 / 6 blocks) -- vs torch
     conv3d, bit-reproducible, with the GRU epilogue class."""
     P = T * H * W
     xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
@@ -959,22 +959,25 @@ P_FORMATS = [pytest.param(1, id="p_fp16"), pytest.param(0, id="p_bf16")]      # 
 
 
 def _attn_check(got, ref, operands, scale, p_format=0):
-    """Per-element bound in ulps OF THE ELEMENT (not of the tensor's range).  bf16 keeps 8 significant bits: round to
-    nearest moves a value by at most 2^-8 of itself (half an ulp); fp16 keeps 11: 2^-11.  With bf16 operands as the oracle uses
-    them the kernel's two extra roundings give err <= eps_P * (P |V|) (probabilities rounded to p_format before the PV product,
-    worst case: all errors aligned; eps_P = 2^-8 for bf16 P~, 2^-11 for fp16 P~ -- fp16's subnormal tail adds at most 2^-25 per
-    key relative to the row maximum, covered by the slop) + 2^-8 |ref| (the bf16 result) + 1e-6 fp32 slop; and the typical error
-    must sit far inside that worst case (rounding errors do not all line up)."""
+    """Per-element bound in ulps OF THE ELEMENT (not of the tensor's range), against the UNROUNDED fp32 read-out x = softmax(Q K^T scale) V on
+    the bf16 operands the oracle uses (`ref` = the oracle's result = bf16(x): checked to be exactly that rounding).  The kernel's two extra
+    roundings give |got - x| <= eps_P * (P |V|) (probabilities rounded to p_format before the PV product, worst case: all errors aligned;
+    eps_P = 2^-8 for bf16 P~ -- 8 significant bits, half an ulp <= 2^-8 of the value --, 2^-11 for fp16 P~; fp16's subnormal tail adds at most
+    2^-25 per key relative to the row maximum, covered by the slop) + 2^-8 |x| (the bf16 result: half an ulp) + 1e-6 fp32 slop; and the typical
+    error must sit far inside that worst case (rounding errors do not all line up)."""
     eps_p = 2.0 ** -11 if p_format == 1 else 2.0 ** -8
     for i, (Q, K, V, _, _) in enumerate(operands):
         Qb, Kb, Vb = (t.to(torch.bfloat16).float() for t in (Q, K, V))
         P = torch.softmax((Qb @ Kb.t()) * scale, dim=-1)
-        bound = eps_p * (P @ Vb.abs()) + 2.0 ** -8 * ref[i].abs() + 1e-6
-        err = (got[i] - ref[i]).abs()
+        x = P @ Vb
+        assert ((ref[i] - x).abs() <= 2.0 ** -8 * x.abs() + 1e-6).all(), "the oracle's result is not the bf16 rounding of this read-out"
+        bound = eps_p * (P @ Vb.abs()) + 2.0 ** -8 * x.abs() + 1e-6
+        err = (got[i] - x).abs()
         assert torch.isfinite(got[i]).all()
         worst = (err / bound).max().item()
-        assert worst <= 1.0, f"clip {i}: element error {worst:.2f}x its bf16 bound"
-        assert err.mean().item() <= 0.2 * bound.mean().item(), (err.mean().item(), bound.mean().item())
+        assert worst <= 1.0, f"clip {i}: element error {worst:.2f}x its bound"
+        # (the final rounding alone averages a quarter ulp = ~0.35 of its half-ulp term; the P~ term must add little to that)
+        assert err.mean().item() <= 0.5 * bound.mean().item(), (err.mean().item(), bound.mean().item())
 
 
 # attn_frames: ppms_mem_attn's frames_per_workgroup argument (0 = the library's choice, which needs a 1/4-scale-sized grid to pick 2)
