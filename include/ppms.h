@@ -311,8 +311,9 @@ int ppms_mem_attn(const void* qb, const void* kb, const void* vt, const int32_t*
  * the softmax reference of their query, see mem_attn.hip).  NULL = one fused
  * launch of the 32-query online-softmax kernel.
  * frames_per_workgroup: the 64-query kernel gives a workgroup ONE picked frame, or TWO consecutive ones where the one-frame grid would
- * run at least two rounds on the chip (fewer partials to write and combine).  0 = the library's choice, 1 / 2 = this call uses that
- * many (a per-call argument: the library keeps no mutable state).  The same softmax either way (different summation order). */
+ * run at least two rounds on the chip (fewer partials to write and combine).  0 = the library's choice (1 or 2), 1 .. 5 = this call uses that
+ * many (5 = all picked frames in one workgroup: one partial set per clip; a per-call argument: the library keeps no mutable state).  The
+ * same softmax either way (different summation order). */
 int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
 
 /* Fused chain of up to three per-pixel (1x1, <= 64 input channels) layers with GELU, optional residual from the chain

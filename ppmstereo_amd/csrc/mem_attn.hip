@@ -431,9 +431,28 @@ __global__ __launch_bounds__(256, 1) void mem_attn64_kernel(const bf16_t* __rest
     //  K tile: row = q >> 4 (key), LDS position q & 15 holds source chunk (q & 15) ^ att_kswz(row)
     //  V^T tile: row d = q >> 3, LDS position q & 7 holds source chunk (q & 7) ^ ((d >> 1) & 7)     (chunk = 8 keys)
     const char* kbase = (const char*)(kb + (int64_t)(clip * ksel + slot0) * n * D);
-    const char* vbase0 = (const char*)(vt_g + (int64_t)sel[clip * 5 + slot0] * D * n);
-    const char* vbase1 = (const char*)(vt_g + (int64_t)sel[clip * 5 + slot0 + (nfr > 1 ? 1 : 0)] * D * n);
-    auto v_tile = [&](int j) __attribute__((always_inline)) { return j < ntf ? vbase0 + (int64_t)j * KT * 2 : vbase1 + (int64_t)(j - ntf) * KT * 2; };
+    // V^T base of the picked frame the DMA stream is in.  Tiles are requested in non-decreasing order (0, 1, 2, then j + 3 clamped to the last tile), so ONE
+    // live base is enough: when the stream crosses into the next picked frame -- a uniform branch taken nfr - 1 times per workgroup -- the base is
+    // re-read from `sel`.  (Five live bases cost ten SGPRs the hand-scheduled loop does not have: the compiler spilled to scratch, and a scratch load is
+    // one more entry on the vmcnt counter the LDS-DMA ring counts on; an indexed array of bases goes to scratch outright.)
+    auto vframe = [&](int f) __attribute__((always_inline)) {
+        // the LDS-DMA statements take the base as an SGPR pair; the words pass a statement that holds the 5 wait states a VALU-written SGPR needs
+        // before a VMEM instruction may read it, should the compiler produce them on the VALU (tools/probe/lds_dma_hazard_probe.hip)
+        const uint64_t a = (uint64_t)(uintptr_t)(vt_g + (int64_t)sel[clip * 5 + slot0 + f] * D * n);
+        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
+        return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+    };
+    const char* vcur = vframe(0);
+    int vf = 0, vj0 = 0;                          // slot (relative to slot0) and first tile of the frame `vcur` points at
+    auto v_tile = [&](int j) __attribute__((always_inline)) {
+        if (j - vj0 >= ntf) {                     // (uniform; j < nt = nfr * ntf, so vf + 1 < nfr here)
+            vj0 += ntf;
+            ++vf;
+            vcur = vframe(vf);
+        }
+        return vcur + (int64_t)(j - vj0) * KT * 2;
+    };
     unsigned koff[4], voff[4];
     {
         const int d = tid >> 3;
@@ -681,7 +700,7 @@ extern "C" int ppms_mem_attn(const void* qb, const void* kb, const void* vt, con
                              ppms_sp mf, ppms_sp mfg, void* out_bf16, int T, int n, void* split_ws, int frames_per_workgroup, int p_format, void* stream) {
     PPMS_REQUIRE(qb && kb && vt && sel && beta, "mem_attn: null operand");
     PPMS_REQUIRE(ksel >= 1 && ksel <= 5 && T >= 1 && n >= 1, "mem_attn: bad sizes ksel=%d T=%d n=%d", ksel, T, n);
-    PPMS_REQUIRE(frames_per_workgroup >= 0 && frames_per_workgroup <= 2, "mem_attn: frames_per_workgroup must be 0 (automatic), 1 or 2, got %d", frames_per_workgroup);
+    PPMS_REQUIRE(frames_per_workgroup >= 0 && frames_per_workgroup <= 5, "mem_attn: frames_per_workgroup must be 0 (automatic) or 1 .. 5, got %d", frames_per_workgroup);
     PPMS_REQUIRE(p_format == PPMS_ATTN_P_BF16 || p_format == PPMS_ATTN_P_FP16, "mem_attn: p_format must be PPMS_ATTN_P_BF16 (0) or PPMS_ATTN_P_FP16 (1), got %d", p_format);
     PPMS_REQUIRE(((mf.hi && mf.lo && mf.ld % 8 == 0) || (!mf.hi && !mf.lo)) && mfg.hi && mfg.lo && mfg.ld % 8 == 0,
                  "mem_attn: mf (or a NULL view: the output is hid itself) / mfg must be 16-B aligned SP views");

@@ -980,9 +980,10 @@ def _attn_check(got, ref, operands, scale, p_format=0):
         assert err.mean().item() <= 0.5 * bound.mean().item(), (err.mean().item(), bound.mean().item())
 
 
-# attn_frames: ppms_mem_attn's frames_per_workgroup argument (0 = the library's choice, which needs a 1/4-scale-sized grid to pick 2)
+# attn_frames: ppms_mem_attn's frames_per_workgroup argument (0 = the library's choice, which needs a 1/4-scale-sized grid to pick 2; 5 = all picked
+# frames in one workgroup, one partial set per clip)
 @pytest.mark.parametrize("p_format", P_FORMATS)
-@pytest.mark.parametrize("attn_frames", [0, 2])
+@pytest.mark.parametrize("attn_frames", [0, 2, 5])
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("T,n,ksel_frames", [(5, 256, 5), (8, 1024, 5), (2, 256, 2), (3, 180, 3), (6, 200, 5), (5, 320, 5)])      # (320: a partly filled 256-query block)
 def test_mem_attn_vs_oracle(lib, T, n, ksel_frames, split, attn_frames, p_format):
