@@ -285,7 +285,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", choices=("sampled", "full"), default="sampled", help="sampled (default): one iteration per scale, extrapolated by iteration "
                     "count (~10 s); full: SURVEY 8(d)'s procedure, 1 warm-up + 3 whole-clip runs, median (~6 min) -- the sampled figure is printed beside it")
-    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets around the attention / conv3 kernels")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the HIP-event brackets around the attention / large-map convolution kernels")
     ap.add_argument("--no-encoders", action="store_true", help="skip the encoder / whole-call timings (fnet + cnet + SST block and "
                     "PPMStereo.forward_batch_test on a host video: once per clip, outside `value`, reported under `encoders` / `whole_call_ms`)")
     ap.add_argument("--with-encoders", action="store_true", help=argparse.SUPPRESS)        # (the default since round 3)
@@ -358,19 +358,19 @@ def main():
         pipe.done_events.clear()
 
     # HIP events around every launch (in the sampled steps: TIMING_EVERY) of the two dominant kernel families (memory attention; the large-map implicit-GEMM
-    # convolution kernels conv5_kernel / conv3_kernel -- whichever the engine picked per conv), on the stream each is launched on
+    # convolution kernels conv6_kernel / conv5_kernel -- whichever the engine picked per conv), on the stream each is launched on
     Tl = T // world if sharded else T
     engs = [(model.update_block16.engine(Tl, H // 16, W // 16, dev, shard), iters // 2), (model.update_block08.engine(Tl, H // 8, W // 8, dev, shard), iters // 2),
             (model.update_block04.engine(Tl, H // 4, W // 4, dev, shard), iters)]
-    conv3, family = {}, {}
+    big, family = {}, {}
     if not args.no_kernel_timing:
         for (e, n_it), sc in zip(engs, (16, 8, 4)):
             e.enable_attn_timing(args.steps * n_it)
             for name, op in e.conv_family_ops().items():          # every convolution-family launch of every scale (roofline_3, timed in
                 family[(sc, name)] = op                            # ONE extra step behind the timed region: ~900 event pairs cost ~5 ms)
-                if getattr(op, "version", 0) in (3, 5, 8):            # the large-map kernels (roofline / roofline_2): inside the timed region
+                if getattr(op, "version", 0) in (5, 8):            # the large-map kernels (roofline / roofline_2): inside the timed region
                     op.events = []
-                    conv3[(sc, name)] = op
+                    big[(sc, name)] = op
 
     step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     D.barrier()
@@ -397,8 +397,8 @@ def main():
     attn_ms = [e.attn_times_ms() for e, _ in engs] if not args.no_kernel_timing else []
     # the large-map convolution launches of the timed region: read their events NOW and detach the lists, so that the extra steps below (which
     # switch KERNEL_TIMING on again) cannot append a second step's launches to them (round 4 counted `total_ms_per_step` twice that way)
-    conv3_ms = {k: [a.elapsed_time(b) for a, b in op.events] for k, op in conv3.items()}
-    for op in conv3.values():
+    big_ms = {k: [a.elapsed_time(b) for a, b in op.events] for k, op in big.items()}
+    for op in big.values():
         op.events = None
     fam_events = {}
     if family:                                        # one extra step (outside `value`) with events around EVERY convolution-family launch
@@ -477,12 +477,12 @@ def main():
                           launches=n_launch, avg_ms=round(tot_ms / n_launch, 4), total_ms_per_step=round(tot_ms / n_sampled, 3),
                           flop_per_launch=tot_flop / n_launch, per_scale=per_scale))
         # ---- large-map conv kernels: algorithmic FLOPs of a launch = 2 * pixels * couts * cin * taps from its descriptor
-        if conv3:
+        if big:
             torch.cuda.synchronize()
             c_flop = c_ms = c_bound_ms = 0.0
             c_n, per_op = 0, {}
-            for (sc, name), op in sorted(conv3.items()):
-                ms = conv3_ms[(sc, name)]
+            for (sc, name), op in sorted(big.items()):
+                ms = big_ms[(sc, name)]
                 if not ms:
                     continue
                 c_flop += op.flops() * len(ms)
@@ -499,7 +499,7 @@ def main():
                 cpeak = c_flop / (c_bound_ms * 1e-3) / 1e12           # the launch mix's own bound: dense bf16 / (flop-weighted MFMAs per product), >= 833.3
                 # every sampled step launches the same list (round 4's line held two steps' launches for one sampled step: 234 = 2 x 117): a
                 # diagnostic field, never an abort behind the timed region
-                consistency["launches_per_sampled_step_equal"] = all(len(ms) % n_sampled == 0 for ms in conv3_ms.values())
+                consistency["launches_per_sampled_step_equal"] = all(len(ms) % n_sampled == 0 for ms in big_ms.values())
                 # HBM bytes of one launch: only an IN-SITU figure counts (a launch inside a clip, inputs cold: profiles/rNN_conv_traffic_insitu.json, tools/traffic_pmc.sh).
                 # The back-to-back probe launches of rounds 2-5 read their inputs from the Infinity Cache (0.69x the algorithmic bytes in round 5: not physical
                 # as HBM traffic of the clip), so those files are no longer quoted here
@@ -508,7 +508,7 @@ def main():
                 if tfile and (T, H, W) == (5, 320, 512):
                     ctraffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
                     ctraffic_note = "HBM bytes per launch of the conv6 family INSIDE a clip (all launches of rocprofv3 --pmc passes over whole clips, summed / launches), " + os.path.basename(tfile)
-                names = sorted({f"conv{6 if op.version == 8 else op.version}_kernel" for (sc, name), op in conv3.items() if conv3_ms[(sc, name)]}, reverse=True)
+                names = sorted({f"conv{6 if op.version == 8 else op.version}_kernel" for (sc, name), op in big.items() if big_ms[(sc, name)]}, reverse=True)
                 roofs.append(dict(bound="mfma", kernel=" / ".join(names) + " (large-map implicit-GEMM convolutions, bf16x3 split MFMA; per_op names the kernel of every launch), "
                                                        "every launch in every 20th step of the timed region (step 0, 20, ...); "
                                                        "algorithmic FLOPs = sum over launches of 2*pixels*couts*cin*taps; peak = dense bf16 / (MFMAs per product): 3 "
@@ -541,7 +541,7 @@ def main():
                 by_scale[f"1/{sc}"] = by_scale.get(f"1/{sc}", 0.0) + sum(ms)
             conv_flop = sum(n_it * Tl * c * e.n for (e, n_it), c in zip(engs, (17.75e6, 14.128e6, 14.128e6)))
             fach = conv_flop / (f_ms * 1e-3) / 1e12
-            family_roof = dict(bound="mfma", kernel="every convolution-family launch of a step at the three scales (conv5 / conv3 / conv2 kernels incl. K-slice reduces, "
+            family_roof = dict(bound="mfma", kernel="every convolution-family launch of a step at the three scales (conv6 / conv5 / conv2 / conv_stream / gemm1 kernels incl. K-slice reduces, "
                                                     "hoisted shares, q/k projection, fused per-pixel chains, depthwise 7x7), event-bracketed in ONE extra step run behind the timed region; algorithmic "
                                                     "FLOPs = the reference's conv FLOPs of the clip (SURVEY 8d: 8.42 TFLOP at config 2), not the FLOPs executed (the inp "
                                                     "hoist removes ~13 %); launches of the two streams overlap, so the event sum is an upper bound of the busy time",

@@ -87,6 +87,11 @@ typedef struct ppms_epilogue {
 typedef struct ppms_conv {
     ppms_sp seg[2];               /* input channel segments, concatenated along K                 */
     int32_t nseg;
+    int32_t groups;               /* 0 / 1: every cout reads all input channels (the segments concatenated along K).  2: a GROUPED convolution of two
+                                   * groups -- nseg == 2, input segment s feeds the couts of epilogue half s only (couts [0, m_split) read seg[0], couts
+                                   * [m_split, M) read seg[1]; weights: the two convolutions' packed images interleaved per k-step, pack_conv6_grouped).
+                                   * Served by ppms_conv_gemm6 only (ppms_conv_gemm6_applicable tells); every other entry point refuses it.
+                                   * (Sits in what was padding: ABI size unchanged.) */
     const void* w;                /* packed weights, see ppmstereo_amd/packing.py                  */
     const float* bias;            /* [M] fp32 (never NULL; zeros when the conv has no bias)        */
     int32_t T, H, W;              /* volume; pixels = T*H*W                                        */
@@ -123,21 +128,13 @@ int64_t ppms_conv_gemm2_slice_workspace_bytes(const ppms_conv* desc, int nslice)
 int ppms_conv_gemm2_sliced(const ppms_conv* desc, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream);
 /* Convs with kh > 1 by the same kernel with ONE halo'd window per (dt, chunk) for all their taps (ppms_conv_gemm2 loads a
  * window per kernel row): (kt, kh, 1) kernels swept along y (weights: pack_conv2 order with the kh / kw axes swapped),
- * kernels with kw > 1 as well through a 2-D window (weights: (ky, kx) flattened into x) -- the conventions of
- * ppms_conv_gemm3.  nslice / workspace as for ppms_conv_gemm2_sliced (nslice == 1: none);
+ * kernels with kw > 1 as well through a 2-D window (weights: (ky, kx) flattened into x) -- the sweep-ordered packs
+ * ppms_conv_gemm5 / ppms_conv_gemm6 use too.  nslice / workspace as for ppms_conv_gemm2_sliced (nslice == 1: none);
  * ppms_conv_gemm2_ysweep_slices() = the slice count that pays off (0: not a candidate / window does not fit). */
 int ppms_conv_gemm2_ysweep_slices(const ppms_conv* desc);
 int ppms_conv_gemm2_ysweep(const ppms_conv* desc, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream);
-/* Large-map variant (128 couts x 256 pixels per workgroup, LDS-DMA operands, activation window swept by the taps along
- * x, along y, or over all kh x kw taps).  ppms_conv_gemm3_applicable() tells whether it serves a descriptor
- * (M % 128 == 0, kw > 1 or kh > 1, the halo'd window fits, enough tiles).  Weights in pack_conv2 order with the k-steps
- * in sweep order: kw == 1 convs (swept along y) packed with the kh / kw axes swapped; kh > 1 and kw > 1 convs packed
- * with (ky, kx) flattened into the x axis, i.e. from the weight viewed as (cout, cin, kt, 1, kh*kw).  desc->kh / kw
- * stay the true extents. */
-int ppms_conv_gemm3_applicable(const ppms_conv* desc);
-int ppms_conv_gemm3(const ppms_conv* desc, const ppms_conv* dev_desc, void* stream);
 /* Barrier-free k-loop (conv_gemm5.hip): the weights are packed in MFMA-fragment order (ppmstereo_amd/packing.py pack_conv4,
- * sweep-ordered like ppms_conv_gemm3's packs) and go from L2 straight to registers; the activation window holds 16 channels and is
+ * sweep-ordered: y-swept kernels with kh / kw swapped, 2-D swept ones with (ky, kx) flattened into x) and go from L2 straight to registers; the activation window holds 16 channels and is
  * double buffered, so the loop synchronises once per window instead of once per k-step.  One 8-wave workgroup per CU owns ALL
  * couts (M == 256, or M == 128 with the K loop split between two wave groups) of a tile of nbt = 7 or 8 blocks of 32 pixels, split
  * 4 + 3 (4 + 4) so that every SIMD carries the same load: 51 200 pixels = 240 tiles of 224 on 256 CUs.  nbt = 0: the library picks. */

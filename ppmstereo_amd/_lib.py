@@ -45,7 +45,7 @@ class Epilogue(C.Structure):
 
 
 class Conv(C.Structure):
-    _fields_ = [("seg", SP * 2), ("nseg", C.c_int32), ("w", c_void_p), ("bias", c_void_p),
+    _fields_ = [("seg", SP * 2), ("nseg", C.c_int32), ("groups", C.c_int32), ("w", c_void_p), ("bias", c_void_p),
                 ("T", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("kt", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32),
                 ("M", C.c_int32), ("m_split", C.c_int32), ("t_halo", C.c_int32), ("lo_zero_from", C.c_int32), ("epi", Epilogue * 2)]
@@ -73,8 +73,6 @@ _SIGS = {
     "ppms_conv_gemm2_sliced": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p, c_void_p]),
     "ppms_conv_gemm2_ysweep_slices": (c_int, [C.POINTER(Conv)]),
     "ppms_conv_gemm2_ysweep": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p, c_void_p]),
-    "ppms_conv_gemm3_applicable": (c_int, [C.POINTER(Conv)]),
-    "ppms_conv_gemm3": (c_int, [C.POINTER(Conv), c_void_p, c_void_p]),
     "ppms_gemm1_applicable": (c_int, [C.POINTER(Conv)]),
     "ppms_gemm1": (c_int, [C.POINTER(Conv), c_void_p, c_int, c_void_p]),
     "ppms_conv_stream_applicable": (c_int, [C.POINTER(Conv)]),

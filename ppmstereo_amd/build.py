@@ -25,7 +25,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libppms.so")
 STAMP = LIB + ".stamp"
 LOCK = LIB + ".lock"
-SOURCES = ["corr.hip", "conv_gemm2.hip", "conv_gemm3.hip", "conv_gemm5.hip", "conv_gemm6.hip", "gemm1.hip", "conv_stream.hip", "small_ops.hip", "encoder_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
+SOURCES = ["corr.hip", "conv_gemm2.hip", "conv_gemm5.hip", "conv_gemm6.hip", "gemm1.hip", "conv_stream.hip", "small_ops.hip", "encoder_ops.hip", "mem_attn.hip", "attn16.hip", "pwchain.hip"]
 HEADERS = ["common.h", "corr_lookup.h", "conv_epilogue.h", "conv5_asm.h", "conv6_asm.h", "attn64_asm.h", os.path.join("..", "..", "include", "ppms.h")]
 # Packed fp32 VALU forms (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) are disabled (NO_PK).  Measured on MI355X: such an instruction
 # with op_sel:[0,1] (low result = src0.lo op src1.hi -- the compiler picks that form freely, e.g. in the bilinear resize kernel) reads

@@ -105,7 +105,7 @@ __device__ __forceinline__ void epilogue_group(const ppms_epilogue& e, const flo
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Coalesced form (conv_gemm2 / conv_gemm3).  In the MFMA accumulator layout a lane owns ONE pixel and 4 couts per
+// Coalesced form (conv_gemm2).  In the MFMA accumulator layout a lane owns ONE pixel and 4 couts per
 // register group, so every epilogue load / store of a wave touches 32 different cache lines with 8-16 useful bytes
 // each; with the residual / gate / hoisted-share operands that is several thousand line requests per tile and showed
 // up as 15-30 % of the short GRU convs.  The kernels therefore transpose 32-pixel x 64-cout accumulator blocks through

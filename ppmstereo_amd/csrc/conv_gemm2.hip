@@ -573,7 +573,7 @@ extern "C" int ppms_conv_gemm2_sliced(const ppms_conv* d, const ppms_conv* dev_d
 
 // Convs with kh > 1 whose taps all step ONE halo'd window per (dt, chunk) (the plain entry loads a window per kernel row):
 // (kt, kh, 1) kernels are swept along y, weights packed with kh / kw swapped; kernels with kw > 1 too use a 2-D window, weights
-// packed with (ky, kx) flattened into x -- the same conventions as ppms_conv_gemm3.  nslice as in ppms_conv_gemm2_sliced.
+// packed with (ky, kx) flattened into x -- the sweep-ordered packs conv_gemm5 / conv_gemm6 use too.  nslice as in ppms_conv_gemm2_sliced.
 extern "C" int ppms_conv_gemm2_ysweep(const ppms_conv* d, const ppms_conv* dev_desc, int nslice, void* workspace, void* stream) {
     PPMS_REQUIRE(d != nullptr && d->kh > 1, "conv_gemm2_ysweep: needs a kernel with kh > 1");
     const int mode = d->kw > 1 ? 2 : 1;              // kw > 1: 2-D window over all kh x kw taps
@@ -591,6 +591,7 @@ extern "C" int ppms_conv_gemm2_ysweep(const ppms_conv* d, const ppms_conv* dev_d
 static int conv2_launch(const ppms_conv* d, const ppms_conv* dev_desc, int wm_hint, int nslice, float* part, void* stream, int ysweep) {
     PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm2: null descriptor (host copy and device copy are both required)");
     PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm2: nseg=%d", d->nseg);
+    PPMS_REQUIRE(d->groups <= 1, "conv_gemm2: a grouped convolution (groups=%d) is served by ppms_conv_gemm6 only", d->groups);
     PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm2: bad volume %dx%dx%d", d->T, d->H, d->W);
     PPMS_REQUIRE(d->t_halo >= 0 && d->t_halo <= 8, "conv_gemm2: t_halo=%d", d->t_halo);
     PPMS_REQUIRE((d->kt & 1) && (d->kh & 1) && (d->kw & 1) && d->kw <= 15, "conv_gemm2: kernel extents must be odd, kw <= 15");

@@ -627,6 +627,7 @@ static int conv5_launch(const ppms_conv* d, const ppms_conv* dev_desc, int nbt, 
     PPMS_REQUIRE(d != nullptr && dev_desc != nullptr, "conv_gemm5: null descriptor");
     PPMS_REQUIRE(nbt == 0 || nbt == 7 || nbt == 8, "conv_gemm5: nbt must be 0 (choose), 7 or 8");
     PPMS_REQUIRE(d->nseg == 1 || d->nseg == 2, "conv_gemm5: nseg=%d", d->nseg);
+    PPMS_REQUIRE(d->groups <= 1, "conv_gemm5: a grouped convolution (groups=%d) is served by ppms_conv_gemm6 only", d->groups);
     PPMS_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, "conv_gemm5: bad volume %dx%dx%d", d->T, d->H, d->W);
     PPMS_REQUIRE((d->M == 256 || d->M == 192 || d->M == 128) && d->m_split % 64 == 0, "conv_gemm5: M=%d must be 128, 192 or 256", d->M);
     PPMS_REQUIRE(d->M != 192 || nslice == 1, "conv_gemm5: the 192-cout layout has no K-sliced form");

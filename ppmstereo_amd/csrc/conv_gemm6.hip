@@ -110,7 +110,11 @@ constexpr unsigned CONV6_OOB = 0xFFFFFFF0u;
 // MB: 16-cout blocks per wave -- 4 (M = 256, 128) or 3 (M = 192); CR: rows of a window column = 16 + y halo (16, 18, 20)
 // STREAM: convolutions WITHOUT spatial taps ((kt,1,1) and 1x1): a window = the tile's 208 pixels x 32 channels of one temporal tap, used by ONE k32-step
 // (nothing re-uses it), three window buffers, every step issues the window two steps ahead -- see CONV6_STEP1
-template <int MB, int CR, bool STREAM = false>
+// GRP: a GROUPED convolution of two groups (ppms_conv.groups == 2; M = 256, x sweep of <= 5 taps): input segment s feeds the couts of epilogue half s only
+// (the two 128 -> 128 (1,1,5) tails of convz1 / convr1, ppmtereo_update.py:254-312, as ONE launch in the M = 256 wave layout instead of two M = 128
+// launches with half the work per fixed cost).  Waves 0-1 own group 0's couts, waves 2-3 group 1's; every window exists twice -- the same patch of
+// segment 0 and of segment 1, 9 DMA pieces each -- and a wave reads its group's copy.
+template <int MB, int CR, bool STREAM = false, bool GRP = false>
 __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const Geo6 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ppms_conv& p = pv;                       // by value in the kernel arguments (see conv_gemm2.hip)
@@ -149,17 +153,19 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     // per piece and input segment ONE register: the byte offset of the lane's 16 B from the window's base (= the segment's hi plane at the window's
     // frame shift and first channel): pixel * bytes per pixel + 16-B unit inside the window's channels (+ the distance of the lo plane); padding:
     // an offset beyond the buffer resource's range, which reads zeros.  (The host checks that every offset fits: conv6_offsets_fit.)
-    constexpr int NP = conv6_np(CR);
+    constexpr int NPG = GRP ? 9 : conv6_np(CR);        // pieces per thread of ONE window image
+    constexpr int NP = GRP ? 2 * NPG : NPG;            // pieces per thread and window (GRP: group 0's image, then group 1's)
+    constexpr unsigned GBYTES = NPG * NT6 * 16;        // GRP: distance of group 1's window image
     const int ld0 = p.seg[0].ld * 2, ld1 = p.seg[p.nseg - 1].ld * 2;          // bytes between pixels
     const char* const sp0h = (const char*)p.seg[0].hi;
     const char* const sp1h = (const char*)p.seg[p.nseg - 1].hi;
     const unsigned pd0 = (unsigned)((const char*)p.seg[0].lo - sp0h), pd1 = (unsigned)((const char*)p.seg[p.nseg - 1].lo - sp1h);
-    unsigned off0[NP], off1[NP], off[NP];          // off: the offsets of the segment the NEXT window lies in (copied by dma_setup; a piece's register is
+    unsigned off0[NPG], off1[NPG], off[NP];          // off: the offsets of the segment the NEXT window lies in (copied by dma_setup; a piece's register is
                                                     // not written again before the next window's set-up, a whole k-step after the piece went out)
     {
         const int rows = g.WH * g.WC;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
+        for (int i = 0; i < NPG; ++i) {
             const int q = tid + i * NT6;
             const int row = q >> 3, pos = q & 7;
             off0[i] = off1[i] = CONV6_OOB;
@@ -181,8 +187,21 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     // first channel; stride 0; range CONV6_NUM_RECORDS) + the piece's offset
     int d_buf = 0;
     u32x4 d_srd = {0u, 0u, CONV6_NUM_RECORDS, 0x00020000u};
+    u32x4 d_srd1 = {0u, 0u, CONV6_NUM_RECORDS, 0x00020000u};      // GRP: group 1's window (segment 1)
     auto dma_setup = [&](int kz, int chunk, int buf) {
         const int dt = kz - ht;
+        if constexpr (GRP) {                       // both groups' windows of (tap kz, chunk): the same channels of segment 0 and of segment 1
+            const int c0 = chunk * g.cpw * 2;
+            const uint64_t b0 = (uint64_t)(uintptr_t)(sp0h + (int64_t)dt * HW * ld0 + c0), b1 = (uint64_t)(uintptr_t)(sp1h + (int64_t)dt * HW * ld1 + c0);
+            unsigned w0 = __builtin_amdgcn_readfirstlane((unsigned)b0), w1 = __builtin_amdgcn_readfirstlane((unsigned)(b0 >> 32) & 0xffffu);
+            unsigned w2 = __builtin_amdgcn_readfirstlane((unsigned)b1), w3 = __builtin_amdgcn_readfirstlane((unsigned)(b1 >> 32) & 0xffffu);
+            asm volatile("s_nop 4" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));      // (five wait states between a VALU-written word and its VMEM reader: below)
+            d_srd[0] = w0, d_srd[1] = w1, d_srd1[0] = w2, d_srd1[1] = w3;
+            d_buf = buf;
+#pragma unroll
+            for (int i = 0; i < NPG; ++i) off[i] = off0[i], off[NPG + i] = off1[i];
+            return;
+        }
         const int sg = (chunk >= g.n0) ? 1 : 0;
         const int c0 = (chunk - (sg ? g.n0 : 0)) * g.cpw * 2;                  // byte offset of the window's first channel
         const int64_t shift = (int64_t)dt * HW * (sg ? ld1 : ld0) + c0;
@@ -205,7 +224,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     };
     // (round 5 spaced the pieces >= 4 MFMAs apart on the belief that an LDS-DMA reads M0 / its offset register late; the round-6 probe refutes that --
     //  what bit was the VALU-written resource, see dma_setup -- but the spacing stays: a piece costs ~60 issue cycles, one per MFMA group hides it)
-    auto dma_piece = [&](int i) { dma16_6(off[i], d_srd, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16))); };
+    auto dma_piece = [&](int i) { dma16_6(off[i], (GRP && i >= NPG) ? d_srd1 : d_srd, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16))); };
     // the pieces of a window leave in the first TWO k-steps of the window before it: PPS0 in the first, PPS1 in the second
     constexpr int PPS0 = (NP + 1) / 2, PPS1 = NP / 2;
 
@@ -224,7 +243,8 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 
     // ---- B-operand addressing: row = (blk0 + n) * CR + tap offset + li; chunk position (plane * 4 + lkg) ^ ((li + tap y) & 6); the n * CR * 128
     // part is an immediate of the read, hi and lo fragments differ in bit 6 ---------------------------------------------------------------
-    auto lane_addr = [&](int tyo) { return lds0 + (unsigned)(blk0 * CR * 128 + li * 128) + (unsigned)(((lkg ^ ((li + tyo) & 6)) & 7) << 4); };
+    const unsigned grp_off = GRP ? (unsigned)(wave >> 1) * GBYTES : 0u;          // GRP: this wave's group's window image
+    auto lane_addr = [&](int tyo) { return lds0 + grp_off + (unsigned)(blk0 * CR * 128 + li * 128) + (unsigned)(((lkg ^ ((li + tyo) & 6)) & 7) << 4); };
 
     // temporal taps outside the readable frames contribute zeros: skip them (contiguous kz range)
     const int kz0 = (ht - tf - p.t_halo) > 0 ? (ht - tf - p.t_halo) : 0;
@@ -294,7 +314,8 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             conv6_prime<NBW, CR>(ring, bhn, bhn ^ 64u);                                                                             \
         } else if (CONV6_ABL_NOWAIT_A) { /* timing experiment (wrong results): no wait for the next step's weight fragments */      \
         } else if (issue) { /* the next step's weight fragments: everything but the pieces this step issued behind them */           \
-            if constexpr (NP == 14) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); /* PPS0 = PPS1 = 7 */                          \
+            if constexpr (NP == 18) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); /* GRP: PPS0 = PPS1 = 9 */                     \
+            else if constexpr (NP == 14) asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); /* PPS0 = PPS1 = 7 */                     \
             else if (sw_cur == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); /* NP = 9: PPS0 = 5 */                           \
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); /* PPS1 = 4 */                                                    \
         } else {                                                                                                                   \
@@ -418,7 +439,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         }
     } else {
         if (nbw == NBT6) CONV6_LOOP(13)
-        else if constexpr (MB == 4) {              // (M = 128: the two pixel halves of the tile)
+        else if constexpr (MB == 4 && !GRP) {      // (M = 128: the two pixel halves of the tile)
             if (nbw == 7) CONV6_LOOP(7) else CONV6_LOOP(6)
         }
     }
@@ -532,6 +553,11 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 
 // window geometry for a descriptor; false when this kernel does not serve it
 static bool plan6(const ppms_conv* d, Geo6& g) {
+    const bool grouped = d->groups == 2;
+    if (d->groups > 2 || d->groups < 0) return false;
+    // two groups: segment s -> the couts of epilogue half s; served in the M = 256 layout for an x sweep of <= 5 taps (a 16 x 17 window: 9 pieces per group)
+    if (grouped && !(d->nseg == 2 && d->seg[0].c == d->seg[1].c && d->M == 256 && d->m_split == 128 && d->kh == 1 && d->kw >= 3 && d->kw <= 5 && d->lo_zero_from == 0))
+        return false;
     const bool stream = d->kw == 1 && d->kh == 1;         // no spatial taps: the STREAM form (one k32-step per window, three buffers)
     g.mode = stream ? 4 : (d->kw > 1 && d->kh > 1) ? 2 : (d->kw > 1 ? 0 : 1);
     const int hx = (g.mode == 0 || g.mode == 2) ? d->kw - 1 : 0, hy = (g.mode == 1 || g.mode == 2) ? d->kh - 1 : 0;
@@ -541,8 +567,9 @@ static bool plan6(const ppms_conv* d, Geo6& g) {
         if (d->seg[s].c <= 0 || d->seg[s].c % g.cpw) return false;
         nchunk += d->seg[s].c / g.cpw;
     }
+    if (grouped) nchunk = d->seg[0].c / g.cpw;           // the groups advance in lockstep: a window = one chunk of EACH segment
     g.nchunk = nchunk;
-    g.n0 = d->seg[0].c / g.cpw;
+    g.n0 = grouped ? nchunk : d->seg[0].c / g.cpw;
     g.lz0 = (d->lo_zero_from > 0 && d->lo_zero_from % g.cpw == 0) ? d->lo_zero_from / g.cpw : nchunk;
     g.tiles_x = (d->W + NBT6 - 1) / NBT6;
     g.tiles_y = (d->H + 15) / 16;
@@ -565,6 +592,10 @@ static bool plan6(const ppms_conv* d, Geo6& g) {
     g.npieces = (rows * 8 + NT6 - 1) / NT6;
     g.wbytes = (stream ? 7 : conv6_np(g.WH)) * NT6 * 16;
     g.P = (int64_t)d->T * d->H * d->W;
+    if (grouped) {
+        g.wbytes = 2 * 9 * NT6 * 16;
+        return g.WH == 16 && g.npieces <= 9 && g.nsweep >= 2;
+    }
     if (stream) return g.npieces == 7;
     return (g.WH == 16 || g.WH == 18 || g.WH == 20) && g.npieces <= conv6_np(g.WH) && g.nsweep >= 2;
 }
@@ -663,12 +694,15 @@ extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, vo
 #undef CONV6_ATTR
         (void)hipFuncSetAttribute((const void*)conv6_kernel<4, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv6_kernel<3, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv6_kernel<4, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
 #ifdef PPMS_CONV6_TIMING
     g.dbg = g_conv6_dbg;
 #endif
 #define CONV6_GO(MBV, CRV) hipLaunchKernelGGL((conv6_kernel<MBV, CRV>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g)
-    if (g.mode == 4) {
+    if (d->groups == 2) {
+        hipLaunchKernelGGL((conv6_kernel<4, 16, false, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+    } else if (g.mode == 4) {
         if (d->M == 192) hipLaunchKernelGGL((conv6_kernel<3, 16, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
         else hipLaunchKernelGGL((conv6_kernel<4, 16, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
     } else if (d->M == 192) {

@@ -253,7 +253,7 @@ struct Plan7 {
 };
 
 bool plan7(const ppms_conv* d, Plan7& pl, int hint) {
-    if (d == nullptr || d->nseg < 1 || d->nseg > 2 || d->w == nullptr || d->bias == nullptr) return false;
+    if (d == nullptr || d->nseg < 1 || d->nseg > 2 || d->w == nullptr || d->bias == nullptr || d->groups > 1) return false;      // (grouped: conv_gemm6 only)
     if (d->kt < 1 || d->kh < 1 || d->kw < 1 || !(d->kt & 1) || !(d->kh & 1) || !(d->kw & 1)) return false;
     if (d->T <= 0 || d->H <= 0 || d->W <= 0 || d->t_halo < 0) return false;
     if (d->M <= 0 || d->M % 64 != 0) return false;

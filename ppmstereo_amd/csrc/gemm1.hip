@@ -171,7 +171,7 @@ struct Plan1 {
 // K = 64 NS with NS in {2, 3, 4, 6, 8}; CB (32-cout blocks per workgroup): 2 when that divides the cout blocks and keeps a workgroup inside
 // one epilogue half, else 1 (measured at config 2's sizes, tools/gemm1_probe.py: 2 is best or tied everywhere, 4 gains nothing).
 bool plan1(const ppms_conv* d, Plan1& pl, int cb_hint = 0) {
-    if (d == nullptr || d->kt != 1 || d->kh != 1 || d->kw != 1 || d->nseg < 1 || d->nseg > 2) return false;
+    if (d == nullptr || d->kt != 1 || d->kh != 1 || d->kw != 1 || d->nseg < 1 || d->nseg > 2 || d->groups > 1) return false;      // (grouped: conv_gemm6 only)
     if (d->M <= 0 || d->M % 32 != 0 || d->w == nullptr || d->bias == nullptr) return false;
     int K = 0;
     for (int s = 0; s < d->nseg; ++s) {

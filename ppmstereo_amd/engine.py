@@ -39,7 +39,6 @@ TUNING = dict(
     conv6_pad2x=False,    # conv_gemm6 also for convs whose couts fill only half of the padded rows (convf2: 64 of 128 -- 50 us instead of 63 + 117 us of K-sliced launch + reduce, but on the side stream it takes whole CUs from convc2: 35.5 vs 35.4 ms per clip)
     conv5_sliced=False,   # its K-sliced form on the 1/8, 1/16 maps: correct (tests) but slower than conv_gemm2's slicing there
     conv5_gemm=True,      # its GEMM mode for the 256-cout convs without a spatial sweep ((5,1,1) GRU pass, 1x1 heads)
-    conv3=True,           # large-map kernel of round 1 (conv_gemm3.hip) where conv_gemm5 does not apply
     pwchain=True,         # fused per-pixel layer chains of the correlation encoder
     ysweep=True,          # conv_gemm2: one y-swept window per (dt, chunk) for (1, kh, 1) convs
     win2d=False,          # conv_gemm2: 2-D window for kh, kw > 1 (measured neutral to slower)
@@ -60,6 +59,8 @@ TUNING = dict(
     convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
     conv5_m192=True,      # conv_gemm5's three-cout-block layout for the 190 / 192-cout convs (else padded to 256 rows)
     fork_min_pixels=0,    # independent branches of an iteration run on the side stream only on maps with at least this many pixels (0: always)
+    conv6_grouped=True,   # the two 128 -> 128 (1,1,5) tails of convz1 / convr1 as ONE grouped conv_gemm6 launch (ppms_conv.groups = 2, M = 256 wave layout) where
+                          # conv_gemm6 serves the map, instead of two M = 128 launches on two streams
     attn_p="fp16",        # format of the unnormalised probabilities P~ in the memory read-out's P~ V product (and of the V^T image the to_v conv writes):
                           # "fp16" = 11 significand bits, "bf16" = 8 (what flash-attention itself uses) at the same MFMA count.  The reference fixtures were
                           # generated with fp32 P (tools/gen_golden.py:89-95); with bf16 P~ the iters = 20 cascade ends 1.3e-3 px from them, with fp16 inside 1e-3
@@ -131,7 +132,7 @@ class ConvOp:
         taps included, as a FLOP counter on the reference conv would)."""
         d = self.desc
         cout = d.epi[0].n_valid + (d.epi[1].n_valid if d.m_split < d.M else 0)
-        cin = sum(d.seg[i].c for i in range(d.nseg))
+        cin = d.seg[0].c if d.groups == 2 else sum(d.seg[i].c for i in range(d.nseg))       # (grouped: every cout reads its own segment only)
         return 2.0 * d.T * d.H * d.W * cout * cin * d.kt * d.kh * d.kw
 
     def mfma_per_product(self) -> float:
@@ -177,8 +178,6 @@ class ConvOp:
             L.check(L.load().ppms_conv_gemm2_ysweep(C.byref(self.desc), self.dev.data_ptr(), self.nslice, L.ptr(self.ws), L.stream_ptr()))
         elif self.nslice > 1:
             L.check(L.load().ppms_conv_gemm2_sliced(C.byref(self.desc), self.dev.data_ptr(), self.nslice, self.ws.data_ptr(), L.stream_ptr()))
-        elif self.version == 3:
-            L.check(L.load().ppms_conv_gemm3(C.byref(self.desc), self.dev.data_ptr(), L.stream_ptr()))
         else:
             L.check(L.load().ppms_conv_gemm2(C.byref(self.desc), self.dev.data_ptr(), self.wm_hint, L.stream_ptr()))
 
@@ -273,11 +272,11 @@ class PackedBlock:
         def put(name, weight, bias, segs, seg_pad=None, cout_map=None, m_pad=None):
             self.w[name] = pack_conv(weight, bias, segs, seg_pad, cout_map, m_pad)
             w5 = weight if weight.dim() == 5 else weight[:, :, None]
-            if TUNING["gemm1"] and tuple(w5.shape[2:]) == (1, 1, 1) and not name.endswith(("_y", "_p")):
+            if TUNING["gemm1"] and tuple(w5.shape[2:]) == (1, 1, 1) and not name.endswith("_y"):
                 meta2 = self.w[name][2]
                 if sum(meta2["seg_padded"]) % 64 == 0:
                     self.w1[name] = _packing.pack_gemm1(weight, bias, segs, meta2["seg_padded"], cout_map, meta2["M"])
-            if TUNING["stream"] and not name.endswith(("_y", "_p")) and sum(self.w[name][2]["seg_padded"]) % 64 == 0:
+            if TUNING["stream"] and not name.endswith("_y") and sum(self.w[name][2]["seg_padded"]) % 64 == 0:
                 self.w7[name] = _packing.pack_stream(weight, bias, segs, self.w[name][2]["seg_padded"], cout_map, self.w[name][2]["M"])
             sweep = w5                                                     # x sweep: natural order
             if w5.shape[3] > 1 and w5.shape[4] > 1:
@@ -287,13 +286,13 @@ class PackedBlock:
             elif w5.shape[3] > 1:
                 sweep = w5.transpose(3, 4).contiguous()                      # y sweep: kh / kw swapped
             rows = (max(cout_map) + 1) if cout_map is not None else w5.shape[0]
-            if TUNING["conv6"] and TUNING["conv6_stream"] and w5.shape[2] > 1 and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith(("_y", "_p")):
+            if TUNING["conv6"] and TUNING["conv6_stream"] and w5.shape[2] > 1 and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith("_y"):
                 # (kt,1,1) convs to 256 couts (the z/r conv of the GRU's pass T): conv_gemm6's STREAM form -- one k32-step per 32-channel window of a temporal
                 # tap, three window buffers (1/4 scale: 131 us against conv_gemm5's 155; the 128-cout q conv stays on conv_gemm2: 85 us against 89 there)
                 pads6 = list(seg_pad) if seg_pad is not None else [((c + 31) // 32) * 32 for c in segs]
                 if all(p % 32 == 0 for p in pads6):
                     self.w6[name] = _packing.pack_conv6(w5, bias, segs, pads6, cout_map, 128 if rows <= 128 else (192 if rows <= 192 else 256))
-            if TUNING["conv5"] and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith(("_y", "_p")):
+            if TUNING["conv5"] and (w5.shape[3] > 1 or w5.shape[4] > 1) and not name.endswith("_y"):
                 # conv_gemm5 serves 128, 192 and 256 rows (192: three 64-cout blocks dealt over the eight waves, round 4 -- convc2's 192 and
                 # final_conv's 190 couts no longer run padded to 256)
                 m5 = 128 if rows <= 128 else (192 if rows <= 192 and TUNING["conv5_m192"] else 256)
@@ -301,7 +300,7 @@ class PackedBlock:
                 pads6 = list(seg_pad) if seg_pad is not None else [((c + 31) // 32) * 32 for c in segs]
                 if TUNING["conv6"] and all(p % 32 == 0 for p in pads6):
                     self.w6[name] = _packing.pack_conv6(sweep, bias, segs, pads6, cout_map, 128 if rows <= 128 else (192 if rows <= 192 else 256))
-            elif TUNING["conv5"] and TUNING["conv5_gemm"] and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith(("_y", "_p")):
+            elif TUNING["conv5"] and TUNING["conv5_gemm"] and w5.shape[3] == 1 and w5.shape[4] == 1 and rows > 128 and not name.endswith("_y"):
                 # no spatial sweep: conv_gemm5's GEMM mode (windows of 64 channels) when the segments come in such multiples.  Only the
                 # 256-cout convs (GRU pass-T z/r 197 -> 164 us, mask_2d.2 62 -> 46 us at the 1/4 scale): with 128 couts the two K-groups
                 # get 32-channel windows = 2 k-steps per window, too short a DMA lookahead (pass-T q 110 -> 122 us, to_v 44 -> 66 us)
@@ -327,15 +326,12 @@ class PackedBlock:
             b[:36] = g(c1 + f"conv_list.{i}.bias")
             self.dw.append((w.contiguous(), b.contiguous(), k))
         put("convc2", g(e + "convc2.weight"), g(e + "convc2.bias"), [256])
-        # 192-cout convs padded to 256 rows: lets the large-map kernel (128-cout groups) take them where it applies
-        put("convc2_p", g(e + "convc2.weight"), g(e + "convc2.bias"), [256], None, None, 256)
         # convf1 (7x7 on the 2-channel flow) runs as a 1x1 GEMM over the im2col patch [tap*2 + c], 98 -> 128
         wf1 = g(e + "convf1.weight").permute(0, 2, 3, 1).reshape(128, 98, 1, 1)
         put("convf1", wf1, g(e + "convf1.bias"), [98], [128])
         put("convf2", g(e + "convf2.weight"), g(e + "convf2.bias"), [128])
         # final_conv: couts 0..125 -> motion features (rows 0..125), couts 126..189 -> motion hidden state (rows 128..191)
         put("final", g(e + "final_conv.weight"), g(e + "final_conv.bias"), [320], None, list(range(126)) + list(range(128, 192)), 192)
-        put("final_p", g(e + "final_conv.weight"), g(e + "final_conv.bias"), [320], None, list(range(126)) + list(range(128, 192)), 256)
         put("to_v", g("aggregator.to_v.weight"), None, [128])
         put("unc0", g("uncertainty.0.weight"), g("uncertainty.0.bias"), [128, 128])
         self.unc2_w = g("uncertainty.2.weight").reshape(128).contiguous()
@@ -345,11 +341,14 @@ class PackedBlock:
         put("zr1_0", cat(gr + "convz1.0.weight", gr + "convr1.0.weight"), cat(gr + "convz1.0.bias", gr + "convr1.0.bias"), [128, 384])
         put("z1_2", g(gr + "convz1.2.weight"), g(gr + "convz1.2.bias"), [128])
         put("r1_2", g(gr + "convr1.2.weight"), g(gr + "convr1.2.bias"), [128])
+        self.zr1_2_grouped = None                   # z1_2 | r1_2 as one grouped convolution (conv_gemm6 only)
+        if TUNING["conv6"] and TUNING["conv6_grouped"]:
+            self.zr1_2_grouped = _packing.pack_conv6_grouped([g(gr + "convz1.2.weight"), g(gr + "convr1.2.weight")], [g(gr + "convz1.2.bias"), g(gr + "convr1.2.bias")], 128)
         put("q1", g(gr + "convq1.weight"), g(gr + "convq1.bias"), [128, 384])
         for n in ("2", "3"):
             put("zr" + n, cat(gr + f"convz{n}.weight", gr + f"convr{n}.weight"), cat(gr + f"convz{n}.bias", gr + f"convr{n}.bias"), [128, 384])
             put("q" + n, g(gr + f"convq{n}.weight"), g(gr + f"convq{n}.bias"), [128, 384])
-        # the (1,5,1) pass again with kh / kw swapped: k-step order of the y-swept large-map kernel (conv_gemm3.hip)
+        # the (1,5,1) pass again with kh / kw swapped: k-step order of conv_gemm2's y-swept form (one halo'd window per (dt, chunk))
         put("zr2_y", cat(gr + "convz2.weight", gr + "convr2.weight").transpose(3, 4).contiguous(), cat(gr + "convz2.bias", gr + "convr2.bias"), [128, 384])
         put("q2_y", g(gr + "convq2.weight").transpose(3, 4).contiguous(), g(gr + "convq2.bias"), [128, 384])
         # The GRU input is [h | inp, mf, mfg] (ppmtereo_update.py:292-310, 985-988) and inp does not change between the
@@ -548,14 +547,6 @@ class ScaleEngine:
             op = self._try_fragment_kernels(wname, d, m_split, keep)
             if op is not None:
                 return op
-        if TUNING["conv3"] and isinstance(wname, str) and self.lib.ppms_conv_gemm3_applicable(C.byref(d)):
-            # the large-map kernel wants its k-steps in sweep order: y-swept convs packed with kh / kw swapped ("_y"),
-            # 2-D swept ones (kh, kw > 1) with (ky, kx) flattened into x ("_2d"); without such a pack: conv_gemm2
-            key = wname + "_2d" if (k3[1] > 1 and k3[2] > 1) else wname + "_y" if (k3[2] == 1 and k3[1] > 1) else wname
-            if key in self.pk.w:
-                packed3, bias3, _ = self.pk.w[key]
-                d.w, d.bias = packed3.data_ptr(), bias3.data_ptr()
-                return ConvOp(d, [packed3, bias3, *keep], 3, device=self.dev)
         if TUNING["ysweep"] and isinstance(wname, str) and k3[1] > 1:
             # kh > 1 on a map the large-map kernel does not take: conv_gemm2 with one window for all taps of a (dt, chunk)
             # (y-swept "_y" pack for kw == 1, 2-D window "_2d" pack otherwise), when the halo'd window fits
@@ -597,14 +588,11 @@ class ScaleEngine:
         return None
 
     def _conv_padded(self, wname, *a, **k) -> ConvOp:
-        """wname + "_p" (couts padded to a multiple of 128) when the large-map kernel takes it, else the tight pack."""
+        """The 190 / 192-cout convs (convc2, final_conv): conv_gemm5 / conv_gemm6 in their three-cout-block layout where they serve the map, else the
+        tight conv_gemm2 pack."""
         if TUNING["conv5"] and wname in self.pk.w4:
             op = self._conv(wname, *a, **k)
             if op.version in (5, 8):
-                return op
-        if TUNING["conv3"] and wname + "_p" in self.pk.w:
-            op = self._conv(wname + "_p", *a, **k)
-            if op.version == 3:
                 return op
         return self._conv(wname, *a, **k)
 
@@ -673,6 +661,14 @@ class ScaleEngine:
         # GRU pass along W (two-layer z / r), then H, then T: h cycles through Hb[0] -> Hb[1] -> Hb[2] -> Hb[0]
         o["z1_2"] = self._conv("z1_2", [self.ZT.view()], (1, 1, 5), E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128))
         o["r1_2"] = self._conv("r1_2", [self.RT.view()], (1, 1, 5), E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[0].view()))
+        if self.pk.zr1_2_grouped is not None:       # both tails in one grouped launch where conv_gemm6 rates the map (else the two launches above)
+            packed_g, bias_g, meta_g = self.pk.zr1_2_grouped
+            dg = L.Conv.from_buffer_copy(bytes(o["z1_2"].desc))
+            dg.seg[0], dg.seg[1], dg.nseg, dg.groups = self.ZT.view(), self.RT.view(), 2, 2
+            dg.w, dg.bias, dg.M, dg.m_split = packed_g.data_ptr(), bias_g.data_ptr(), 256, 128
+            dg.epi[0], dg.epi[1] = o["z1_2"].desc.epi[0], o["r1_2"].desc.epi[0]
+            if self.lib.ppms_conv_gemm6_applicable(C.byref(dg)) == 1:
+                o["zr1_2"] = ConvOp(dg, [packed_g, bias_g, self.ZT, self.RT, self.Z, self.RH, H[0]], 8, device=self.dev)
         # the convs over x exist twice on hoisted blocks: "" reads [h | mf, mfg] (the reference's operands: update() driven with a caller's mfg),
         # "_x" reads [h | mf, hid] with the folded weights and skips the products with hid's all-zero lo plane (the loop: attend() leaves hid)
         self.hid_mode = bool(hoist and TUNING["hid_exact"])
@@ -934,7 +930,7 @@ class ScaleEngine:
             self._xa_halo = self._halo_sp(self.XA, 2, async_op=True)
 
     def conv_ops(self, version: Optional[int] = None):
-        """name -> ConvOp of every implicit-GEMM launch of an iteration (version 3: only the large-map kernel's)."""
+        """name -> ConvOp of every implicit-GEMM launch of an iteration (version: only that kernel generation's -- 2 conv_gemm2, 5 conv_gemm5, 6 gemm1, 7 conv_stream, 8 conv_gemm6)."""
         return {k: v for k, v in self.op.items() if isinstance(v, ConvOp) and (version is None or v.version == version)}
 
     def conv_family_ops(self):
@@ -1000,10 +996,13 @@ class ScaleEngine:
             self._pre_pending = False
         tag = "_x" if self._x_hid else ""         # which operands X[256:384] holds: hid (the loop) or mfg (a caller's)
         o["zr1_0" + tag]()
-        with self._fork():
-            o["r1_2"]()
-        o["z1_2"]()
-        self._join()
+        if "zr1_2" in o:
+            o["zr1_2"]()
+        else:
+            with self._fork():
+                o["r1_2"]()
+            o["z1_2"]()
+            self._join()
         for k in ("q1", "zr2", "q2"):
             o[k + tag]()
         # GRU pass along T, (5,1,1) convs (ppmtereo_update.py:305-310): +-2 frames of [h | mf, mfg], then of r*h

@@ -3,7 +3,7 @@
 Reference layout: Conv2d (Cout, Cin, kh, kw) / Conv3d (Cout, Cin, kt, kh, kw) fp32
 (/root/reference/models/core/ppmtereo_update.py, e.g. :254-289).
 
-Packed layout (ppmstereo_amd/csrc/conv_gemm2.hip, conv_gemm3.hip): bf16 [k-step][M/64][2 planes (hi, lo)][64 couts][32 k];
+Packed layout (ppmstereo_amd/csrc/conv_gemm2.hip): bf16 [k-step][M/64][2 planes (hi, lo)][64 couts][32 k];
 the input segments are concatenated along K (each zero-padded to a multiple of 32 channels), and inside each [64][32]
 tile the four 16-byte chunks of row m are stored at chunk position c ^ ((m >> 2) & 3) (the kernels' bank-conflict-free
 read swizzle).  One (k-step, cout block) tile is a contiguous 8 KiB block that reaches LDS by a linear copy.
@@ -79,7 +79,7 @@ def pack_conv4(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
         bf16 [k16-step][M/64][frag = 2*mb + plane][lane = 32*h + r][8]
              = W[cout = 64*blk + 32*mb + r][cin = 16*chunk + 8*h + j] of tap (row-step, s), plane 0 = hi, 1 = lo,
         k16-step = ((kz*kh + ky) * nchunk16 + chunk) * kw + kx.
-    As for conv_gemm3 the LAST kernel axis is the swept one: y-swept convs are passed with kh / kw swapped, 2-D swept ones
+    As for conv_gemm2's swept forms the LAST kernel axis is the swept one: y-swept convs are passed with kh / kw swapped, 2-D swept ones
     with (ky, kx) flattened into x."""
     w = weight.detach().float()
     if w.dim() == 4:
@@ -154,6 +154,25 @@ def pack_conv6(weight: torch.Tensor, bias: Optional[torch.Tensor], seg_channels:
         b[ridx] = bias.detach().float()
     meta = dict(M=M, nk=nk, taps=(kt, kh, kw), cpad=cpad, seg_padded=seg_padded, version=8)
     return packed.reshape(-1), b, meta
+
+
+def pack_conv6_grouped(weights: Sequence[torch.Tensor], biases: Sequence[Optional[torch.Tensor]], group_channels: int) -> Tuple[torch.Tensor, torch.Tensor, dict]:
+    """Two convolutions of the same shape (cout = 128, cin = group_channels, the same taps) as ONE grouped launch of conv_gemm6 (ppms_conv.groups == 2:
+    input segment g feeds the couts of epilogue half g): each is packed as pack_conv6 packs an M = 128 convolution, and the two images are interleaved per
+    k32-step -- [k32-step][16 cout blocks: 8 of group 0, 8 of group 1][plane][lane][8] -- which is the M = 256 layout the kernel's four waves read
+    (wave w: blocks 4 w .. 4 w + 3, i.e. waves 0-1 group 0, waves 2-3 group 1)."""
+    assert len(weights) == 2 and len(biases) == 2
+    parts, bs, meta0 = [], [], None
+    for w, b in zip(weights, biases):
+        assert w.shape[0] <= 128 and w.shape[1] == group_channels, (tuple(w.shape), group_channels)
+        packed, bias, meta = pack_conv6(w, b, [group_channels], None, None, 128)
+        parts.append(packed.reshape(meta["nk"], 8, 2, 64, 8))
+        bs.append(bias)
+        assert meta0 is None or (meta0["nk"], meta0["taps"], meta0["cpad"]) == (meta["nk"], meta["taps"], meta["cpad"])
+        meta0 = meta
+    packed = torch.cat(parts, dim=1).contiguous()                          # [ks][16 blocks][plane][lane][8]
+    meta = dict(M=256, nk=meta0["nk"], taps=meta0["taps"], cpad=meta0["cpad"], seg_padded=[meta0["cpad"], meta0["cpad"]], version=8, groups=2)
+    return packed.reshape(-1), torch.cat(bs), meta
 
 
 def unpack_conv6_reference(packed: torch.Tensor, M: int, nk: int, taps, nchunk: int) -> torch.Tensor:

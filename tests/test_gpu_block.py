@@ -364,7 +364,7 @@ def test_T1_gives_nan_like_reference(model):
 def test_config2_full_size_vs_oracle(model):
     """BASELINE config 2 geometry at FULL size (T=5, 320x512) against the CPU oracle: the cascade with 1 / 1 / 2 iterations at
     the 1/16, 1/8, 1/4 scales (the oracle needs ~15 s for it).  This is the comparison of mem_attn64_kernel at n = 10 240,
-    conv3_kernel at 5x80x128 and every launch planner at the sizes the headline number is measured on."""
+    conv6_kernel at 5x80x128 and every launch planner at the sizes the headline number is measured on."""
     T, H, Wd = 5, 320, 512
     feats = synth_cascade_feats(T, H, Wd)
     rp, ru = [], []

@@ -129,9 +129,9 @@ def _run_conv(L, x_list, weight, bias, k3, T, H, W, act=0, kind=0, aux=None, z=N
         segs.append(t.view())
         keep.append(t)
     wpack = weight
-    if (version in (3, 5, 8) or ysweep) and k3[2] == 1 and k3[1] > 1:       # y-swept kernels: pack with kh / kw swapped
+    if (version in (5, 8) or ysweep) and k3[2] == 1 and k3[1] > 1:       # y-swept kernels: pack with kh / kw swapped
         wpack = (weight if weight.dim() == 5 else weight[:, :, None]).transpose(3, 4).contiguous()
-    if (version in (3, 5, 8) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
+    if (version in (5, 8) or ysweep) and k3[2] > 1 and k3[1] > 1:        # 2-D swept: (ky, kx) flattened into the x axis
         w5 = weight if weight.dim() == 5 else weight[:, :, None]
         wpack = w5.reshape(w5.shape[0], w5.shape[1], w5.shape[2], 1, k3[1] * k3[2]).contiguous()
     packed, b, meta = pack_conv(wpack.to(DEV), None if bias is None else bias.to(DEV), [x.shape[1] for x in x_list], seg_pad,
@@ -236,36 +236,6 @@ def test_conv_gemm_epilogues(lib, version):
     assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RESID, act=L.ACT_GELU, aux=aux), F.gelu(aux + lin)) < 5e-5
     assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_RH, aux=aux), torch.sigmoid(lin) * aux) < 5e-5
     assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < 5e-5
-
-
-CONV3_CASES = [
-    ("gru_1x15", 2, 6, 128, [128, 384], 256, (1, 1, 15)),
-    ("q_1x5", 1, 5, 128, [128, 64], 128, (1, 1, 5)),
-    ("3x3_m128", 3, 20, 32, [128, 128], 128, (1, 3, 3)),
-    ("3x3x3_m256", 4, 9, 64, [128], 256, (3, 3, 3)),
-    ("y_1x5x1", 2, 40, 32, [128, 32], 256, (1, 5, 1)),
-    ("y_w80", 1, 23, 80, [64], 128, (1, 5, 1)),
-    ("x_w80_1x5", 2, 7, 80, [64], 128, (1, 1, 5)),
-    ("3x3_w80_ragged", 2, 23, 80, [32, 32], 128, (1, 3, 3)),
-    ("3x3x3_odd", 3, 11, 50, [64], 128, (3, 3, 3)),
-]
-
-
-@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV3_CASES)
-def test_conv_gemm3_vs_torch(lib, name, T, H, W, segs, cout, k3):
-    """Large-map kernel (64x128 wave tiles, LDS-DMA operands, x / y swept windows) vs torch conv3d."""
-    P = T * H * W
-    xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
-    cin = sum(segs)
-    wt = hash_normal((cout, cin, *k3), 200) / math.sqrt(cin * k3[0] * k3[1] * k3[2])
-    bs = hash_normal((cout,), 201) * 0.1
-    ref = _ref_conv(xs, wt, bs, k3, T, H, W)
-    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=3)
-    assert maxdiff(got, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
-    aux = hash_normal((P, cout), 303)
-    z = torch.sigmoid(hash_normal((P, cout), 304))
-    got = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=3, kind=lib.EPI_GRU, aux=aux, z=z)
-    assert maxdiff(got, (1 - z) * aux + z * torch.tanh(ref)) < 5e-5, name
 
 
 GEMM1_CASES = [
@@ -797,7 +767,61 @@ def test_conv_gemm6_two_epilogue_halves(lib):
         assert (o0.to_f32()[:, n0:] == 0).all()
 
 
-@pytest.mark.parametrize("version", [5, 3, 2])
+@pytest.mark.parametrize("T,H,W,kw", [(2, 20, 30, 5), (1, 16, 13, 5), (3, 33, 40, 3), (5, 80, 128, 5)])
+def test_conv_gemm6_grouped_two_tails_in_one_launch(lib, T, H, W, kw):
+    """ppms_conv.groups = 2: the two 128 -> 128 (1,1,5) tails of convz1 / convr1 (ppmtereo_update.py:254-312) as ONE conv_gemm6 launch -- segment 0 (the
+    z branch's gelu output) feeds couts 0..127 with a sigmoid -> fp32 epilogue, segment 1 (the r branch's) feeds couts 128..255 with the r * h epilogue --
+    against torch conv3d of each tail, and BIT FOR BIT against the two separate M = 128 launches (the same k order per cout); the other convolution
+    entry points refuse a grouped descriptor."""
+    from ppmstereo_amd.engine import ConvOp, epilogue
+    from ppmstereo_amd.packing import pack_conv6, pack_conv6_grouped
+    L = lib
+    P = T * H * W
+    k3 = (1, 1, kw)
+    xz, xr, h = hash_normal((P, 128), 820), hash_normal((P, 128), 821), hash_normal((P, 128), 822)
+    wz, wr = hash_normal((128, 128, *k3), 823) / math.sqrt(128 * kw), hash_normal((128, 128, *k3), 824) / math.sqrt(128 * kw)
+    bz, br = hash_normal((128,), 825) * 0.1, hash_normal((128,), 826) * 0.1
+    zt, rt, ht = L.SPTensor(P, 128, DEV), L.SPTensor(P, 128, DEV), L.SPTensor(P, 128, DEV)
+    zt.set_f32(xz.to(DEV)), rt.set_f32(xr.to(DEV)), ht.set_f32(h.to(DEV))
+    packed, b, meta = pack_conv6_grouped([wz.to(DEV), wr.to(DEV)], [bz.to(DEV), br.to(DEV)], 128)
+    Z, RH = torch.zeros(P, 128, device=DEV), L.SPTensor(P, 128, DEV)
+    d = L.Conv()
+    d.seg[0], d.seg[1], d.nseg, d.groups = zt.view(), rt.view(), 2, 2
+    d.w, d.bias = packed.data_ptr(), b.data_ptr()
+    d.T, d.H, d.W, d.kt, d.kh, d.kw, d.M, d.m_split = T, H, W, 1, 1, kw, 256, 128
+    d.epi[0] = epilogue(act=L.ACT_SIGMOID, n_valid=128, out_f32=Z, out_f32_ld=128)
+    d.epi[1] = epilogue(L.EPI_RH, n_valid=128, out_sp=RH.view(), aux_sp=ht.view())
+    # (the library RATES only maps with enough tiles for the chip -- config 2's 1/4 scale is the last case; the kernel itself serves every size)
+    assert L.load().ppms_conv_gemm6_applicable(C.byref(d)) == (1 if P >= 40000 else 0)
+    ConvOp(d, [zt, rt, ht, packed, b, Z, RH], 8)()
+    torch.cuda.synchronize()
+    ref_z = torch.sigmoid(_ref_conv([xz], wz, bz, k3, T, H, W))
+    ref_r = torch.sigmoid(_ref_conv([xr], wr, br, k3, T, H, W)) * h
+    assert maxdiff(Z.cpu(), ref_z) < 3e-5 and maxdiff(RH.to_f32().cpu(), ref_r) < 3e-5 * max(1.0, h.abs().max().item())
+    # the two separate launches (M = 128 layout): the same bits
+    Z2, RH2 = torch.zeros(P, 128, device=DEV), L.SPTensor(P, 128, DEV)
+    for x_, w_, b_, e_ in ((zt, wz, bz, epilogue(act=L.ACT_SIGMOID, n_valid=128, out_f32=Z2, out_f32_ld=128)),
+                           (rt, wr, br, epilogue(L.EPI_RH, n_valid=128, out_sp=RH2.view(), aux_sp=ht.view()))):
+        p1, b1, m1 = pack_conv6(w_.to(DEV), b_.to(DEV), [128], None, None, 128)
+        d1 = L.Conv()
+        d1.seg[0], d1.nseg, d1.w, d1.bias = x_.view(), 1, p1.data_ptr(), b1.data_ptr()
+        d1.T, d1.H, d1.W, d1.kt, d1.kh, d1.kw, d1.M, d1.m_split = T, H, W, 1, 1, kw, 128, 128
+        d1.epi[0] = e_
+        ConvOp(d1, [x_, p1, b1, Z2, RH2, ht], 8)()
+    torch.cuda.synchronize()
+    assert torch.equal(Z, Z2) and torch.equal(RH.data, RH2.data), "the grouped launch must reproduce the two single launches bit for bit"
+    # repeatable, and refused elsewhere
+    Zc = Z.clone()
+    ConvOp(d, [zt, rt, ht, packed, b, Z, RH], 8)()
+    torch.cuda.synchronize()
+    assert torch.equal(Z, Zc)
+    for ver in (2, 5):
+        with pytest.raises(RuntimeError, match="grouped"):
+            ConvOp(d, [zt, rt, ht, packed, b, Z, RH], ver)()
+    assert L.load().ppms_conv_stream_applicable(C.byref(d)) == 0 and L.load().ppms_gemm1_applicable(C.byref(d)) == 0
+
+
+@pytest.mark.parametrize("version", [5, 2])
 def test_conv_gemm_hoisted_input_share(lib, version):
     """conv([h | inp | rest]) == conv_h_rest([h | rest]) + pre, pre = conv_inp(inp) + bias computed by another launch
     (the engine hoists the inp share of the GRU gates out of the iteration loop): every epilogue adds pre_f32 to

@@ -241,20 +241,35 @@ def test_conv_stream_rating():
 
 
 def test_large_map_kernel_applicability():
-    """ppms_conv_gemm3_applicable: M % 128 == 0, a spatial sweep axis, >= 384 workgroups, and (2-D sweeps) a halo'd window
-    that fits the LDS budget."""
+    """ppms_conv_gemm6_applicable rates a descriptor 1 where its 16 x 13-pixel tiles fill >= 85 % of the CU slots of the launch's rounds (config 2's
+    and config 3's 1/4 scales), 2 where it serves but fills poorly (the caller keeps conv_gemm5 there), 0 on small maps (fewer tiles than ~CUs: the
+    K-sliced / register-streamed kernels fill the chip better) and for what it does not serve; grouped descriptors (groups = 2) only in the shape of the
+    GRU's two (1,1,5) tails.  (No GPU call: the rating is host arithmetic; the CU count falls back to 256 without a device.)"""
     import ctypes as C
     from ppmstereo_amd import _lib as L
     lib = L.load()
-    a = lambda *args: lib.ppms_conv_gemm3_applicable(C.byref(_desc(*args)))
-    assert a(5, 80, 128, 256, (1, 1, 15), [128, 256]) == 1         # x sweep
+
+    def a(T, H, W, M, k3, segs, groups=0, m_split=None):
+        d = _desc(T, H, W, M, k3, segs)
+        d.groups = groups
+        if m_split is not None:
+            d.m_split = m_split
+        return lib.ppms_conv_gemm6_applicable(C.byref(d))
+
+    assert a(5, 80, 128, 256, (1, 1, 15), [128, 256]) == 1         # x sweep, 250 tiles on 256 CUs
     assert a(5, 80, 128, 256, (1, 5, 1), [128, 256]) == 1          # y sweep
-    assert a(5, 80, 128, 256, (3, 3, 3), [128]) == 1               # 2-D sweep, 3x3 window fits
-    assert a(5, 80, 128, 256, (1, 9, 9), [128]) == 0               # 9x9 halo does not fit
-    assert a(5, 80, 128, 256, (5, 1, 1), [128, 256]) == 0          # temporal only: no sweep axis
-    assert a(5, 80, 128, 128, (1, 1, 5), [128, 256]) == 0          # 200 workgroups: conv_gemm2 fills the chip better
-    assert a(5, 80, 128, 192, (1, 3, 3), [256]) == 0               # M not a multiple of 128 (the engine pads such convs)
-    assert a(5, 40, 64, 256, (1, 1, 15), [128, 256]) == 0          # 1/8 scale: too few tiles
+    assert a(5, 80, 128, 256, (3, 3, 3), [128]) == 1               # 2-D sweep
+    assert a(5, 80, 128, 256, (5, 1, 1), [128, 256]) == 1          # temporal only: the STREAM form
+    assert a(5, 80, 128, 128, (1, 1, 5), [128, 256]) == 1          # M = 128: two cout halves x two pixel halves
+    assert a(5, 184, 320, 256, (1, 1, 15), [128, 256]) == 1        # config 3's 1/4 scale
+    assert a(5, 92, 160, 256, (1, 1, 15), [128, 256]) == 2         # config 3's 1/8 scale: 390 tiles = 76 % of two rounds
+    assert a(5, 40, 64, 256, (1, 1, 15), [128, 256]) == 0          # 1/8 scale of config 2: too few tiles
+    assert a(5, 80, 128, 256, (1, 9, 9), [128]) == 0               # kh > 5
+    assert a(5, 80, 128, 64, (1, 3, 3), [128]) == 0                # M = 64
+    assert a(5, 80, 128, 256, (1, 1, 5), [128, 128], groups=2, m_split=128) == 1      # the grouped z1_2 | r1_2 launch
+    assert a(5, 80, 128, 256, (1, 1, 15), [128, 128], groups=2, m_split=128) == 0     # grouped: x sweeps of <= 5 taps only
+    assert a(5, 80, 128, 256, (1, 1, 5), [128, 256], groups=2, m_split=128) == 0      # grouped: equal segments
+    assert a(5, 80, 128, 256, (1, 1, 5), [128, 128], groups=3, m_split=128) == 0
 
 
 def test_fnet_state_dict_is_the_reference_layout():
@@ -347,6 +362,27 @@ def test_pack_gemm1_round_trip():
     packed, b, meta = pack_gemm1(hash_normal((20, 64, 1, 1), 79), None, [64], None, rows)
     full = unpack_gemm1_reference(packed, meta["M"], meta["nk"])
     assert meta["M"] == 64 and (full[1::2][:20] == 0).all() and full[0::2][:20].abs().max() > 0
+
+
+def test_pack_conv6_grouped_interleaves_the_two_convolutions_per_k_step():
+    """pack_conv6_grouped (ppms_conv.groups = 2): per k32-step the 8 cout blocks of group 0's pack_conv6 image, then the 8 of group 1's; both unpack
+    to their own weights (unpack_conv6_reference)."""
+    import torch
+    from ppmstereo_amd.packing import pack_conv6, pack_conv6_grouped, unpack_conv6_reference
+    from ppmstereo_amd.weights import hash_normal
+    k3 = (1, 1, 5)
+    wz, wr = hash_normal((128, 128, *k3), 31), hash_normal((128, 128, *k3), 32)
+    bz, br = hash_normal((128,), 33), hash_normal((128,), 34)
+    packed, bias, meta = pack_conv6_grouped([wz, wr], [bz, br], 128)
+    assert meta["M"] == 256 and meta["groups"] == 2 and meta["seg_padded"] == [128, 128] and meta["nk"] == 4 * 5
+    assert torch.equal(bias, torch.cat([bz, br]))
+    g = packed.reshape(meta["nk"], 16, 2, 64, 8)
+    for i, (w, b) in enumerate(((wz, bz), (wr, br))):
+        single, _, m1 = pack_conv6(w, b, [128], None, None, 128)
+        assert torch.equal(g[:, 8 * i:8 * i + 8].reshape(-1), single)
+        back = unpack_conv6_reference(g[:, 8 * i:8 * i + 8].contiguous().reshape(-1), 128, meta["nk"], k3, 4)        # [128][tap * 128 + ci]
+        want = w[:, :, 0, 0].permute(0, 2, 1).reshape(128, 5 * 128)
+        assert (back - want).abs().max().item() < 1e-4 * want.abs().max().item()
 
 
 def test_pack_stream_round_trip():

@@ -3,7 +3,7 @@ no environment variable itself).  Import this module before the first engine is 
 
     PPMS_CONV5=0 PPMS_SLICE=0 python -c "import tools.ab_switches; ..."      or      import ab_switches  (from tools/)
 
-    PPMS_CONV6, PPMS_CONV5, PPMS_CONV5_SLICED, PPMS_CONV5_GEMM, PPMS_CONV3, PPMS_PWCHAIN, PPMS_SLICE, PPMS_HOIST, PPMS_CONV5_PAD2X: 0 / 1
+    PPMS_CONV6, PPMS_CONV5, PPMS_CONV5_SLICED, PPMS_CONV5_GEMM, PPMS_CONV6_GROUPED, PPMS_PWCHAIN, PPMS_SLICE, PPMS_HOIST, PPMS_CONV5_PAD2X: 0 / 1
     PPMS_HID: 0 / 1 (GRU convs of the hoisted blocks on [h | mf, hid] with folded weights, products with hid's zero lo plane skipped)
     PPMS_STREAM: 0 / 1 / all (conv_stream.hip: off / where the library rates it faster / wherever it serves a small map); PPMS_STREAM_HINT: 0 / 1 / 2
     PPMS_ATTN_P: fp16 / bf16 (ppms_mem_attn's p_format)
@@ -15,7 +15,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ppmstereo_amd import engine as _engine  # noqa: E402
 
-_MAP = dict(PPMS_CONV6="conv6", PPMS_CONV6_STREAM="conv6_stream", PPMS_LOOKUP_FUSED="lookup_fused", PPMS_FLOW_CONV7="flow_conv7", PPMS_CONV6_PAD2X="conv6_pad2x", PPMS_CONV5="conv5", PPMS_CONV5_SLICED="conv5_sliced", PPMS_CONV5_GEMM="conv5_gemm", PPMS_CONV3="conv3", PPMS_PWCHAIN="pwchain",
+_MAP = dict(PPMS_CONV6="conv6", PPMS_CONV6_STREAM="conv6_stream", PPMS_LOOKUP_FUSED="lookup_fused", PPMS_FLOW_CONV7="flow_conv7", PPMS_CONV6_PAD2X="conv6_pad2x", PPMS_CONV5="conv5", PPMS_CONV5_SLICED="conv5_sliced", PPMS_CONV5_GEMM="conv5_gemm", PPMS_CONV6_GROUPED="conv6_grouped", PPMS_PWCHAIN="pwchain",
             PPMS_SLICE="slices", PPMS_HOIST="hoist", PPMS_CONV5_PAD2X="conv5_pad2x", PPMS_CONVF2_UNSLICED="convf2_unsliced", PPMS_GEMM1="gemm1", PPMS_CONV5_M192="conv5_m192", PPMS_HID="hid_exact")
 for _env, _key in _MAP.items():
     if _env in os.environ:
