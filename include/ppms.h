@@ -189,10 +189,6 @@ int ppms_struct_sizes(int* sp, int* epilogue, int* conv);
 int ppms_dwconv_gelu(ppms_sp x, ppms_sp y, const float* w, const float* b, int k, int BT, int H, int W, void* stream);
 /* im2col of the 2-channel flow for convf1 (7x7, ppmtereo_update.py:452,477): patch[pixel][tap*2+c], 98 -> 128 zero padded */
 int ppms_flow_patch7(const float* flow_nhwc, ppms_sp patch, int BT, int H, int W, void* stream);
-/* convf1 + relu in ONE launch (ppmtereo_update.py:452,477: relu(Conv2d(2, 128, 7, padding=3)(flow))): the im2col rows are built in LDS from the
- * fp32 flow [BT][H][W][2] and multiplied with the weights packed as the 1x1 conv over patch[tap*2+c] (98 -> 128 inputs, 128 couts: the
- * conv_gemm2 pack, 4 k-steps x 2 cout blocks); out: SP view of 128 channels.  Replaces ppms_flow_patch7 + the 1x1 implicit-GEMM launch. */
-int ppms_flow_conv7(const float* flow_nhwc, const void* w_packed, const float* bias, ppms_sp out, int BT, int H, int W, void* stream);
 /* uncertainty tail: sigmoid(w . x + b) per pixel (ppmtereo_update.py:891-892) + per-frame partial sums for the
  * QAM frame confidence (ppmstereo.py:506).  unc: fp32 [pixel]; partial: fp32 [BT][nblk], nblk = ceil(H*W/256). */
 int ppms_unc_tail(ppms_sp x, const float* w, float bias, float* unc, float* partial, int BT, int HW, void* stream);
@@ -318,12 +314,6 @@ int64_t ppms_mem_attn_workspace_bytes(int T, int ksel, int n);
  * (ppmtereo_update.py:1024-1030).  dev_params: device copy of the parameter block built by the host
  * (ppmstereo_amd/engine.py: PwChain; layout checked with ppms_pwchain_param_bytes). */
 int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream);
-/* The same chain with its input tile looked up by the chain itself: CorrBlock1D.__call__ (corr.py:74-94; 4 levels x 9 taps at x + flow_x, as
- * ppms_corr_lookup) of every pixel goes straight into the chain's first layer (channels 0..35 of its 64 padded inputs) -- the chain's `in` view is
- * not read.  pyr: levels 0..3 of ppms_corr_build; flow_nhwc: fp32 [BT*H*W][2]; flow_sp_hi / _lo (optional, both or neither): SP planes that
- * receive the flow as two channels at [pixel * flow_sp_ld + 0 / 1] (the motion features' last two channels, ppmtereo_update.py:480). */
-int ppms_pwchain_lookup(const void* dev_params, const float* const pyr[4], const float* flow_nhwc, void* flow_sp_hi, void* flow_sp_lo, int flow_sp_ld,
-                        int BT, int H, int W, void* stream);
 int ppms_pwchain_param_bytes(void);
 
 /* ---------------------------------------------------------------- update_block16 time / space attention pieces */

@@ -86,7 +86,6 @@ _SIGS = {
     "ppms_struct_sizes": (c_int, [C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int)]),
     "ppms_dwconv_gelu": (c_int, [SP, SP, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_flow_patch7": (c_int, [c_void_p, SP, c_int, c_int, c_int, c_void_p]),
-    "ppms_flow_conv7": (c_int, [c_void_p, c_void_p, c_void_p, SP, c_int, c_int, c_int, c_void_p]),
     "ppms_unc_tail": (c_int, [SP, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_nchw_to_sp": (c_int, [c_void_p, SP, c_int, c_int, c_int, c_void_p]),
     "ppms_sp_to_nchw": (c_int, [SP, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -120,7 +119,6 @@ _SIGS = {
     "ppms_attn_prep_q": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ppms_attn_prep_k": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ppms_pwchain": (c_int, [c_void_p, c_int64, c_void_p]),
-    "ppms_pwchain_lookup": (c_int, [c_void_p, C.POINTER(c_void_p), c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ppms_pwchain_param_bytes": (c_int, []),
     "ppms_time_attn": (c_int, [SP, c_void_p, c_void_p, SP, c_int, c_int, c_int, c_void_p]),
     "ppms_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, SP, SP, c_int64, c_int, c_void_p]),

@@ -5,52 +5,8 @@
 // operand format) from layer to layer: one launch replaces three implicit-GEMM launches plus the depthwise 1x1 kernel.
 // Same arithmetic as the unfused path (bf16x3 split MFMA, fp32 accumulate, erf GELU).
 #include "common.h"
-#include "corr_lookup.h"
-
-// The chain's input tile looked up by the chain itself (chain A of the correlation encoder): the 36 taps of CorrBlock1D.__call__
-// (corr.py:74-94) of every pixel of the tile go straight into the LDS activation buffer -- the corr_lookup launch and its 64-channel
-// tensor (26 MB written and read back per iteration at the 1/4 scale) disappear.  Passed BY VALUE beside the parameter block: the pyramid
-// belongs to the clip, the parameter block to the engine.  l[0] == nullptr: the chain reads its input tensor.
-struct ppms_chain_lookup {
-    const float* l[4];        // pyramid levels 0..3, [pixel][W >> level] fp32
-    const float* flow;        // [pixel][2] fp32
-    void* flow_hi;            // optional SP copy of the flow (the last two motion-feature channels, ppmtereo_update.py:480): [pixel * flow_ld + 0 / 1]
-    void* flow_lo;
-    int flow_ld, H, W, pad;
-};
 
 namespace {
-
-// the 16-byte piece `ch8` (input channels 8 ch8 .. 8 ch8 + 7; 36 real taps, then zeros) of pixel `pix` as split bf16
-__device__ __forceinline__ void lookup_piece(const ppms_chain_lookup& lk, int64_t pix, int ch8, u32x4& vh, u32x4& vl) {
-    bf16x8 oh = {0, 0, 0, 0, 0, 0, 0, 0}, ol = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ch8 < 5) {
-        const float xs = (float)(int)(pix % lk.W) + lk.flow[pix * 2];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int ch = ch8 * 8 + j;
-            if (ch < 36) {
-                const int lvl = ch / 9, kk = ch - lvl * 9;
-                const int Wl = lk.W >> lvl;
-                const float* L = (lvl == 0 ? lk.l[0] : lvl == 1 ? lk.l[1] : lvl == 2 ? lk.l[2] : lk.l[3]) + pix * Wl;
-                bf16_t hh, ll;
-                split_bf16(lookup_tap(L, Wl, xs, lvl, kk), hh, ll);
-                oh[j] = hh;
-                ol[j] = ll;
-            }
-        }
-    } else if (ch8 == 5 && lk.flow_hi != nullptr) {          // (an otherwise idle lane) the flow's SP copy
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            bf16_t hh, ll;
-            split_bf16(lk.flow[pix * 2 + c], hh, ll);
-            ((bf16_t*)lk.flow_hi)[pix * lk.flow_ld + c] = hh;
-            ((bf16_t*)lk.flow_lo)[pix * lk.flow_ld + c] = ll;
-        }
-    }
-    vh = *(const u32x4*)&oh;
-    vl = *(const u32x4*)&ol;
-}
 
 constexpr int TP = 128;                      // pixels per workgroup
 constexpr int ROWB = 64;                     // bytes per LDS row: 32 channels x bf16
@@ -79,7 +35,7 @@ struct ChainParams {
 
 // (The parameter block stays behind a device pointer: passed by value in the kernel arguments -- as the conv descriptors are -- the layer
 // loop's dynamic index c.layer[l] sends the struct to scratch memory: chain B at the 1/4 scale 43 -> 54 us, nothing gained at 1/16.)
-__global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restrict__ cp, const ppms_chain_lookup lk) {
+__global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restrict__ cp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ChainParams& c = *cp;
     // Two activation buffers, used alternately, + one weight block: 80 KiB, so that TWO workgroups share a CU (three buffers: one
@@ -100,12 +56,8 @@ __global__ __launch_bounds__(256) void pwchain_kernel(const ChainParams* __restr
         const int64_t pix = p0 + px;
         u32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
         if (pix < c.P) {
-            if (lk.l[0] != nullptr) {                          // (uniform)
-                lookup_piece(lk, pix, ch, vh, vl);
-            } else {
-                vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
-                vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
-            }
+            vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
+            vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
         }
         const int off = (ch >> 2) * 2 * ACT_PLANE + swzp(px, ch & 3);
         *(u32x4*)(bufX + off) = vh;
@@ -239,7 +191,7 @@ constexpr int ACT32_PLANE = TP32 * ROWB;     // 2 KiB
 constexpr int ACT32_BUF = 4 * ACT32_PLANE;   // [kstep 2][plane 2][32 px][64 B] = 8 KiB
 constexpr int W32_MAX = 4 * W_BLK;           // weights of a 256-cout layer: 64 KiB (reused as the output staging patch of the last layer)
 
-__global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __restrict__ cp, const ppms_chain_lookup lk) {
+__global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __restrict__ cp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ChainParams& c = *cp;
     char* bufX = smem;
@@ -253,12 +205,8 @@ __global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __res
         const int64_t pix = p0 + px;
         u32x4 vh = {0, 0, 0, 0}, vl = {0, 0, 0, 0};
         if (pix < c.P) {
-            if (lk.l[0] != nullptr) {
-                lookup_piece(lk, pix, ch, vh, vl);
-            } else {
-                vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
-                vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
-            }
+            vh = gload16((const bf16_t*)c.in.hi + pix * c.in.ld + ch * 8);
+            vl = gload16((const bf16_t*)c.in.lo + pix * c.in.ld + ch * 8);
         }
         const int off = (ch >> 2) * 2 * ACT32_PLANE + swzp(px, ch & 3);
         *(u32x4*)(bufX + off) = vh;
@@ -391,140 +339,9 @@ __global__ __launch_bounds__(256) void pwchain32_kernel(const ChainParams* __res
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// convf1 of the motion encoder (/root/reference/models/core/ppmtereo_update.py:62,87: Conv2d(2, 128, 7, padding=3) + relu on the flow) as ONE
-// launch: the 7x7x2 im2col rows [tap * 2 + c] (98 of 128 k values) of a 64-pixel tile are built in LDS straight from the fp32 flow -- in the
-// split-bf16 MFMA B-operand layout the chains above use -- and multiplied with the 1x1-packed weights (pack_conv2, 4 k-steps x 2 cout blocks).
-// Before, flow_patch7_kernel wrote the im2col tensor to memory (26 MB of 2-byte stores at the 1/4 scale) for an implicit-GEMM launch to read back.
-// Same arithmetic per output element (k order, split products, fp32 accumulate) as that pair of launches.
-constexpr int FC_TP = 64;                     // pixels per workgroup
-constexpr int FC_PLANE = FC_TP * ROWB;        // one 32-channel k-step of one plane: 4 KiB
-constexpr int FC_ACT = 4 * 2 * FC_PLANE;      // [kstep 4][plane 2][64 px][64 B] = 32 KiB
-constexpr int FC_W = 4 * 8192;                // one 64-cout block, K = 128: [kstep 4][plane 2][64][64 B] = 32 KiB
-constexpr int FC_STG = 2 * FC_TP * 128;       // output staging [plane][64 px][64 couts] = 16 KiB          (80 KiB: two workgroups per CU)
-
-__global__ __launch_bounds__(256) void flow_conv7_kernel(const float* __restrict__ flow, const char* __restrict__ w, const float* __restrict__ bias,
-                                                         ppms_sp out, int H, int W, int64_t P) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* act = smem;
-    char* wsm = smem + FC_ACT;
-    char* stg = smem + FC_ACT + FC_W;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int64_t p0 = (int64_t)blockIdx.x * FC_TP;
-    u32x4 wreg[8];                            // the next cout block's weights: 32 KiB / 256 threads
-    auto load_w = [&](int mblk) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int q = tid + i * 256;
-            const int ks = q >> 9, rem = q & 511;                 // 512 pieces (8 KiB) per k-step and cout block
-            wreg[i] = gload16(w + ((int64_t)(ks * 2 + mblk) * 512 + rem) * 16);
-        }
-    };
-    load_w(0);
-    {   // im2col: lane = pixel, a wave owns the 16-byte pieces (8 k values = 4 taps x 2 channels) wave, wave + 4, ... of every pixel row
-        const int64_t pix = p0 + lane;
-        const bool live = pix < P;
-        const int px = live ? (int)(pix % W) : 0, py = live ? (int)((pix / W) % H) : 0;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int ch = __builtin_amdgcn_readfirstlane(wave + 4 * it);
-            float v[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int tap = ch * 4 + i;
-                const int ky = tap / 7, kx = tap - ky * 7;
-                const int xx = px + kx - 3, yy = py + ky - 3;
-                float2 f = {0.0f, 0.0f};
-                if (tap < 49 && live && (unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H)
-                    f = *(const float2*)(flow + (pix + (int64_t)(ky - 3) * W + (kx - 3)) * 2);
-                v[2 * i] = f.x;
-                v[2 * i + 1] = f.y;
-            }
-            bf16x8 oh, ol;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                bf16_t hh, ll;
-                split_bf16(v[j], hh, ll);
-                oh[j] = hh;
-                ol[j] = ll;
-            }
-            const int off = (ch >> 2) * 2 * FC_PLANE + swzp(lane, ch & 3);
-            *(bf16x8*)(act + off) = oh;
-            *(bf16x8*)(act + FC_PLANE + off) = ol;
-        }
-    }
-    const int mb = wave & 1, ph = wave >> 1;          // wave: couts [32 mb, 32 mb + 32) of the block x pixels [32 ph, 32 ph + 32)
-    for (int mblk = 0; mblk < 2; ++mblk) {
-        __syncthreads();                              // im2col rows written / the previous block's readers of wsm are done
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *(u32x4*)(wsm + (tid + i * 256) * 16) = wreg[i];
-        if (mblk == 0) load_w(1);
-        __syncthreads();
-        f32x16 acc = (f32x16){0};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int k16 = 0; k16 < 2; ++k16) {
-                const int boff = ks * 2 * FC_PLANE + swzp(ph * 32 + r, 2 * k16 + h);
-                const bf16x8 bh = *(const bf16x8*)(act + boff), bl = *(const bf16x8*)(act + FC_PLANE + boff);
-                const int aoff = ks * 8192 + swzp(mb * 32 + r, 2 * k16 + h);
-                const bf16x8 ah = *(const bf16x8*)(wsm + aoff), al = *(const bf16x8*)(wsm + 4096 + aoff);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
-            }
-        // epilogue: lane = pixel 32 ph + r, couts cl = 32 mb + 8 g + 4 h + j of the block -> staging rows of 128 B per pixel and plane (16-byte
-        // pieces rotated by the pixel index, so that the 32 rows a wave writes spread over the banks)
-        const int spx = ph * 32 + r;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int cl = mb * 32 + 8 * g + 4 * h;
-            const f32x4 b4 = gld<f32x4>(bias + mblk * 64 + cl);
-            bf16x4 oh, ol;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float y = acc[4 * g + j] + b4[j];
-                y = y < 0.0f ? 0.0f : y;
-                bf16_t hh, ll;
-                split_bf16(y, hh, ll);
-                oh[j] = hh;
-                ol[j] = ll;
-            }
-            const int so = spx * 128 + ((((cl >> 3) ^ spx) & 7) << 4) + (cl & 7) * 2;
-            *(bf16x4*)(stg + so) = oh;
-            *(bf16x4*)(stg + FC_TP * 128 + so) = ol;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {                 // 64 px x 2 planes x 8 pieces
-            const int qd = tid + i * 256;
-            const int opx = qd >> 4, plane = (qd >> 3) & 1, ch = qd & 7;
-            const int64_t opix = p0 + opx;
-            if (opix < P) {
-                const u32x4 v = *(const u32x4*)(stg + plane * FC_TP * 128 + opx * 128 + (((ch ^ opx) & 7) << 4));
-                gstore16((bf16_t*)(plane ? out.lo : out.hi) + opix * out.ld + mblk * 64 + ch * 8, v);
-            }
-        }
-    }
-}
-
 }  // namespace
 
-extern "C" int ppms_flow_conv7(const float* flow_nhwc, const void* w_packed, const float* bias, ppms_sp out, int BT, int H, int W, void* stream) {
-    PPMS_REQUIRE(flow_nhwc && w_packed && bias && out.hi && out.lo, "flow_conv7: null argument");
-    PPMS_REQUIRE(out.c == 128 && out.ld % 8 == 0 && out.ld >= 128 && ((uintptr_t)out.hi & 15) == 0 && ((uintptr_t)out.lo & 15) == 0,
-                 "flow_conv7: the output view must hold 128 channels (ld a multiple of 8, 16-byte aligned)");
-    PPMS_REQUIRE(BT > 0 && H > 0 && W > 0, "flow_conv7: bad map %dx%dx%d", BT, H, W);
-    constexpr size_t lds = FC_ACT + FC_W + FC_STG;
-    static ppms_device_once once;
-    once.run([] { (void)hipFuncSetAttribute((const void*)flow_conv7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(FC_ACT + FC_W + FC_STG)); });
-    const int64_t P = (int64_t)BT * H * W;
-    hipLaunchKernelGGL(flow_conv7_kernel, dim3(ceil_div(P, FC_TP)), dim3(256), lds, (hipStream_t)stream, flow_nhwc, (const char*)w_packed, bias, out, H, W, P);
-    return ppms_check_launch("flow_conv7");
-}
-
-static int pwchain_launch(const void* dev_params, int64_t pixels, const ppms_chain_lookup& lk, void* stream) {
+static int pwchain_launch(const void* dev_params, int64_t pixels, void* stream) {
     constexpr size_t lds = 2 * ACT_BUF + W_BLK;                // 80 KiB: two workgroups per CU
     constexpr size_t lds32 = 2 * ACT32_BUF + W32_MAX;          // 80 KiB
     static ppms_device_once once;
@@ -533,26 +350,16 @@ static int pwchain_launch(const void* dev_params, int64_t pixels, const ppms_cha
         (void)hipFuncSetAttribute((const void*)pwchain32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * ACT32_BUF + W32_MAX));
     });
     if (pixels <= 16384) {                                       // small maps: 32-pixel tiles, one phase per layer
-        hipLaunchKernelGGL(pwchain32_kernel, dim3(ceil_div(pixels, TP32)), dim3(256), lds32, (hipStream_t)stream, (const ChainParams*)dev_params, lk);
+        hipLaunchKernelGGL(pwchain32_kernel, dim3(ceil_div(pixels, TP32)), dim3(256), lds32, (hipStream_t)stream, (const ChainParams*)dev_params);
         return ppms_check_launch("pwchain");
     }
-    hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params, lk);
+    hipLaunchKernelGGL(pwchain_kernel, dim3(ceil_div(pixels, TP)), dim3(256), lds, (hipStream_t)stream, (const ChainParams*)dev_params);
     return ppms_check_launch("pwchain");
 }
 
 extern "C" int ppms_pwchain(const void* dev_params, int64_t pixels, void* stream) {
     PPMS_REQUIRE(dev_params != nullptr && pixels > 0, "pwchain: bad arguments");
-    ppms_chain_lookup lk = {};
-    return pwchain_launch(dev_params, pixels, lk, stream);
-}
-
-extern "C" int ppms_pwchain_lookup(const void* dev_params, const float* const pyr[4], const float* flow_nhwc, void* flow_sp_hi, void* flow_sp_lo, int flow_sp_ld,
-                                   int BT, int H, int W, void* stream) {
-    PPMS_REQUIRE(dev_params != nullptr && pyr != nullptr && pyr[0] && pyr[1] && pyr[2] && pyr[3] && flow_nhwc != nullptr, "pwchain_lookup: null operand");
-    PPMS_REQUIRE(BT > 0 && H > 0 && (W >> 3) >= 2, "pwchain_lookup: bad shape BT=%d H=%d W=%d (level 3 needs >= 2 columns)", BT, H, W);
-    PPMS_REQUIRE((flow_sp_hi == nullptr) == (flow_sp_lo == nullptr), "pwchain_lookup: the flow's SP copy needs both planes");
-    ppms_chain_lookup lk = {{pyr[0], pyr[1], pyr[2], pyr[3]}, flow_nhwc, flow_sp_hi, flow_sp_lo, flow_sp_ld, H, W, 0};
-    return pwchain_launch(dev_params, (int64_t)BT * H * W, lk, stream);
+    return pwchain_launch(dev_params, pixels, stream);
 }
 
 extern "C" int ppms_pwchain_param_bytes(void) { return (int)sizeof(ChainParams); }

@@ -50,12 +50,6 @@ TUNING = dict(
     stream_hint=0,        # its tile: 0 = the library chooses, 1 / 2 = 32- / 64-pixel tiles
     hid_exact=True,       # hoisted blocks: the GRU convs read [h | mf, hid] with weights (W_mf + W_mfg | beta W_mfg) instead of [h | mf, mfg]; hid is a
                           # bf16 tensor (all-zero lo plane), so the products with that plane are skipped (ppms_conv.lo_zero_from)
-    lookup_fused=False,   # the correlation lookup inside chain A's input stage (pwchain.hip: lookup_piece) instead of its own launch + the 64-channel CORR tensor:
-                          # one launch fewer per iteration, but the taps then come from 400 workgroups instead of 12 800 (chain A 28 -> ~55 us for the 17 us launch
-                          # it replaces at the 1/4 scale): 35.37 vs 35.40 ms per clip, three alternations -- off
-    flow_conv7=False,     # convf1 as one launch building its 7x7 im2col rows in LDS (pwchain.hip: flow_conv7_kernel) instead of flow_patch7 + a 1x1 GEMM launch:
-                          # 26 + 36 us -> one launch at the 1/4 scale, but the flow branch runs on the side stream under the (longer) correlation encoder
-                          # chain: 35.9 vs 35.85 ms per clip, three alternations on one box -- off
     convf2_unsliced=False,  # the flow encoder's 3x3 128 -> 64 conv without K slices on large maps (measured neutral: 40.3 / 40.2 ms per clip)
     conv5_m192=True,      # conv_gemm5's three-cout-block layout for the 190 / 192-cout convs (else padded to 256 rows)
     fork_min_pixels=0,    # independent branches of an iteration run on the side stream only on maps with at least this many pixels (0: always)
@@ -239,19 +233,13 @@ class PwChain:
         self.pixels, self.keep, self.cp = pixels, keep, cp
         self.dev = torch.frombuffer(bytearray(bytes(cp)), dtype=torch.uint8).clone().to(device)
         self.events = None
-        self.lookup = None            # callable -> (pyr_ptrs, flow_ptr, flow_sp_hi, flow_sp_lo, flow_sp_ld, BT, H, W): the chain looks its input up itself ...
-        self.lookup_armed = False     # ... in its NEXT launch (ScaleEngine.lookup() arms it; a caller's own correlation tensor is read from the input view)
 
     def __call__(self):
         ev = self.events if KERNEL_TIMING["on"] else None
         if ev is not None:
             pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             pair[0].record()
-        if self.lookup is not None and self.lookup_armed:
-            self.lookup_armed = False
-            L.check(L.load().ppms_pwchain_lookup(self.dev.data_ptr(), *self.lookup(), L.stream_ptr()))
-        else:
-            L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
+        L.check(L.load().ppms_pwchain(self.dev.data_ptr(), self.pixels, L.stream_ptr()))
         if ev is not None:
             pair[1].record()
             ev.append(pair)
@@ -611,9 +599,6 @@ class ScaleEngine:
             # chain A: x1 = gelu(x + ffn1(x)); x2 = gelu(x1 + dw1x1(x1))      CORR -> C2
             o["chainA"] = PwChain(self.CORR.view(), self.C2.view(), [(w["ffn1_0"], 54, False, None), (w["ffn1_2"], 36, True, dw1)], self.P, [dw1[0]],
                                  device=self.dev)
-            if TUNING["lookup_fused"]:
-                fl = self.X.view(254, 2)
-                o["chainA"].lookup = lambda: (self.pyr_ptrs, self.FLOW.data_ptr(), fl.hi, fl.lo, 384, self.T, self.h, self.w)
             # chain B: x4 = gelu(x3 + pw x3); cor = gelu(ffn2(x4))              C1 -> COR256
             o["chainB"] = PwChain(self.C1.view(), self.COR256.view(), [(w["pw"], 36, True, None), (w["ffn2_0"], 54, False, None),
                                                                        (w["ffn2_2"], 256, False, None)], self.P, [], device=self.dev)
@@ -626,11 +611,6 @@ class ScaleEngine:
         o["ffn2_0"] = self._conv("ffn2_0", [self.C2.view()], k1, E(act=L.ACT_GELU, n_valid=54, out_sp=self.T1.view()))
         o["ffn2_2"] = self._conv("ffn2_2", [self.T1.view()], k1, E(act=L.ACT_GELU, n_valid=256, out_sp=self.COR256.view()))
         o["convf1"] = self._conv("convf1", [self.PATCH.view()], k1, E(act=L.ACT_RELU, n_valid=128, out_sp=self.FLO1.view()))
-        if TUNING["flow_conv7"]:
-            wf1, bf1, mf1 = self.pk.w["convf1"]
-            assert mf1["nk"] == 4 and mf1["M"] == 128 and mf1["version"] == 2, mf1
-            o["flow_conv7"] = TimedCall(lambda: L.check(self.lib.ppms_flow_conv7(self.FLOW.data_ptr(), wf1.data_ptr(), bf1.data_ptr(), self.FLO1.view(),
-                                                                                 self.T, self.h, self.w, L.stream_ptr())))
         for par in (0, 1):
             cf, cf_next = self.CF[par], self.CF[1 - par]
             o[f"init2_{par}"] = self._conv("init2", [self.ZT.view(0, 64)], k3, E(n_valid=64, out_sp=cf.view(256, 64)))
@@ -661,7 +641,7 @@ class ScaleEngine:
         # GRU pass along W (two-layer z / r), then H, then T: h cycles through Hb[0] -> Hb[1] -> Hb[2] -> Hb[0]
         o["z1_2"] = self._conv("z1_2", [self.ZT.view()], (1, 1, 5), E(act=L.ACT_SIGMOID, n_valid=128, out_f32=self.Z, out_f32_ld=128))
         o["r1_2"] = self._conv("r1_2", [self.RT.view()], (1, 1, 5), E(L.EPI_RH, n_valid=128, out_sp=self.RH.view(), aux_sp=H[0].view()))
-        if self.pk.zr1_2_grouped is not None:       # both tails in one grouped launch where conv_gemm6 rates the map (else the two launches above)
+        if self.pk.zr1_2_grouped is not None and TUNING["conv6_grouped"]:       # both tails in one grouped launch where conv_gemm6 rates the map (else the two launches above)
             packed_g, bias_g, meta_g = self.pk.zr1_2_grouped
             dg = L.Conv.from_buffer_copy(bytes(o["z1_2"].desc))
             dg.seg[0], dg.seg[1], dg.nseg, dg.groups = self.ZT.view(), self.RT.view(), 2, 2
@@ -818,13 +798,7 @@ class ScaleEngine:
         self.STRIVE.fill_(1.0)
 
     # ------------------------------------------------------------------ iteration stages
-    def lookup(self, force: bool = False):
-        """force: run the stand-alone lookup launch (CORR holds the taps afterwards: stage-by-stage checks) even where chain A looks them up itself."""
-        if not force and "chainA" in self.op and self.op["chainA"].lookup is not None:
-            self.op["chainA"].lookup_armed = True   # chain A of the next motion_and_value() looks the taps up itself
-            return
-        if "chainA" in self.op:
-            self.op["chainA"].lookup_armed = False
+    def lookup(self):
         self.hbm["corr_lookup"]()
 
     def _lookup(self):
@@ -858,11 +832,8 @@ class ScaleEngine:
     def motion_and_value(self):
         o, s, par = self.op, self._s(), self.parity
         with self._fork():                        # flow branch: convf1 (7x7 via im2col) -> convf2
-            if "flow_conv7" in o:
-                o["flow_conv7"]()
-            else:
-                L.check(self.lib.ppms_flow_patch7(self.FLOW.data_ptr(), self.PATCH.view(), self.T, self.h, self.w, self._s()))
-                o["convf1"]()
+            L.check(self.lib.ppms_flow_patch7(self.FLOW.data_ptr(), self.PATCH.view(), self.T, self.h, self.w, self._s()))
+            o["convf1"]()
             o[f"convf2_{par}"]()
         if not self.have_mhs:                     # init_conv(inp), ppmtereo_update.py:469-471
             o["init0"]()

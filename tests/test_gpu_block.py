@@ -470,12 +470,11 @@ def test_test_mode_drops_only_dead_work(model):
     assert len(preds) == 20 and torch.equal(d, preds[-1]) and torch.equal(c, uncs[-1])
 
 
-def test_fused_launch_switches_do_not_change_the_cascade(model):
-    """The two launch fusions kept behind engine.TUNING switches (off by default: measured neutral in the clip) stay correct: the correlation
-    lookup inside chain A's tile staging (lookup_fused) reproduces the cascade bit for bit, convf1 as one launch with its im2col rows built in
-    LDS (flow_conv7) to a step of the split-bf16 storage of its output."""
+def test_grouped_gru_tails_do_not_change_the_cascade(model):
+    """engine.TUNING["conv6_grouped"]: the two (1,1,5) tails of convz1 / convr1 as ONE grouped conv_gemm6 launch (ppms_conv.groups = 2) or as two launches on
+    two streams -- the same k order per cout, hence the same bits, at config 2's size (where conv_gemm6 serves the 1/4 scale)."""
     from ppmstereo_amd import engine as E
-    T, H, Wd = 3, 64, 256
+    T, H, Wd = 5, 320, 512
     feats = {k: v.to(DEV) for k, v in synth_cascade_feats(T, H, Wd).items()}
     blocks = (model.update_block16, model.update_block08, model.update_block04)
 
@@ -483,21 +482,21 @@ def test_fused_launch_switches_do_not_change_the_cascade(model):
         old = {k: E.TUNING[k] for k in sw}
         E.TUNING.update(sw)
         for b in blocks:
-            b._engines.clear()
+            b.invalidate()                     # weights are packed (and engines built) under the switch
         try:
             preds, uncs = [], []
-            model.cascade(feats, 4, T, preds, uncs)
-            return torch.stack(preds).float().cpu(), torch.stack(uncs).float().cpu()
+            model.cascade(feats, 2, T, preds, uncs)
+            eng = model.update_block04.engine(T, H // 4, Wd // 4, DEV)
+            return torch.stack(preds).float().cpu(), torch.stack(uncs).float().cpu(), "zr1_2" in eng.op
         finally:
             E.TUNING.update(old)
             for b in blocks:
-                b._engines.clear()
+                b.invalidate()
 
-    base = run(flow_conv7=False, lookup_fused=False)
-    lk = run(flow_conv7=False, lookup_fused=True)
-    assert torch.equal(base[0], lk[0]) and torch.equal(base[1], lk[1])
-    fc = run(flow_conv7=True, lookup_fused=False)
-    assert (fc[0] - base[0]).abs().mean() < 1e-4 and (fc[1] - base[1]).abs().max() < 1e-4, ((fc[0] - base[0]).abs().mean(), (fc[1] - base[1]).abs().max())
+    grouped = run(conv6_grouped=True)
+    two = run(conv6_grouped=False)
+    assert grouped[2] and not two[2], "the switch must select the launch plan of the 1/4 scale"
+    assert torch.equal(grouped[0], two[0]) and torch.equal(grouped[1], two[1])
 
 
 def test_attention_is_a_convex_combination(model):

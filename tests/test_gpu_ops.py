@@ -1140,40 +1140,6 @@ def test_dwconv_gelu(lib, k, BT, H, W, cv):
     assert (got[:, cv:] == 0).all(), "channels outside the view must not be written"
 
 
-@pytest.mark.parametrize("BT,H,W", [(2, 9, 18), (1, 5, 7), (3, 20, 32), (5, 80, 128), (1, 3, 64)])
-def test_flow_conv7_vs_conv2d(lib, BT, H, W):
-    """convf1 + relu of the motion encoder (ppmtereo_update.py:452,477: Conv2d(2, 128, 7, padding=3) on the flow) as one launch building its
-    im2col rows in LDS, against F.conv2d on the same fp32 flow; ragged tiles (pixel counts off the 64-pixel tile), maps narrower than the 7-tap
-    reach, and against the two launches it replaces (flow_patch7 + the 1x1 implicit GEMM over the same pack: equal to a step of the split-bf16 storage)."""
-    from ppmstereo_amd.packing import pack_conv2
-    L = lib
-    P = BT * H * W
-    flow = (hash_normal((P, 2), 540) * 3.0).to(DEV)
-    wt = hash_normal((128, 2, 7, 7), 541) / math.sqrt(98)
-    bs = hash_normal((128,), 542) * 0.1
-    w1 = wt.permute(0, 2, 3, 1).reshape(128, 98, 1, 1)                              # k = tap * 2 + c, as the engine packs convf1
-    packed, bias, meta = pack_conv2(w1.to(DEV), bs.to(DEV), [98], [128])
-    assert meta["nk"] == 4 and meta["M"] == 128
-    out = L.SPTensor(P, 192, DEV)
-    L.check(L.load().ppms_flow_conv7(flow.data_ptr(), packed.data_ptr(), bias.data_ptr(), out.view(32, 128), BT, H, W, L.stream_ptr()))
-    torch.cuda.synchronize()
-    ref = F.relu(F.conv2d(flow.cpu().reshape(BT, H, W, 2).permute(0, 3, 1, 2), wt, bs, padding=3)).permute(0, 2, 3, 1).reshape(P, 128)
-    got = out.to_f32().cpu()
-    assert maxdiff(got[:, 32:160], ref) < 3e-5 * max(1.0, ref.abs().max().item())
-    assert (got[:, :32] == 0).all() and (got[:, 160:] == 0).all(), "channels outside the view must not be written"
-    patch, out2 = L.SPTensor(P, 128, DEV), L.SPTensor(P, 128, DEV)
-    L.check(L.load().ppms_flow_patch7(flow.data_ptr(), patch.view(), BT, H, W, L.stream_ptr()))
-    from ppmstereo_amd.engine import ConvOp, epilogue
-    d = L.Conv()
-    d.seg[0], d.nseg = patch.view(), 1
-    d.w, d.bias, d.T, d.H, d.W, d.kt, d.kh, d.kw, d.M, d.m_split = packed.data_ptr(), bias.data_ptr(), BT, H, W, 1, 1, 1, 128, 128
-    d.epi[0] = epilogue(act=L.ACT_RELU, n_valid=128, out_sp=out2.view())
-    ConvOp(d, [packed, bias, patch, out2], 2, nslice=1)()
-    torch.cuda.synchronize()
-    assert maxdiff(out2.to_f32().cpu(), ref) < 3e-5 * max(1.0, ref.abs().max().item())
-    assert maxdiff(out2.to_f32().cpu(), got[:, 32:160]) < 1e-5 * max(1.0, ref.abs().max().item())    # (one step of the split-bf16 storage)
-
-
 @pytest.mark.parametrize("T,H,W", [(3, 5, 9), (1, 4, 6), (5, 10, 16)])
 def test_tap_gather_sum(lib, T, H, W):
     """FlowHead3D.conv2 (256 -> 2, 3x3x3) = 1x1 GEMM to 54 channels + shifted sum; checked against conv3d."""
@@ -1236,42 +1202,6 @@ def test_pwchain_vs_unfused_layers(lib, P):
     x4 = F.gelu(x2g + lin(x2g, wp, bp))
     ref = F.gelu(lin(F.gelu(lin(x4, w3, b3)), w4, b4))
     assert maxdiff(out.to_f32(), ref) < 5e-5 * max(1.0, ref.abs().max().item())
-
-
-@pytest.mark.parametrize("BT,H,W", [(2, 9, 24), (3, 40, 144)])
-def test_pwchain_with_its_own_lookup_is_lookup_then_chain_bit_for_bit(lib, BT, H, W):
-    """Chain A with the correlation lookup in its input stage (ppms_pwchain_lookup: CorrBlock1D.__call__, corr.py:74-94, inside the chain's tile
-    staging) against ppms_corr_lookup + ppms_pwchain on the tensor in between: the same taps, the same chain -- equal bit for bit, on the small-map
-    kernel (432 pixels) and the large-map one (17 280 pixels, ragged last tile); the flow's SP copy (the motion features' last two channels) too."""
-    from ppmstereo_amd.corr import CorrBlock1D
-    from ppmstereo_amd.engine import PwChain
-    from ppmstereo_amd.packing import pack_conv2
-    L = lib
-    P = BT * H * W
-    f1, f2 = hash_normal((BT, 32, H, W), 560).to(DEV), hash_normal((BT, 32, H, W), 561).to(DEV)
-    pyr = CorrBlock1D(f1, f2).levels
-    flow = (hash_normal((P, 2), 562) * 6.0).to(DEV)                               # (reaches past both image borders)
-    mk = lambda co, ci, s: (hash_normal((co, ci, 1, 1), s) / math.sqrt(ci), hash_normal((co,), s + 1) * 0.1)
-    (w0, b0), (w2, b2) = mk(54, 36, 563), mk(36, 54, 565)
-    pk = lambda w, b, ci: pack_conv2(w.to(DEV), b.to(DEV), [ci], [64])
-    s64, t64 = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
-    s64[:36], t64[:36] = (hash_normal((36,), 567) * 0.5).to(DEV), (hash_normal((36,), 568) * 0.1).to(DEV)
-    layers = lambda: [(pk(w0, b0, 36), 54, False, None), (pk(w2, b2, 54), 36, True, (s64, t64))]
-    corr, out_a, out_b = L.SPTensor(P, 64, DEV), L.SPTensor(P, 64, DEV), L.SPTensor(P, 64, DEV)
-    fl_a, fl_b = L.SPTensor(P, 8, DEV), L.SPTensor(P, 8, DEV)
-    ptrs = (C.c_void_p * 4)(*[p.data_ptr() for p in pyr[:4]])
-    L.check(L.load().ppms_corr_lookup(ptrs, flow.data_ptr(), 1, None, corr.view().hi, corr.view().lo, 64, fl_a.view(2, 2).hi, fl_a.view(2, 2).lo, 8, BT, H, W,
-                                      L.stream_ptr()))
-    PwChain(corr.view(), out_a.view(), layers(), P, [])()
-    fused = PwChain(corr.view(), out_b.view(), layers(), P, [])
-    vb = fl_b.view(2, 2)
-    fused.lookup, fused.lookup_armed = (lambda: (ptrs, flow.data_ptr(), vb.hi, vb.lo, 8, BT, H, W)), True
-    corr.set_f32(torch.full((P, 64), 7.0, device=DEV))                             # the fused chain must not read its input tensor
-    fused()
-    torch.cuda.synchronize()
-    assert torch.equal(out_a.to_f32(), out_b.to_f32())
-    assert torch.equal(fl_a.to_f32(), fl_b.to_f32()) and maxdiff(fl_b.to_f32()[:, 2:4], flow) < 1e-3
-    assert out_a.to_f32()[:, :36].abs().max() > 0.1
 
 
 @pytest.mark.parametrize("T,n", [(5, 640), (3, 77), (2, 1000)])

@@ -216,7 +216,7 @@ def test_config5_quarter_scale_iteration_high_addresses_vs_oracle(model):
     with torch.cuda.device(DEV):
         eng.set_inp(d["inp"]), eng.set_net(d["net"]), eng.set_flow(d["flow"]), eng.set_mhs(d["mhs"])
         eng.begin(CorrBlock1D(d["fmap1"], d["fmap2"]).levels, model.att[2].packed(torch.device(DEV)))
-        eng.lookup(force=True)
+        eng.lookup()
         corr_last = eng.store_nchw(eng.CORR.view(0, 36), 36)[-1:].cpu()
         eng.motion_and_value()
         mf, val, mhs = eng.get_mf(), eng.get_value(), eng.get_mhs()

@@ -15,7 +15,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ppmstereo_amd import engine as _engine  # noqa: E402
 
-_MAP = dict(PPMS_CONV6="conv6", PPMS_CONV6_STREAM="conv6_stream", PPMS_LOOKUP_FUSED="lookup_fused", PPMS_FLOW_CONV7="flow_conv7", PPMS_CONV6_PAD2X="conv6_pad2x", PPMS_CONV5="conv5", PPMS_CONV5_SLICED="conv5_sliced", PPMS_CONV5_GEMM="conv5_gemm", PPMS_CONV6_GROUPED="conv6_grouped", PPMS_PWCHAIN="pwchain",
+_MAP = dict(PPMS_CONV6="conv6", PPMS_CONV6_STREAM="conv6_stream", PPMS_CONV6_PAD2X="conv6_pad2x", PPMS_CONV5="conv5", PPMS_CONV5_SLICED="conv5_sliced", PPMS_CONV5_GEMM="conv5_gemm", PPMS_CONV6_GROUPED="conv6_grouped", PPMS_PWCHAIN="pwchain",
             PPMS_SLICE="slices", PPMS_HOIST="hoist", PPMS_CONV5_PAD2X="conv5_pad2x", PPMS_CONVF2_UNSLICED="convf2_unsliced", PPMS_GEMM1="gemm1", PPMS_CONV5_M192="conv5_m192", PPMS_HID="hid_exact")
 for _env, _key in _MAP.items():
     if _env in os.environ:

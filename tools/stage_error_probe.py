@@ -46,7 +46,7 @@ def main():
             eng = blk.engine(T, h, w, DEV)
             eng.set_inp(g(d["inp"])), eng.set_net(g(d["net"])), eng.set_flow(g(d["flow"])), eng.set_mhs(g(d["mhs"]))
             eng.begin(CorrBlock1D(g(d["fmap1"]), g(d["fmap2"])).levels, model.att[ai].packed(DEV))
-            eng.lookup(force=True)
+            eng.lookup()
             rel("corr lookup", eng.store_nchw(eng.CORR.view(0, 36), 36), t["corr"])
             eng.motion_and_value()
             rel("mf", eng.get_mf(), t["mf"]), rel("value", eng.get_value(), t["value"])
