@@ -238,6 +238,19 @@ def test_conv_gemm_epilogues(lib, version):
     assert maxdiff(run(L, [x], wt, bs, k3, T, H, W, kind=L.EPI_GRU, aux=aux, z=z), (1 - z) * aux + z * torch.tanh(lin)) < 5e-5
 
 
+LARGE_MAP_CASES = [          # shapes of the large-map kernels' sweeps (x, y, 2-D, with a temporal extent), ragged tiles included
+    ("gru_1x15", 2, 6, 128, [128, 384], 256, (1, 1, 15)),
+    ("q_1x5", 1, 5, 128, [128, 64], 128, (1, 1, 5)),
+    ("3x3_m128", 3, 20, 32, [128, 128], 128, (1, 3, 3)),
+    ("3x3x3_m256", 4, 9, 64, [128], 256, (3, 3, 3)),
+    ("y_1x5x1", 2, 40, 32, [128, 32], 256, (1, 5, 1)),
+    ("y_w80", 1, 23, 80, [64], 128, (1, 5, 1)),
+    ("x_w80_1x5", 2, 7, 80, [64], 128, (1, 1, 5)),
+    ("3x3_w80_ragged", 2, 23, 80, [32, 32], 128, (1, 3, 3)),
+    ("3x3x3_odd", 3, 11, 50, [64], 128, (3, 3, 3)),
+]
+
+
 GEMM1_CASES = [
     # name, T,H,W, segs, cout, M-pad
     ("to_v_like", 2, 8, 32, [128], 128),
@@ -481,7 +494,7 @@ def test_conv_gemm5_sliced_vs_torch(lib, name, T, H, W, segs, cout, k3, nslice):
 
 
 @pytest.mark.parametrize("nbt", [5007, 5008])
-@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", CONV3_CASES + [("3x3_ragged_m256", 2, 13, 45, [48, 16], 190, (1, 3, 3)), ("x15_w24", 1, 9, 24, [32], 128, (1, 1, 15)),
+@pytest.mark.parametrize("name,T,H,W,segs,cout,k3", LARGE_MAP_CASES + [("3x3_ragged_m256", 2, 13, 45, [48, 16], 190, (1, 3, 3)), ("x15_w24", 1, 9, 24, [32], 128, (1, 1, 15)),
                                                    ("3x3x3_m128_T5", 5, 10, 40, [128], 128, (3, 3, 3)),
                                                    # GEMM mode (kh = kw = 1): 64- / 32-channel windows, the temporal taps as separate windows
                                                    ("t5_gemm_m256", 5, 20, 64, [128, 256], 256, (5, 1, 1)), ("1x1_m256_pad", 2, 13, 45, [256], 144, (1, 1, 1)),
