@@ -1,4 +1,4 @@
-"""Benchmark of the PPMStereo hot path on MI355X (contract: see the round prompt / DESIGN.md section 5).
+"""Benchmark of the PPMStereo hot path on MI355X (contract: see the round prompt / docs/LOG_r01_r05.md section 5).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python bench.py --gpus 8 --steps 10 --warmup 3          # no launcher around it: starts the 8 ranks itself (launch_ranks), exit code = theirs
@@ -10,7 +10,7 @@ uncertainty, QAM pick, pick-and-play memory attention, ConvGRU3D, heads, convex 
 outputs the loop consumes) are synthetic and resident in HBM before the timed region.
 
 N > 1, T = 5 (config 2): every rank runs its own replica of the clip (T=5 does not divide across ranks without changing
-the result -- DESIGN.md section 6), scaling "weak", value = N * pixels / max-over-ranks time.
+the result -- docs/LOG_r01_r05.md section 6), scaling "weak", value = N * pixels / max-over-ranks time.
 N > 1, T = 5: behind the replica measurement the same ranks run ONE frame-sharded window (--sharded-T 40 --sharded-iters 20 = BASELINE config 4), checked
 against the unsharded result on rank 0 first; it is reported under `sharded` / `sharded_check`, never in `value`.
 N > 1, --T divisible by N and >= 2 frames per rank (configs 4-5, e.g. --T 40): the window's frames are SHARDED over the

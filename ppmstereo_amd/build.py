@@ -31,7 +31,7 @@ HEADERS = ["common.h", "corr_lookup.h", "conv_epilogue.h", "conv5_asm.h", "conv6
 # with op_sel:[0,1] (low result = src0.lo op src1.hi -- the compiler picks that form freely, e.g. in the bilinear resize kernel) reads
 # src1.hi as 0 in lanes 48-63 whenever ANOTHER wave on the same SIMD is issuing MFMAs, and the engine runs MFMA kernels beside small
 # kernels on two streams.  Register-only reproducer: tools/pk_opsel_probe.py; evidence: profiles/r02_pk_opsel_probe.txt; static guard:
-# tools/check_no_packed_fp32.py (tests/test_host_logic.py); DESIGN.md section 5.  Sources listed in PACKED_FP32_SOURCES keep the packed forms.
+# tools/check_no_packed_fp32.py (tests/test_host_logic.py); docs/LOG_r01_r05.md section 5.  Sources listed in PACKED_FP32_SOURCES keep the packed forms.
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 EXTRA = [x for x in os.environ.get("PPMS_BUILD_DEFINES", "").split() if x]        # build-time A/B only, e.g. "-DPPMS_CONV5_TIMING"

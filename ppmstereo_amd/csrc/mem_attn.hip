@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void mem_attn_kernel(const bf16_t* __restri
 //    makes the workgroup raise a flag instead: the 32-query kernel, launched right after as a fix-up pass, recomputes
 //    exactly the flagged tiles with the classic online softmax and returns immediately everywhere else;
 //  * the softmax denominator comes out of the matrix pipe too: l += 1 * P with an all-ones A operand, i.e. the sum of exactly the
-//    bf16-rounded probabilities the numerator uses, accumulated the same way (the rounding of P then cancels
+//    bf16-rounded probabilities the numerator uses, accumulated the same way (docs/LOG_r01_r05.md section 4: the rounding of P then cancels
 //    to first order between numerator and denominator).
 //  * workgroups are renumbered so that the ~40 workgroups streaming one (clip, picked frame) K / V^T sit on ONE XCD (each XCD has
 //    its own L2; dealt round-robin every XCD would read all of K / V^T: 8x the fetch traffic).

@@ -36,7 +36,7 @@ Two levels of parallelism:
    be left in flight (``async_op``) while the compute stream goes on: RCCL runs it on its own stream, ``wait()`` makes the compute
    stream wait for it right where the data is read.  Sizes at 320x512, 1/4 scale, 5 frames per GPU: K 13 MB per rank once per
    scale, V 6.6 MB per rank and iteration, halos 2 x 15.7 MB ([h | x], split-bf16 = 4 B per value) + 2 x 5.2 MB (r*h) + small ones
-   per iteration.  Per-iteration schedule and its latency budget: DESIGN.md section 6.
+   per iteration.  Per-iteration schedule and its latency budget: docs/LOG_r01_r05.md section 6.
 """
 from __future__ import annotations
 

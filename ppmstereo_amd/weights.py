@@ -195,7 +195,7 @@ def _gen(name: str, shape: Tuple[int, ...], seed: int) -> np.ndarray:
         # SST block, LoFTR layers (attention.py:186-190): every layer adds norm2(mlp(...)) to the feature stream, so with unit LayerNorm
         # weights the 8 self / cross layers of the block take O(1) features to rms ~3.3 and the 1/16 correlation volume (which is
         # quadratic in them) to values of several hundred -- far from a trained network's operating point and, through the bf16 ulp of
-        # the attention operands, the reason the whole-model parity tests could only be sanity bounds.  A quarter
+        # the attention operands, the reason the whole-model parity tests could only be sanity bounds (docs/LOG_r01_r05.md section 4).  A quarter
         # of that keeps the block's output at the magnitude of its input.
         return (0.25 * (1.0 + 0.1 * x) if leaf == "weight" else 0.005 * x).astype(np.float32)
     if ("norm" in name and leaf == "weight") or (name.startswith("cnet.") and leaf == "weight" and len(shape) == 1):

@@ -156,7 +156,7 @@ def test_frame_sharded_loop_eight_ranks(tmp_path, T, blocks):
     """World size 8 = the node BASELINE configs 4-5 are quoted on: T = 40 -> f = 5 frames per rank (config 4's exact split: six interior
     ranks, seven peers in every direct all-gather, the top-5 pick over 40 frames computed identically on all eight ranks) and T = 16 -> f = 2
     = the halo depth with the 1/16 block's time-attention gather.  gloo on the CPU, oracle math per rank; every rank's block against the
-    unsharded loop.  (The RCCL transport of the same calls is unmeasured on hardware: DESIGN.md section 6.)"""
+    unsharded loop.  (The RCCL transport of the same calls is unmeasured on hardware: docs/LOG_r01_r05.md section 6.)"""
     out = str(tmp_path / "s8.pt")
     mp.spawn(_shard_worker, args=(8, _free_port(), out, False, None, T, blocks), nprocs=8, join=True)
     _check_against_unsharded([torch.load(out + f".{r}") for r in range(8)], T, False, blocks)

@@ -302,7 +302,7 @@ def test_stride2_conv_as_space_to_depth_conv(k, pad, cin, cout, h, w):
 
 
 def test_library_holds_no_packed_fp32_arithmetic():
-    """The hardware condition of DESIGN.md section 5: on gfx950 a v_pk_add/mul/fma_f32 whose op_sel is [0,1] (low result from src0.lo and
+    """The hardware condition of docs/LOG_r01_r05.md section 5: on gfx950 a v_pk_add/mul/fma_f32 whose op_sel is [0,1] (low result from src0.lo and
     src1.hi -- a form the compiler picks freely) reads src1.hi as 0 in lanes 48-63 while another wave on the same SIMD issues MFMAs, and the
     engine does run MFMA kernels beside small kernels on two streams.  The library is therefore built without packed fp32 formation; this
     test disassembles every gfx950 code object of the shipped libppms.so and checks that none of these instructions is in it."""

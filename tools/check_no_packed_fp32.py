@@ -1,4 +1,4 @@
-"""Static guard for the packed-fp32 hardware condition: disassembles every gfx950 code object inside
+"""Static guard for the packed-fp32 hardware condition (docs/LOG_r01_r05.md section 5): disassembles every gfx950 code object inside
 ppmstereo_amd/libppms.so and fails if a v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 instruction is present.
 usage: tools/check_no_packed_fp32.py [library.so]   (also imported by tests/test_host_logic.py)"""
 import os

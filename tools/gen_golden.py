@@ -29,7 +29,7 @@ sys.path.insert(0, REF)
 # published algorithm is restated here: UnfoldNd(kernel_size, padding)(x) is torch.nn.Unfold generalised to N spatial
 # dims -- for x (N, C, T, H, W) it returns (N, C * kt*kh*kw, T*H*W) with output channel c * (kt*kh*kw) + k, k = (kt, kh, kw)
 # row-major, positions row-major, zero padding, stride 1, dilation 1.  The convex_upsample_3d fixtures are pinned to THIS
-# restatement.
+# restatement (docs/LOG_r01_r05.md section 4).
 _unf = types.ModuleType("unfoldNd")
 
 

@@ -1,4 +1,4 @@
-// The packed-fp32 finding on the kernel it was found in: the library's bilinear resize, compiled here WITH
+// The packed-fp32 finding (docs/LOG_r01_r05.md section 5) on the kernel it was found in: the library's bilinear resize, compiled here WITH
 // packed fp32 formation (the compiler default), in three forms:
 //   variant 0: the kernel as it is in small_ops.hip;
 //   variant 1: the same, plus the four taps it loaded written to a debug buffer (were the LOADED values wrong, or the arithmetic?);

@@ -1,4 +1,4 @@
-// Minimal reproducer attempt for the packed-fp32 finding: does a wave's v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+// Minimal reproducer attempt for the packed-fp32 finding (docs/LOG_r01_r05.md section 5): does a wave's v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
 // return wrong values while ANOTHER stream's MFMA-streaming kernel shares its SIMD?
 //   kernel A (victim): every thread evaluates a short chain of packed fp32 ops (or the same math with scalar ops, VAR = 0) on values
 //                      derived from its index and writes the result;

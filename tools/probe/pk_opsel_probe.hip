@@ -1,4 +1,4 @@
-// Minimal form of the packed-fp32 finding (tools/probe/bilinear_pk_probe.hip narrowed it to the swizzled packed add):
+// Minimal form of the packed-fp32 finding (docs/LOG_r01_r05.md section 5; tools/probe/bilinear_pk_probe.hip narrowed it to the swizzled packed add):
 // a register-only victim -- no loads -- evaluates one VOP3P fp32 instruction per round on values derived from the thread index and checks
 // it against scalar arithmetic.  It keeps to < 24 VGPRs so that one of its waves still fits on a SIMD beside two 240-register waves of the
 // library's conv kernels (the high-register probes of earlier rounds never shared a SIMD with them, which is why they saw nothing).

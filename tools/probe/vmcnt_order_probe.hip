@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void order_kernel(const float* __restrict__ sr
     if (gap == 12345) out[idx] += v0 + v1 + v3;        // keep the other loads alive
 }
 
-// The failing pattern of the packed-fp32 finding, instruction for instruction: loads 0..3 land in the register
+// The failing pattern of the packed-fp32 finding (docs/LOG_r01_r05.md section 5), instruction for instruction: loads 0..3 land in the register
 // pairs (l0, l3) and (l2, l1); behind vmcnt(1) a v_pk_mul_f32 reads the pair (l2, l1), behind vmcnt(0) another reads (l0, l3).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __global__ __launch_bounds__(256) void pk_after_wait_kernel(const float* __restrict__ src, float* __restrict__ out, long n, int W, int scalar_ops) {
