@@ -40,8 +40,10 @@ FLAGS = COMMON + NO_PK + EXTRA
 
 
 def _digest() -> str:
-    """sha256 over the flags and exactly the files that go into the library (editor temp files do not count)."""
-    h = hashlib.sha256(" ".join(FLAGS + list(PACKED_FP32_SOURCES)).encode())
+    """sha256 over the flags and exactly the files that go into the library (editor temp files do not count).  The checkout's own location is
+    taken out of the -I paths first: the library built here travels with the tree to the GPU box, where the tree sits under another path -- with
+    absolute paths in the digest every fresh box found the stamp "stale" and spent its first minute recompiling identical sources (rounds 1-5)."""
+    h = hashlib.sha256(" ".join(x.replace(ROOT, "$ROOT") for x in FLAGS + list(PACKED_FP32_SOURCES)).encode())
     for f in SOURCES + HEADERS:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(os.path.basename(f).encode() + fh.read())
