@@ -48,6 +48,8 @@ struct Geo6 {
     int lz0;                 // windows whose index inside the tap is >= lz0 hold bf16-exact activations (all-zero lo plane): hi x lo products skipped
     int npieces;             // DMA pieces per thread and window that carry rows (<= conv6_np(WH), which is what every window issues)
     int wbytes;              // bytes of one window buffer (conv6_np(WH) * 4 KiB)
+    int ks;                  // 1: the K-split form of M = 128 (below); nchunk / lz0 then count ONE K group's windows per tap, *_full all of them
+    int nchunk_full, lz0_full;
     int64_t P;
 #ifdef PPMS_CONV6_TIMING
     long long* dbg;
@@ -105,6 +107,9 @@ constexpr unsigned CONV6_OOB = 0xFFFFFFF0u;
 #define CONV6_SWITCH_SLACK
 #define CONV6_PRE_BARRIER
 #endif
+#ifndef CONV6_KSPLIT
+#define CONV6_KSPLIT 1         // -DCONV6_KSPLIT=0: M = 128 convolutions always in the two-pixel-halves layout (A/B builds)
+#endif
 #include "conv6_asm.h"
 
 // MB: 16-cout blocks per wave -- 4 (M = 256, 128) or 3 (M = 192); CR: rows of a window column = 16 + y halo (16, 18, 20)
@@ -114,7 +119,14 @@ constexpr unsigned CONV6_OOB = 0xFFFFFFF0u;
 // (the two 128 -> 128 (1,1,5) tails of convz1 / convr1, ppmtereo_update.py:254-312, as ONE launch in the M = 256 wave layout instead of two M = 128
 // launches with half the work per fixed cost).  Waves 0-1 own group 0's couts, waves 2-3 group 1's; every window exists twice -- the same patch of
 // segment 0 and of segment 1, 9 DMA pieces each -- and a wave reads its group's copy.
-template <int MB, int CR, bool STREAM = false, bool GRP = false>
+// KS: the K-SPLIT form of an M = 128 convolution (round 6).  In the plain M = 128 layout a wave owns 64 couts x 7 (6) pixel blocks: 84 MFMAs per k32-step, a
+// step of 0.7 us -- shorter than the L2 round trip of the next step's weight fragments, with a step's fixed costs (waits, address upkeep, window switch)
+// spread over half the work of an M = 256 step.  Here the two wave PAIRS split K instead of the pixels: waves 0-1 take one half of the windows of every tap,
+// waves 2-3 the other half (each half: the same share of windows with and without a lo plane, so the two-phase loop stays in lockstep), every wave 64 couts x
+// all 13 pixel blocks -- the M = 256 step body on half as many steps.  Both halves' windows are resident like GRP's two images.  Behind the loop the pairs
+// exchange the partial sums of the pixel blocks the other one finishes (through LDS, one barrier) and the epilogue runs in the two-pixel-halves layout.
+// The sum of a cout is (first half of K) + (second half of K): a fixed order, but not the plain layout's -- results agree to fp32 rounding, not bit for bit.
+template <int MB, int CR, bool STREAM = false, bool GRP = false, bool KS = false>
 __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const Geo6 g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ppms_conv& p = pv;                       // by value in the kernel arguments (see conv_gemm2.hip)
@@ -124,11 +136,17 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     const int li = lane & 15, lkg = lane >> 4;                    // fragment roles: pixel (cout) of the block, k-group of 8 channels
     // wave roles: M = 256 / 192: wave w owns cout blocks [w MB, w MB + MB) and all 13 pixel blocks; M = 128: (wm, wn) = (w & 1, w >> 1), 64 couts x
     // pixel blocks [0, 7) or [7, 13)
-    const bool split = p.M == 128;
-    const int wm = split ? (wave & 1) : wave;
+    constexpr bool DUAL = GRP || KS;               // two window images per window buffer, one per wave pair
+    const bool split = p.M == 128 && !KS;
+    const int wm = (split || KS) ? (wave & 1) : wave;
     const int wn = split ? (wave >> 1) : 0;
+    const int kg = KS ? (wave >> 1) : 0;           // KS: this wave's K group
     const int nbw = split ? (wn ? 6 : 7) : NBT6;
     const int blk0 = wn ? 7 : 0;
+    // KS: K group kg's c-th window of a tap is window gchunk(kg, c) of the tap in the descriptor's order (phase 0: the windows with a lo plane, phase 1: the others)
+    auto gchunk = [&](int grp, int c) { return c < g.lz0 ? grp * g.lz0 + c : g.lz0_full + grp * (g.nchunk - g.lz0) + (c - g.lz0); };
+    auto wchunk = [&](int c) { return KS ? gchunk(kg, c) : c; };          // window index the WEIGHTS of this wave's step are stored under
+    const int ncf = KS ? g.nchunk_full : g.nchunk;
     // workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one; each XCD has its own L2): XCD k gets the k-th eighth of the tile
     // list, so that the x / y neighbours whose windows overlap in their halo columns fetch them through ONE L2 (placement is a speed hint only)
     int tile = blockIdx.x;
@@ -153,9 +171,9 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     // per piece and input segment ONE register: the byte offset of the lane's 16 B from the window's base (= the segment's hi plane at the window's
     // frame shift and first channel): pixel * bytes per pixel + 16-B unit inside the window's channels (+ the distance of the lo plane); padding:
     // an offset beyond the buffer resource's range, which reads zeros.  (The host checks that every offset fits: conv6_offsets_fit.)
-    constexpr int NPG = GRP ? 9 : conv6_np(CR);        // pieces per thread of ONE window image
-    constexpr int NP = GRP ? 2 * NPG : NPG;            // pieces per thread and window (GRP: group 0's image, then group 1's)
-    constexpr unsigned GBYTES = NPG * NT6 * 16;        // GRP: distance of group 1's window image
+    constexpr int NPG = DUAL ? 9 : conv6_np(CR);       // pieces per thread of ONE window image
+    constexpr int NP = DUAL ? 2 * NPG : NPG;           // pieces per thread and window (DUAL: group 0's image, then group 1's)
+    constexpr unsigned GBYTES = NPG * NT6 * 16;        // DUAL: distance of group 1's window image
     const int ld0 = p.seg[0].ld * 2, ld1 = p.seg[p.nseg - 1].ld * 2;          // bytes between pixels
     const char* const sp0h = (const char*)p.seg[0].hi;
     const char* const sp1h = (const char*)p.seg[p.nseg - 1].hi;
@@ -202,6 +220,20 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             for (int i = 0; i < NPG; ++i) off[i] = off0[i], off[NPG + i] = off1[i];
             return;
         }
+        if constexpr (KS) {                        // the two K groups' windows of (tap kz, local window `chunk`)
+            const int gc0 = gchunk(0, chunk), gc1 = gchunk(1, chunk);
+            const int s0 = gc0 >= g.n0 ? 1 : 0, s1 = gc1 >= g.n0 ? 1 : 0;
+            const uint64_t b0 = (uint64_t)(uintptr_t)((s0 ? sp1h : sp0h) + (int64_t)dt * HW * (s0 ? ld1 : ld0) + (gc0 - (s0 ? g.n0 : 0)) * g.cpw * 2);
+            const uint64_t b1 = (uint64_t)(uintptr_t)((s1 ? sp1h : sp0h) + (int64_t)dt * HW * (s1 ? ld1 : ld0) + (gc1 - (s1 ? g.n0 : 0)) * g.cpw * 2);
+            unsigned w0 = __builtin_amdgcn_readfirstlane((unsigned)b0), w1 = __builtin_amdgcn_readfirstlane((unsigned)(b0 >> 32) & 0xffffu);
+            unsigned w2 = __builtin_amdgcn_readfirstlane((unsigned)b1), w3 = __builtin_amdgcn_readfirstlane((unsigned)(b1 >> 32) & 0xffffu);
+            asm volatile("s_nop 4" : "+s"(w0), "+s"(w1), "+s"(w2), "+s"(w3));
+            d_srd[0] = w0, d_srd[1] = w1, d_srd1[0] = w2, d_srd1[1] = w3;
+            d_buf = buf;
+#pragma unroll
+            for (int i = 0; i < NPG; ++i) off[i] = s0 ? off1[i] : off0[i], off[NPG + i] = s1 ? off1[i] : off0[i];
+            return;
+        }
         const int sg = (chunk >= g.n0) ? 1 : 0;
         const int c0 = (chunk - (sg ? g.n0 : 0)) * g.cpw * 2;                  // byte offset of the window's first channel
         const int64_t shift = (int64_t)dt * HW * (sg ? ld1 : ld0) + c0;
@@ -224,7 +256,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
     };
     // (round 5 spaced the pieces >= 4 MFMAs apart on the belief that an LDS-DMA reads M0 / its offset register late; the round-6 probe refutes that --
     //  what bit was the VALU-written resource, see dma_setup -- but the spacing stays: a piece costs ~60 issue cycles, one per MFMA group hides it)
-    auto dma_piece = [&](int i) { dma16_6(off[i], (GRP && i >= NPG) ? d_srd1 : d_srd, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16))); };
+    auto dma_piece = [&](int i) { dma16_6(off[i], (DUAL && i >= NPG) ? d_srd1 : d_srd, wave_dst + (unsigned)(d_buf * g.wbytes + i * (NT6 * 16))); };
     // the pieces of a window leave in the first TWO k-steps of the window before it: PPS0 in the first, PPS1 in the second
     constexpr int PPS0 = (NP + 1) / 2, PPS1 = NP / 2;
 
@@ -243,7 +275,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 
     // ---- B-operand addressing: row = (blk0 + n) * CR + tap offset + li; chunk position (plane * 4 + lkg) ^ ((li + tap y) & 6); the n * CR * 128
     // part is an immediate of the read, hi and lo fragments differ in bit 6 ---------------------------------------------------------------
-    const unsigned grp_off = GRP ? (unsigned)(wave >> 1) * GBYTES : 0u;          // GRP: this wave's group's window image
+    const unsigned grp_off = DUAL ? (unsigned)(wave >> 1) * GBYTES : 0u;         // DUAL: this wave pair's window image
     auto lane_addr = [&](int tyo) { return lds0 + grp_off + (unsigned)(blk0 * CR * 128 + li * 128) + (unsigned)(((lkg ^ ((li + tyo) & 6)) & 7) << 4); };
 
     // temporal taps outside the readable frames contribute zeros: skip them (contiguous kz range)
@@ -287,7 +319,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         const int sw_cur = sw;                                                                                                     \
         const bool issue = sw < 2 && nxkz >= 0; /* the first two steps of a window carry the DMA of the next window (other buffer) */ \
         if (issue && sw == 0) dma_setup(nxkz, nxch, w ^ 1);                                                                        \
-        const int ksn = last ? (ckz * g.nchunk + cch) * g.nsweep + sw : (wend ? (nxkz * g.nchunk + nxch) * g.nsweep : (ckz * g.nchunk + cch) * g.nsweep + sw + 1); \
+        const int ksn = last ? (ckz * ncf + wchunk(cch)) * g.nsweep + sw : (wend ? (nxkz * ncf + wchunk(nxch)) * g.nsweep : (ckz * ncf + wchunk(cch)) * g.nsweep + sw + 1); \
         const char* sbn = abase + (int64_t)ksn * astep;                                                                            \
         conv6_step<MB, NBW, CR, SKIP>(acc, areg[U], areg[(U) ^ 1], ring, bh, bh ^ 64u, bhn, bhn ^ 64u, avoff0, avoff1, sbn, [&](int K) { \
             constexpr int SL = conv6_shape<MB, NBW, SKIP>::SLOTS;                                                                    \
@@ -348,7 +380,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
             dma_piece(i);                                                                                                          \
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory"); /* 64 cycles between two pieces */         \
         }                                                                                                                          \
-        load_a(areg[0], (ckz * g.nchunk + cch) * g.nsweep);                                                                        \
+        load_a(areg[0], (ckz * ncf + wchunk(cch)) * g.nsweep);                                                                     \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                           \
         __builtin_amdgcn_s_barrier();                                                                                              \
         int sw = 0, swx = 0, off = 0, tyo = 0, w = 0;                                                                               \
@@ -439,7 +471,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         }
     } else {
         if (nbw == NBT6) CONV6_LOOP(13)
-        else if constexpr (MB == 4 && !GRP) {      // (M = 128: the two pixel halves of the tile)
+        else if constexpr (MB == 4 && !DUAL) {     // (M = 128: the two pixel halves of the tile)
             if (nbw == 7) CONV6_LOOP(7) else CONV6_LOOP(6)
         }
     }
@@ -451,6 +483,40 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 #undef CONV6_PHASE1
 #undef CONV6_STEP1
     __syncthreads();                               // the window buffers become the epilogue's staging areas
+    int e_nbw = nbw, e_blk0 = blk0;                // the epilogue's layout: pixel blocks [e_blk0, e_blk0 + e_nbw) of the tile are this wave's to finish
+    if constexpr (KS) {
+        // K groups -> pixel halves.  Wave (wm, kg) holds the partial sums of ALL 13 pixel blocks over its half of K; it finishes blocks 0..6 (kg = 0) or
+        // 7..12 (kg = 1) and hands the other blocks' partial sums to its partner (wm, kg ^ 1): 16 B per lane, [block][m][lane], conflict-free
+        constexpr int XW = 7 * 4 * 64 * 4;                              // floats per wave: 7 blocks x 4 cout blocks x 64 lanes x 4 (28 KiB)
+        float* xs = (float*)smem + wave * XW;
+        const float* xr = (const float*)smem + (wave ^ 2) * XW;
+        if (kg == 0) {
+#pragma unroll
+            for (int nl = 0; nl < 6; ++nl)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) *(f32x4*)(xs + ((nl * 4 + m) * 64 + lane) * 4) = acc[m][7 + nl];
+        } else {
+#pragma unroll
+            for (int nl = 0; nl < 7; ++nl)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) *(f32x4*)(xs + ((nl * 4 + m) * 64 + lane) * 4) = acc[m][nl];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int nl = 0; nl < 7; ++nl)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m][nl] += *(const f32x4*)(xr + ((nl * 4 + m) * 64 + lane) * 4);
+        } else {
+#pragma unroll
+            for (int nl = 0; nl < 6; ++nl)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m][7 + nl] += *(const f32x4*)(xr + ((nl * 4 + m) * 64 + lane) * 4);
+        }
+        __syncthreads();                           // (the staging patches below overlay the exchange area)
+        e_nbw = kg ? 6 : 7;
+        e_blk0 = kg ? 7 : 0;
+    }
 
     // ---- epilogue: accumulators (lane: pixel li, couts 16 m + 4 lkg ..) -> wave-private LDS patch [pixel][16 MB couts] -> 8 couts of one
     // pixel per lane, the shared row epilogue (conv_epilogue.h).  Two passes of <= 7 pixel blocks.
@@ -473,17 +539,18 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 #pragma unroll
         for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(b8[j]));       // landed before the row loops (vmcnt counts loads and stores in one order)
     }
-    auto do_pass = [&](auto pass_tag) {
-        constexpr int pass = decltype(pass_tag)::value;
+    // AB: accumulator block of the wave's first block (0; KS, K group 1: 7 -- its accumulators are indexed by the tile's blocks, its blocks to finish are 7..12)
+    auto do_pass = [&](auto pass_tag, auto ab_tag) {
+        constexpr int pass = decltype(pass_tag)::value, AB = decltype(ab_tag)::value;
         constexpr int pb0 = pass * 7;                                   // first block (wave-local) of the pass
-        const int npb = (nbw - pb0) < 7 ? (nbw - pb0) : 7;              // blocks in this pass (<= 0: none)
+        const int npb = (e_nbw - pb0) < 7 ? (e_nbw - pb0) : 7;          // blocks in this pass (<= 0: none)
         if (npb > 0) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int nl = 0; nl < 7; ++nl) {
             if (pb0 + nl < 13 && nl < npb) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m) *(f32x4*)(stg + (nl * 16 + li) * LD6 + m * 16 + 4 * lkg) = acc[m][pb0 + nl < 13 ? pb0 + nl : 0];
+                for (int m = 0; m < MB; ++m) *(f32x4*)(stg + (nl * 16 + li) * LD6 + m * 16 + 4 * lkg) = acc[m][AB + pb0 + nl < 13 ? AB + pb0 + nl : 0];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -505,7 +572,7 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
 #pragma unroll
                     for (int gi = 0; gi < G; ++gi) {
                         const int prow = (it0 + gi) * 8 + (lane >> 3);
-                        const int px = x0 + blk0 + pb0 + (prow >> 4), py = y0 + (prow & 15);
+                        const int px = x0 + e_blk0 + pb0 + (prow >> 4), py = y0 + (prow & 15);
                         okg[gi] = mine && it0 + gi < nit && px < W && py < H;
                         pixg[gi] = (int64_t)(tf * H + py) * W + px;
                         if (okg[gi]) row8_fetch<CLS>(e, pixg[gi], cl, aux[gi]);
@@ -546,8 +613,14 @@ __global__ __launch_bounds__(NT6, 1) void conv6_kernel(const ppms_conv pv, const
         }
         }
     };
-    do_pass(std::integral_constant<int, 0>{});
-    do_pass(std::integral_constant<int, 1>{});
+    using Z0 = std::integral_constant<int, 0>;
+    if constexpr (KS) {
+        if (kg == 0) do_pass(Z0{}, Z0{});
+        else do_pass(Z0{}, std::integral_constant<int, 7>{});
+    } else {
+        do_pass(Z0{}, Z0{});
+        do_pass(std::integral_constant<int, 1>{}, Z0{});
+    }
     CONV6_STAMP(3)
 }
 
@@ -592,6 +665,19 @@ static bool plan6(const ppms_conv* d, Geo6& g) {
     g.npieces = (rows * 8 + NT6 - 1) / NT6;
     g.wbytes = (stream ? 7 : conv6_np(g.WH)) * NT6 * 16;
     g.P = (int64_t)d->T * d->H * d->W;
+    g.ks = 0, g.nchunk_full = nchunk, g.lz0_full = g.lz0;
+    // K-split form of M = 128 (the kernel's KS parameter): an even split of the windows with and of those without a lo plane over the two wave pairs, a
+    // window image of <= 9 pieces (two images per buffer: 144 KiB), and -- as for the plain layout -- an even number of phase-0 steps per K group
+    if (CONV6_KSPLIT && d->M == 128 && !grouped && !stream && g.npieces <= 9 && (g.WH == 16 || g.WH == 18 || g.WH == 20) && g.nsweep >= 2 && nchunk % 2 == 0 &&
+        nchunk >= 4) {
+        int lz = g.lz0;
+        if (lz < nchunk && ((lz % 2) || ((nchunk - lz) % 2) || (((lz / 2) * g.nsweep) & 1))) lz = nchunk;      // uneven phases: every product is computed
+        g.ks = 1;
+        g.nchunk_full = nchunk, g.lz0_full = lz;
+        g.nchunk = nchunk / 2, g.lz0 = lz / 2;
+        g.wbytes = 2 * 9 * NT6 * 16;
+        return true;
+    }
     if (grouped) {
         g.wbytes = 2 * 9 * NT6 * 16;
         return g.WH == 16 && g.npieces <= 9 && g.nsweep >= 2;
@@ -695,6 +781,9 @@ extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, vo
         (void)hipFuncSetAttribute((const void*)conv6_kernel<4, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv6_kernel<3, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)conv6_kernel<4, 16, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv6_kernel<4, 16, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv6_kernel<4, 18, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv6_kernel<4, 20, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     });
 #ifdef PPMS_CONV6_TIMING
     g.dbg = g_conv6_dbg;
@@ -702,6 +791,10 @@ extern "C" int ppms_conv_gemm6(const ppms_conv* d, const ppms_conv* dev_desc, vo
 #define CONV6_GO(MBV, CRV) hipLaunchKernelGGL((conv6_kernel<MBV, CRV>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g)
     if (d->groups == 2) {
         hipLaunchKernelGGL((conv6_kernel<4, 16, false, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+    } else if (g.ks) {
+        if (g.WH == 16) hipLaunchKernelGGL((conv6_kernel<4, 16, false, false, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+        else if (g.WH == 18) hipLaunchKernelGGL((conv6_kernel<4, 18, false, false, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
+        else hipLaunchKernelGGL((conv6_kernel<4, 20, false, false, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
     } else if (g.mode == 4) {
         if (d->M == 192) hipLaunchKernelGGL((conv6_kernel<3, 16, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);
         else hipLaunchKernelGGL((conv6_kernel<4, 16, true>), dim3(ntiles), dim3(NT6), lds, (hipStream_t)stream, *d, g);

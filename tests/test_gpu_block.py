@@ -472,7 +472,7 @@ def test_test_mode_drops_only_dead_work(model):
 
 def test_grouped_gru_tails_do_not_change_the_cascade(model):
     """engine.TUNING["conv6_grouped"]: the two (1,1,5) tails of convz1 / convr1 as ONE grouped conv_gemm6 launch (ppms_conv.groups = 2) or as two launches on
-    two streams -- the same k order per cout, hence the same bits, at config 2's size (where conv_gemm6 serves the 1/4 scale)."""
+    two streams -- the same sums up to fp32 rounding, at config 2's size (where conv_gemm6 serves the 1/4 scale)."""
     from ppmstereo_amd import engine as E
     T, H, Wd = 5, 320, 512
     feats = {k: v.to(DEV) for k, v in synth_cascade_feats(T, H, Wd).items()}
@@ -496,7 +496,8 @@ def test_grouped_gru_tails_do_not_change_the_cascade(model):
     grouped = run(conv6_grouped=True)
     two = run(conv6_grouped=False)
     assert grouped[2] and not two[2], "the switch must select the launch plan of the 1/4 scale"
-    assert torch.equal(grouped[0], two[0]) and torch.equal(grouped[1], two[1])
+    # (one pass over K in the grouped launch, two K halves added in the K-split single launches: fp32 rounding apart, amplified by two iterations)
+    assert (grouped[0] - two[0]).abs().max().item() < 2e-4 and (grouped[1] - two[1]).abs().max().item() < 2e-4
 
 
 def test_attention_is_a_convex_combination(model):

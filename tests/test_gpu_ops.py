@@ -676,7 +676,8 @@ def test_conv_gemm6_three_cout_blocks_vs_torch(lib, name, T, H, W, segs, cout, k
 def test_conv_gemm6_skips_products_with_a_zero_lo_plane(lib, name, T, H, W, segs, cout, k3, lz):
     """ppms_conv.lo_zero_from on conv_gemm6: the windows whose lo plane is all zero run in a second phase of the K loop whose step body has no
     hi x lo MFMAs.  Same bits as the full product where both visit the windows in the same order (one temporal tap); with temporal taps the
-    two-phase order (all full windows of every tap, then all skipped ones) sums in another order than the one-phase loop: equal to fp32 rounding."""
+    two-phase order (all full windows of every tap, then all skipped ones) sums in another order than the one-phase loop, and so does the K-split form
+    of M = 128 (each wave pair takes half of the windows with and half of those without a lo plane): equal to fp32 rounding."""
     P = T * H * W
     xs = [hash_normal((P, c), 100 + i) for i, c in enumerate(segs)]
     cin = sum(segs)
@@ -689,9 +690,9 @@ def test_conv_gemm6_skips_products_with_a_zero_lo_plane(lib, name, T, H, W, segs
     m_pad = 128 if cout <= 128 else 192 if cout <= 192 else 256
     full = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, m_pad=m_pad)
     skip = _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, m_pad=m_pad, lo_zero_from=lz)
-    if k3[0] == 1:
+    if k3[0] == 1 and m_pad != 128:
         assert torch.equal(full, skip), name
-    else:
+    else:        # (M = 128 with a spatial sweep runs K-split: the two wave pairs' shares of the windows depend on where the zero-lo windows begin)
         assert maxdiff(full, skip) < 1e-5 * max(1.0, ref.abs().max().item()), name
     assert torch.equal(skip, _run_conv(lib, xs, wt, bs, k3, T, H, W, version=8, m_pad=m_pad, lo_zero_from=lz)), "bit-reproducible"
     assert maxdiff(skip, ref) < 3e-5 * max(1.0, ref.abs().max().item()), name
@@ -784,8 +785,8 @@ def test_conv_gemm6_two_epilogue_halves(lib):
 def test_conv_gemm6_grouped_two_tails_in_one_launch(lib, T, H, W, kw):
     """ppms_conv.groups = 2: the two 128 -> 128 (1,1,5) tails of convz1 / convr1 (ppmtereo_update.py:254-312) as ONE conv_gemm6 launch -- segment 0 (the
     z branch's gelu output) feeds couts 0..127 with a sigmoid -> fp32 epilogue, segment 1 (the r branch's) feeds couts 128..255 with the r * h epilogue --
-    against torch conv3d of each tail, and BIT FOR BIT against the two separate M = 128 launches (the same k order per cout); the other convolution
-    entry points refuse a grouped descriptor."""
+    against torch conv3d of each tail and against the two separate M = 128 launches (fp32 rounding apart: those run K-split); bit-reproducible; the other
+    convolution entry points refuse a grouped descriptor."""
     from ppmstereo_amd.engine import ConvOp, epilogue
     from ppmstereo_amd.packing import pack_conv6, pack_conv6_grouped
     L = lib
@@ -822,7 +823,8 @@ def test_conv_gemm6_grouped_two_tails_in_one_launch(lib, T, H, W, kw):
         d1.epi[0] = e_
         ConvOp(d1, [x_, p1, b1, Z2, RH2, ht], 8)()
     torch.cuda.synchronize()
-    assert torch.equal(Z, Z2) and torch.equal(RH.data, RH2.data), "the grouped launch must reproduce the two single launches bit for bit"
+    # (the single M = 128 launches run K-split -- (first half of K) + (second half) per cout --, the grouped launch sums K in one pass: fp32 rounding apart)
+    assert maxdiff(Z, Z2) < 1e-6 and maxdiff(RH.to_f32(), RH2.to_f32()) < 1e-5 * max(1.0, h.abs().max().item())
     # repeatable, and refused elsewhere
     Zc = Z.clone()
     ConvOp(d, [zt, rt, ht, packed, b, Z, RH], 8)()
